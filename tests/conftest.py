@@ -1,0 +1,36 @@
+"""pytest configuration: registers the ``gpu`` marker and shared helpers."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def random_scene(n_walls: int, seed: int = 1234):
+    """Layout of Scene.random_uniform_scene (reference scene.py:718-733) with a NumPy PRNG
+    (jax.random is unavailable): pts[0] = tx, wall i = pts[1+2i : 3+2i]."""
+    pts = np.random.default_rng(seed).random((1 + 2 * n_walls + 1, 2), dtype=np.float32)
+    tx = pts[0].copy()
+    walls = pts[1 : 1 + 2 * n_walls].reshape(n_walls, 2, 2).copy()
+    return tx, walls
+
+
+def unit_grid(n: int, m: int | None = None):
+    m = n if m is None else m
+    x = np.linspace(0.0, 1.0, n).astype(np.float32)
+    y = np.linspace(0.0, 1.0, m).astype(np.float32)
+    return np.meshgrid(x, y)
+
+
+@pytest.fixture(scope="session")
+def seed() -> int:
+    return 1234
