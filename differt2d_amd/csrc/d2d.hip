@@ -1,0 +1,478 @@
+// libd2d.so -- host side of the C ABI declared in include/d2d.h (HIP runtime, gfx950 only).
+// No CPU fallback lives here: every sweep is a kernel launch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/d2d.h"
+#include "d2d_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(D2D_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n && p) return D2D_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        if (count == 0) count = 1;
+        HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+        return D2D_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// lax.integer_pow lowering (square and multiply), fp32
+float integer_pow(float x, int n) {
+    if (n == 0) return 1.0f;
+    float acc = 0.0f;
+    bool have = false;
+    while (n > 0) {
+        if (n & 1) {
+            acc = have ? acc * x : x;
+            have = true;
+        }
+        n >>= 1;
+        if (n > 0) x = x * x;
+    }
+    return acc;
+}
+
+}  // namespace
+
+struct d2d_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // scene (host copies)
+    int N = 0;
+    bool have_scene = false;
+    std::vector<float> xys;        // [N][2][2]
+    std::vector<uint8_t> kind;     // [N]
+    std::vector<float> phi;        // [N]
+    std::vector<uint8_t> allowed;  // [N]
+    std::vector<int> cw;           // compact list of allowed indices
+    float occl_patch = NAN;        // patch the occlusion table was built for
+    // scene (device)
+    DevBuf<float4> d_occl, d_refl;
+    DevBuf<int> d_cw;
+    // grid
+    int m = 0, n = 0;
+    bool have_grid = false;
+    DevBuf<float> d_X, d_Y, d_out;
+};
+
+namespace {
+
+int set_device(d2d_ctx* c) {
+    HIP_TRY(hipSetDevice(c->device));
+    return D2D_OK;
+}
+
+// Per-object constants, computed once with the reference's operations (fp32, no contraction):
+// t = dest - origin (geometry.py:479-487), n = normalize((t_y, -t_x)) (:561-573, 206-230),
+// sq = where(t.t == 0, 1, t.t) (:596-597).
+int upload_refl(d2d_ctx* c) {
+    std::vector<float4> refl(2 * (size_t)c->N + 2);
+    for (int j = 0; j < c->N; ++j) {
+        const float* w = &c->xys[4 * (size_t)j];
+        float ox = w[0], oy = w[1], dx = w[2], dy = w[3];
+        float tx = dx - ox, ty = dy - oy;
+        float vx = ty, vy = -tx;
+        float len = sqrtf(vx * vx + vy * vy);
+        if (len == 0.0f) len = 1.0f;
+        float nx = vx / len, ny = vy / len;
+        float sq = tx * tx + ty * ty;
+        if (sq == 0.0f) sq = 1.0f;
+        refl[2 * j] = make_float4(ox, oy, nx, ny);
+        refl[2 * j + 1] = make_float4(tx, ty, sq, 0.0f);
+    }
+    int rc = c->d_refl.ensure(refl.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_refl.p, refl.data(), refl.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D2D_OK;
+}
+
+// Patched end points, geometry.py:632-636: P1 = origin - patch*t, P2 = dest + patch*t, A = P2 - P1.
+int upload_occl(d2d_ctx* c, float patch) {
+    if (c->occl_patch == patch && c->d_occl.p) return D2D_OK;
+    std::vector<float4> occl((size_t)c->N + 1);
+    for (int j = 0; j < c->N; ++j) {
+        const float* w = &c->xys[4 * (size_t)j];
+        float ox = w[0], oy = w[1], dx = w[2], dy = w[3];
+        float tx = dx - ox, ty = dy - oy;
+        float ptx = patch * tx, pty = patch * ty;
+        float p1x = ox - ptx, p1y = oy - pty;
+        float p2x = dx + ptx, p2y = dy + pty;
+        occl[j] = make_float4(p1x, p1y, p2x - p1x, p2y - p1y);
+    }
+    int rc = c->d_occl.ensure(occl.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_occl.p, occl.data(), occl.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->occl_patch = patch;
+    return D2D_OK;
+}
+
+int upload_mask(d2d_ctx* c) {
+    c->cw.clear();
+    for (int j = 0; j < c->N; ++j)
+        if (c->allowed[j]) c->cw.push_back(j);
+    int rc = c->d_cw.ensure(c->cw.size() + 1);
+    if (rc) return rc;
+    if (!c->cw.empty()) {
+        HIP_TRY(hipMemcpyAsync(c->d_cw.p, c->cw.data(), c->cw.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return D2D_OK;
+}
+
+int64_t count_order(int64_t nc, int k) {
+    if (k == 0) return 1;
+    if (nc <= 0) return 0;
+    int64_t c = nc;
+    for (int i = 1; i < k; ++i) c *= (nc - 1);
+    return c;
+}
+
+int check_params(const d2d_params* p) {
+    if (!p) return fail(D2D_ERR_INVALID, "params is NULL");
+    if (p->min_order < 0 || p->max_order > D2D_MAX_ORDER)
+        return fail(D2D_ERR_INVALID, "orders must lie in [0, %d], got [%d, %d]", D2D_MAX_ORDER, p->min_order, p->max_order);
+    if (p->approx && !(p->alpha > 0.0f)) return fail(D2D_ERR_INVALID, "alpha must be > 0 in approx mode, got %g", (double)p->alpha);
+    if (p->approx && p->act != D2D_ACT_HARD_SIGMOID && p->act != D2D_ACT_SIGMOID)
+        return fail(D2D_ERR_UNSUPPORTED, "activation %d is not one of the native activations", p->act);
+    if (p->fun_id < 0 || p->fun_id > D2D_FUN_ONE) return fail(D2D_ERR_UNSUPPORTED, "fun_id %d is not a native path function", p->fun_id);
+    if (p->out_mode != D2D_OUT_OVERWRITE && p->out_mode != D2D_OUT_ADD) return fail(D2D_ERR_INVALID, "bad out_mode %d", p->out_mode);
+    if (!(p->seg_tol >= 0.0f)) return fail(D2D_ERR_INVALID, "seg_tol must be >= 0");
+    return D2D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int d2d_abi_version(void) { return D2D_ABI_VERSION; }
+
+const char* d2d_last_error(void) { return g_err.c_str(); }
+
+int d2d_device_count(int* count) {
+    if (!count) return fail(D2D_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return D2D_OK;
+}
+
+int d2d_device_info(int device, char* name, int cap, int* cus, int64_t* mem_bytes) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (name && cap > 0) {
+        snprintf(name, (size_t)cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (mem_bytes) *mem_bytes = (int64_t)prop.totalGlobalMem;
+    return D2D_OK;
+}
+
+int d2d_create(int device, d2d_ctx** out) {
+    if (!out) return fail(D2D_ERR_INVALID, "ctx out-pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(D2D_ERR_NO_DEVICE, "no HIP device visible (%s); libd2d has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    if (device < 0 || device >= n) return fail(D2D_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+    d2d_ctx* c = new d2d_ctx();
+    c->device = device;
+    hipError_t e1 = hipSetDevice(device);
+    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e1 == hipSuccess) e1 = hipEventCreate(&c->ev0);
+    if (e1 == hipSuccess) e1 = hipEventCreate(&c->ev1);
+    if (e1 != hipSuccess) {
+        delete c;
+        return fail(D2D_ERR_HIP, "context creation failed: %s", hipGetErrorString(e1));
+    }
+    *out = c;
+    return D2D_OK;
+}
+
+void d2d_destroy(d2d_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->d_occl.release();
+    c->d_refl.release();
+    c->d_cw.release();
+    c->d_X.release();
+    c->d_Y.release();
+    c->d_out.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int d2d_synchronize(d2d_ctx* c) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D2D_OK;
+}
+
+int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float* phi, int32_t n_objects) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (n_objects < 0 || (n_objects > 0 && !xys)) return fail(D2D_ERR_INVALID, "bad scene arguments");
+    int rc = set_device(c);
+    if (rc) return rc;
+    for (size_t i = 0; i < 4 * (size_t)n_objects; ++i)
+        if (!(std::fabs(xys[i]) < 1e18f)) return fail(D2D_ERR_INVALID, "object coordinate %zu is not finite (or >= 1e18)", i);
+    c->N = n_objects;
+    c->xys.assign(xys, xys + 4 * (size_t)n_objects);
+    c->kind.assign((size_t)n_objects, (uint8_t)D2D_WALL);
+    if (kind) c->kind.assign(kind, kind + n_objects);
+    for (int j = 0; j < n_objects; ++j)
+        if (c->kind[j] > D2D_VERTEX) return fail(D2D_ERR_INVALID, "object %d has unknown kind %d", j, (int)c->kind[j]);
+    c->phi.assign((size_t)n_objects, 0.78539816339744830962f);
+    if (phi) c->phi.assign(phi, phi + n_objects);
+    c->allowed.assign((size_t)n_objects, (uint8_t)1);
+    c->occl_patch = NAN;
+    rc = upload_refl(c);
+    if (rc) return rc;
+    rc = upload_mask(c);
+    if (rc) return rc;
+    c->have_scene = true;
+    return D2D_OK;
+}
+
+int d2d_set_candidate_mask(d2d_ctx* c, const uint8_t* allowed) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (allowed) c->allowed.assign(allowed, allowed + c->N);
+    else c->allowed.assign((size_t)c->N, (uint8_t)1);
+    return upload_mask(c);
+}
+
+int d2d_num_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int64_t* count) {
+    if (!c || !count) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
+    if (min_order < 0) return fail(D2D_ERR_INVALID, "min_order < 0");
+    int64_t total = 0;
+    for (int k = min_order; k <= max_order; ++k) total += count_order((int64_t)c->cw.size(), k);
+    *count = total;
+    return D2D_OK;
+}
+
+int d2d_list_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int32_t* cand, int32_t* order, int64_t capacity) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
+    if (min_order < 0 || max_order > D2D_MAX_ORDER) return fail(D2D_ERR_INVALID, "orders must lie in [0, %d]", D2D_MAX_ORDER);
+    int64_t total = 0;
+    int rc = d2d_num_candidates(c, min_order, max_order, &total);
+    if (rc) return rc;
+    if (capacity < total) return fail(D2D_ERR_INVALID, "capacity %lld < %lld candidates", (long long)capacity, (long long)total);
+    const int nc = (int)c->cw.size();
+    int64_t at = 0;
+    for (int k = min_order; k <= max_order; ++k) {
+        if (k == 0) {
+            if (cand) for (int i = 0; i < D2D_MAX_ORDER; ++i) cand[at * D2D_MAX_ORDER + i] = -1;
+            if (order) order[at] = 0;
+            ++at;
+            continue;
+        }
+        // odometer over positions in the compact list, lexicographic, no equal neighbours
+        int pos[D2D_MAX_ORDER];
+        int depth = 0;
+        pos[0] = -1;
+        while (depth >= 0) {
+            int p = pos[depth] + 1;
+            if (depth > 0 && p == pos[depth - 1]) ++p;
+            if (p >= nc) {
+                --depth;
+                continue;
+            }
+            pos[depth] = p;
+            if (depth == k - 1) {
+                if (cand)
+                    for (int i = 0; i < D2D_MAX_ORDER; ++i) cand[at * D2D_MAX_ORDER + i] = (i < k) ? c->cw[pos[i]] : -1;
+                if (order) order[at] = k;
+                ++at;
+            } else {
+                ++depth;
+                pos[depth] = -1;
+            }
+        }
+    }
+    return D2D_OK;
+}
+
+int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t n) {
+    if (!c || !X || !Y) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (m <= 0 || n <= 0) return fail(D2D_ERR_INVALID, "grid must be at least 1 x 1, got %d x %d", m, n);
+    int rc = set_device(c);
+    if (rc) return rc;
+    size_t cells = (size_t)m * (size_t)n;
+    if ((rc = c->d_X.ensure(cells))) return rc;
+    if ((rc = c->d_Y.ensure(cells))) return rc;
+    if ((rc = c->d_out.ensure(cells))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_X.p, X, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_Y.p, Y, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_out.p, 0, cells * sizeof(float), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->m = m;
+    c->n = n;
+    c->have_grid = true;
+    return D2D_OK;
+}
+
+int d2d_power_map_launch(d2d_ctx* c, const d2d_params* p, const float* tx) {
+    if (!c || !tx) return fail(D2D_ERR_INVALID, "NULL argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come before a sweep");
+    if (!c->have_grid) return fail(D2D_ERR_STATE, "d2d_set_grid must come before a sweep");
+    if (p->solver != D2D_SOLVER_IMAGE) return fail(D2D_ERR_UNSUPPORTED, "solver %d is not available in this build", p->solver);
+    if (p->max_order >= 1)
+        for (int j = 0; j < c->N; ++j)
+            if (c->allowed[j] && c->kind[j] != D2D_WALL)
+                return fail(D2D_ERR_UNSUPPORTED,
+                            "ImagePath needs homogeneous Wall objects (reference: stack_leaves raises on mixed types); "
+                            "object %d has kind %d", j, (int)c->kind[j]);
+    for (int j = 0; j < c->N; ++j)
+        if (c->kind[j] == D2D_VERTEX) return fail(D2D_ERR_UNSUPPORTED, "Vertex objects need the MinPath/FermatPath solver");
+    if ((rc = set_device(c))) return rc;
+    if ((rc = upload_occl(c, p->patch))) return rc;
+
+    d2d::SweepArgs a;
+    memset(&a, 0, sizeof a);
+    a.occl = c->d_occl.p;
+    a.refl = c->d_refl.p;
+    a.cw = c->d_cw.p;
+    a.N = c->N;
+    a.Nc = (int)c->cw.size();
+    a.X = c->d_X.p;
+    a.Y = c->d_Y.p;
+    a.out = c->d_out.p;
+    a.m = c->m;
+    a.n = c->n;
+    a.txx = tx[0];
+    a.txy = tx[1];
+    a.min_order = p->min_order;
+    a.max_order = p->max_order;
+    a.alpha = p->alpha;
+    a.tol = p->tol;
+    a.seg_lo = -p->seg_tol;
+    a.seg_hi = 1.0f + p->seg_tol;
+    // Filter thresholds: the soft window is where some activation of t is not exactly saturated
+    // to "outside": hard -> [-tol, 1+tol]; hard_sigmoid -> widened by 3/alpha; sigmoid -> by 89/alpha
+    // (exp(89) overflows fp32, 1/(1+inf) == 0).  1e-5 relative slack covers every rounding in the
+    // filter's own arithmetic (a few ulp).
+    double widen = 0.0;
+    int mode = d2d::MODE_HARD;
+    if (p->approx) {
+        mode = (p->act == D2D_ACT_HARD_SIGMOID) ? d2d::MODE_HSIG : d2d::MODE_SIG;
+        widen = ((mode == d2d::MODE_HSIG) ? 3.0 : 89.0) / (double)p->alpha;
+    }
+    double lo = -((double)p->seg_tol + widen);
+    double hi = 1.0 + (double)p->seg_tol + widen;
+    a.flt_lo = (float)(lo * (1.0 + 1e-5) - 1e-30);
+    a.flt_hi = (float)(hi * (1.0 + 1e-5) + 1e-30);
+    for (int k = 0; k <= D2D_MAX_ORDER; ++k) a.fnum[k] = integer_pow(p->r_coef, k);
+    a.h2 = p->height * p->height;
+    a.fun_id = p->fun_id;
+    a.out_mode = p->out_mode;
+    a.stats = nullptr;
+
+    const int tiles_x = (c->n + d2d::TILE_W - 1) / d2d::TILE_W;
+    const int tiles_y = (c->m + d2d::TILE_H - 1) / d2d::TILE_H;
+    const long long tiles = (long long)tiles_x * tiles_y;
+    if (tiles > 0x7fffffffLL) return fail(D2D_ERR_INVALID, "grid too large: %lld tiles", tiles);
+    dim3 grid((unsigned)tiles), block(64);
+    switch (mode) {
+        case d2d::MODE_HARD: hipLaunchKernelGGL(d2d::power_fwd_kernel<d2d::MODE_HARD>, grid, block, 0, c->stream, a); break;
+        case d2d::MODE_HSIG: hipLaunchKernelGGL(d2d::power_fwd_kernel<d2d::MODE_HSIG>, grid, block, 0, c->stream, a); break;
+        default: hipLaunchKernelGGL(d2d::power_fwd_kernel<d2d::MODE_SIG>, grid, block, 0, c->stream, a); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return D2D_OK;
+}
+
+int d2d_get_map(d2d_ctx* c, float* out) {
+    if (!c || !out) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (!c->have_grid) return fail(D2D_ERR_STATE, "no grid set");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->d_out.p, (size_t)c->m * c->n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D2D_OK;
+}
+
+int d2d_power_map(d2d_ctx* c, const d2d_params* p, const float* tx, const float* X, const float* Y, int32_t m, int32_t n,
+                  float* out) {
+    int rc = d2d_set_grid(c, X, Y, m, n);
+    if (rc) return rc;
+    if ((rc = d2d_power_map_launch(c, p, tx))) return rc;
+    return d2d_get_map(c, out);
+}
+
+int d2d_timer_begin(d2d_ctx* c) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return D2D_OK;
+}
+
+int d2d_timer_end(d2d_ctx* c, float* ms) {
+    if (!c || !ms) return fail(D2D_ERR_INVALID, "NULL argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return D2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+"""
+Thin object wrapper over the C ABI: one :class:`Context` = one MI355X + one HIP stream.
+
+The higher-level mirror of the reference API (:mod:`differt2d_amd.scene`) drives this class;
+benchmarks and tests may use it directly.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .defaults import DEFAULT_ALPHA, DEFAULT_HEIGHT, DEFAULT_PATCH, DEFAULT_R_COEF
+
+FUN_IDS = {
+    "received_power": L.FUN_RECEIVED_POWER,
+    "length_squared": L.FUN_LENGTH_SQUARED,
+    "length": L.FUN_LENGTH,
+    "one": L.FUN_ONE,
+}
+ACT_IDS = {"hard_sigmoid": L.ACT_HARD_SIGMOID, "sigmoid": L.ACT_SIGMOID}
+SOLVER_IDS = {"image": L.SOLVER_IMAGE, "min": L.SOLVER_MINPATH, "fermat": L.SOLVER_FERMAT}
+
+
+def make_params(
+    min_order: int = 0,
+    max_order: int = 1,
+    order: Optional[int] = None,
+    approx: bool = False,
+    function: str = "hard_sigmoid",
+    alpha: float = DEFAULT_ALPHA,
+    tol: float = 1e-2,
+    patch: float = DEFAULT_PATCH,
+    seg_tol: float = 0.005,
+    fun: str = "received_power",
+    r_coef: float = DEFAULT_R_COEF,
+    height: float = DEFAULT_HEIGHT,
+    solver: str = "image",
+    steps: int = 100,
+    out_mode: int = L.OUT_OVERWRITE,
+) -> L.Params:
+    """Builds a ``d2d_params``; keyword names follow the reference's kwargs
+    (scene.py:1803-1826, geometry.py:910-919, logic.py:258-267, utils.py:17-24)."""
+    if order is not None:
+        min_order = max_order = order
+    if function not in ACT_IDS:
+        raise L.D2DUnsupported(-4, f"activation {function!r} is not native (hard_sigmoid, sigmoid)")
+    if fun not in FUN_IDS:
+        raise L.D2DUnsupported(-4, f"path function {fun!r} is not native ({', '.join(FUN_IDS)})")
+    p = L.Params()
+    p.min_order, p.max_order = int(min_order), int(max_order)
+    p.approx, p.act = int(bool(approx)), ACT_IDS[function]
+    p.alpha, p.tol, p.patch, p.seg_tol = float(alpha), float(tol), float(patch), float(seg_tol)
+    p.fun_id, p.r_coef, p.height = FUN_IDS[fun], float(r_coef), float(height)
+    p.solver, p.steps, p.out_mode = SOLVER_IDS[solver], int(steps), int(out_mode)
+    return p
+
+
+class Context:
+    """Owns a ``d2d_ctx``: device buffers for one scene and one RX grid stay resident in HBM."""
+
+    def __init__(self, device: int = 0):
+        self._lib = L.load()
+        self._ctx = C.c_void_p()
+        L.check(self._lib.d2d_create(int(device), C.byref(self._ctx)))
+        self.device = int(device)
+        self.shape = None
+        self.n_objects = 0
+
+    # -- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.d2d_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int(0), C.c_int64(0)
+        L.check(self._lib.d2d_device_info(self.device, name, 256, C.byref(cus), C.byref(mem)))
+        return {"name": name.value.decode(), "cus": cus.value, "mem_bytes": mem.value}
+
+    # -- scene ------------------------------------------------------------------------
+    def set_scene(self, xys, kind=None, phi=None):
+        xys = np.ascontiguousarray(xys, dtype=np.float32).reshape(-1, 2, 2)
+        n = xys.shape[0]
+        kind_a = None if kind is None else np.ascontiguousarray(kind, dtype=np.uint8)
+        phi_a = None if phi is None else np.ascontiguousarray(phi, dtype=np.float32)
+        if kind_a is not None and kind_a.shape != (n,):
+            raise ValueError("kind must have one entry per object")
+        if phi_a is not None and phi_a.shape != (n,):
+            raise ValueError("phi must have one entry per object")
+        L.check(
+            self._lib.d2d_set_scene(
+                self._ctx,
+                xys.ctypes.data_as(C.c_void_p) if n else None,
+                None if kind_a is None else kind_a.ctypes.data_as(C.c_void_p),
+                None if phi_a is None else phi_a.ctypes.data_as(C.c_void_p),
+                n,
+            )
+        )
+        self.n_objects = n
+
+    def set_candidate_mask(self, allowed=None):
+        if allowed is None:
+            L.check(self._lib.d2d_set_candidate_mask(self._ctx, None))
+            return
+        a = np.ascontiguousarray(allowed, dtype=np.uint8)
+        if a.shape != (self.n_objects,):
+            raise ValueError("mask must have one entry per object")
+        L.check(self._lib.d2d_set_candidate_mask(self._ctx, a.ctypes.data_as(C.c_void_p)))
+
+    def num_candidates(self, min_order=0, max_order=1) -> int:
+        n = C.c_int64(0)
+        L.check(self._lib.d2d_num_candidates(self._ctx, min_order, max_order, C.byref(n)))
+        return n.value
+
+    def list_candidates(self, min_order=0, max_order=1):
+        """Returns the reference's candidate list: a python list of int32 arrays of shape (k,)."""
+        n = self.num_candidates(min_order, max_order)
+        cand = np.empty((max(n, 1), L.D2D_MAX_ORDER), np.int32)
+        order = np.empty(max(n, 1), np.int32)
+        L.check(
+            self._lib.d2d_list_candidates(
+                self._ctx, min_order, max_order, cand.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p), n
+            )
+        )
+        return [cand[i, : order[i]].copy() for i in range(n)]
+
+    # -- grid sweep -------------------------------------------------------------------
+    def set_grid(self, X, Y):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        Y = np.ascontiguousarray(Y, dtype=np.float32)
+        if X.shape != Y.shape or X.ndim != 2:
+            raise ValueError(f"X and Y must be 2-D arrays of one shape, got {X.shape} and {Y.shape}")
+        L.check(self._lib.d2d_set_grid(self._ctx, X, Y, X.shape[0], X.shape[1]))
+        self.shape = X.shape
+
+    def launch(self, params: L.Params, tx):
+        tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(2)
+        L.check(self._lib.d2d_power_map_launch(self._ctx, C.byref(params), tx))
+
+    def get_map(self) -> np.ndarray:
+        out = np.empty(self.shape, np.float32)
+        L.check(self._lib.d2d_get_map(self._ctx, out))
+        return out
+
+    def synchronize(self):
+        L.check(self._lib.d2d_synchronize(self._ctx))
+
+    def power_map(self, tx, X, Y, **kw) -> np.ndarray:
+        """One transmitter, one grid: upload, sweep, download."""
+        self.set_grid(X, Y)
+        self.launch(make_params(**kw), tx)
+        return self.get_map()
+
+    # -- timing -----------------------------------------------------------------------
+    def timer_begin(self):
+        L.check(self._lib.d2d_timer_begin(self._ctx))
+
+    def timer_end(self) -> float:
+        ms = C.c_float(0.0)
+        L.check(self._lib.d2d_timer_end(self._ctx, C.byref(ms)))
+        return ms.value
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    """Process-wide context per device (created on first use; raises without a GPU)."""
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,145 @@
+/*
+ * d2d.h -- C ABI of libd2d.so, the MI355X (gfx950) drop-in for DiffeRT2d's hot path.
+ *
+ * DiffeRT2d (v0.4.0) is pure Python on JAX: it has no FFI, its extension points are Python
+ * protocols.  This header is the boundary a maintainer would bind with ctypes/cffi from
+ * differt2d/scene.py (see INTEGRATION.md for the stub).  Each entry point cites the
+ * reference interface it replaces (paths relative to the DiffeRT2d checkout).
+ *
+ * Conventions
+ *   - every function returns D2D_OK (0) or a negative d2d_status; nothing throws across the
+ *     ABI; d2d_last_error() returns a thread-local, human-readable message for the last failure;
+ *   - the caller owns all host buffers (C-contiguous fp32 / int32 / uint8); the library owns
+ *     every device buffer inside d2d_ctx; one ctx = one GPU + one HIP stream; calls on one ctx
+ *     are serialised by the caller, different ctxs may be driven from different threads;
+ *   - all floating point is IEEE fp32 with one rounding per operation (no fma contraction,
+ *     correctly rounded divide/sqrt), operations in the order the reference writes them;
+ *   - there is NO CPU fallback: without a usable gfx950 device d2d_create fails.
+ */
+#ifndef D2D_H
+#define D2D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D2D_MAX_ORDER 4 /* highest interaction order a sweep accepts */
+#define D2D_ABI_VERSION 1
+
+typedef enum d2d_status {
+    D2D_OK = 0,
+    D2D_ERR_INVALID = -1,     /* bad argument (NULL, negative size, order > D2D_MAX_ORDER, alpha <= 0 ...) */
+    D2D_ERR_HIP = -2,         /* a HIP runtime call failed */
+    D2D_ERR_NO_DEVICE = -3,   /* no gfx950 device visible */
+    D2D_ERR_UNSUPPORTED = -4, /* feature outside the native closed set (e.g. ImagePath with RIS objects) */
+    D2D_ERR_STATE = -5,       /* call order violated (e.g. sweep before d2d_set_scene / d2d_set_grid) */
+    D2D_ERR_COMM = -6         /* RCCL failure */
+} d2d_status;
+
+/* Object kinds, differt2d/geometry.py:542-721 (Wall), :683-721 (RIS), :352-431 (Vertex). */
+enum { D2D_WALL = 0, D2D_RIS = 1, D2D_VERTEX = 2 };
+
+/* Path solver = `path_cls`, differt2d/scene.py:1814 (ImagePath geometry.py:1013-1114,
+ * MinPath :1207-1288, FermatPath :1117-1204). */
+enum { D2D_SOLVER_IMAGE = 0, D2D_SOLVER_MINPATH = 1, D2D_SOLVER_FERMAT = 2 };
+
+/* Activation = `function` kwarg of differt2d/logic.py:258-312. */
+enum { D2D_ACT_HARD_SIGMOID = 0, D2D_ACT_SIGMOID = 1 };
+
+/* Natively fused `fun` (PathFun, differt2d/scene.py:51):
+ *   RECEIVED_POWER  differt2d/utils.py:17-54        r_coef**n / (height^2 + length^2)
+ *   LENGTH_SQUARED  tests/test_scene.py:444-445     path.length() ** 2
+ *   LENGTH          differt2d/geometry.py:811-819   path.length()
+ *   ONE             1.0 (the map then counts valid paths -- "intersection counts") */
+enum { D2D_FUN_RECEIVED_POWER = 0, D2D_FUN_LENGTH_SQUARED = 1, D2D_FUN_LENGTH = 2, D2D_FUN_ONE = 3 };
+
+/* How a sweep combines with what the output map already holds. */
+enum {
+    D2D_OUT_OVERWRITE = 0, /* Z  = facc                                              */
+    D2D_OUT_ADD = 1        /* Z  = Z + facc   (reduce_all over transmitters, differt2d/scene.py:1939-1952) */
+};
+
+/* Everything Scene.accumulate_on_receivers_grid_over_paths threads down to Path.is_valid and
+ * `fun` (differt2d/scene.py:1803-1826; kwargs -> differt2d/geometry.py:910-919, logic.py:258-267). */
+typedef struct d2d_params {
+    int32_t min_order;  /* differt2d/scene.py:1817 */
+    int32_t max_order;  /* differt2d/scene.py:1818 */
+    int32_t approx;     /* 0 = jnp.logical_*, 1 = min/max/activation (differt2d/logic.py:315-537) */
+    int32_t act;        /* D2D_ACT_* */
+    float alpha;        /* differt2d/defaults.py:3 (100.0) */
+    float tol;          /* differt2d/geometry.py:915 (1e-2): loss tolerance of is_valid */
+    float patch;        /* differt2d/geometry.py:916 / defaults.py:7 (0.0) */
+    float seg_tol;      /* differt2d/geometry.py:89 (0.005); not reachable from the reference's sweep kwargs */
+    int32_t fun_id;     /* D2D_FUN_* */
+    float r_coef;       /* differt2d/defaults.py:12 (0.5) */
+    float height;       /* differt2d/defaults.py:15 (0.1) */
+    int32_t solver;     /* D2D_SOLVER_* */
+    int32_t steps;      /* differt2d/optimize.py:50 (100): Adam steps of MinPath / FermatPath */
+    int32_t out_mode;   /* D2D_OUT_* */
+    int32_t reserved[4];
+} d2d_params;
+
+typedef struct d2d_ctx d2d_ctx;
+
+/* ---- library / device ------------------------------------------------------------------ */
+
+int d2d_abi_version(void);
+const char* d2d_last_error(void);
+/* Number of visible HIP devices (0 is not an error). */
+int d2d_device_count(int* count);
+/* Fills name (<= cap bytes), number of CUs and total global memory of a device. */
+int d2d_device_info(int device, char* name, int cap, int* cus, int64_t* mem_bytes);
+
+/* One context per GPU. Fails with D2D_ERR_NO_DEVICE when `device` does not exist. */
+int d2d_create(int device, d2d_ctx** ctx);
+void d2d_destroy(d2d_ctx* ctx);
+int d2d_synchronize(d2d_ctx* ctx);
+
+/* ---- scene (replaces Scene.objects / Scene.from_walls_array, differt2d/scene.py:191, 413-426) -- */
+
+/* objects: xys[N][2][2] (origin, dest; a Vertex stores its point in both rows), kind[N]
+ * (D2D_WALL / D2D_RIS / D2D_VERTEX, NULL = all walls), phi[N] (RIS angle, NULL = pi/4). */
+int d2d_set_scene(d2d_ctx* ctx, const float* xys, const uint8_t* kind, const float* phi, int32_t n_objects);
+
+/* filter_objects of Scene.all_path_candidates (differt2d/scene.py:1089-1134): allowed[i] != 0
+ * means object i may appear in a path candidate; NULL = all. Filtered objects still occlude. */
+int d2d_set_candidate_mask(d2d_ctx* ctx, const uint8_t* allowed);
+
+/* Number of path candidates sum_k |{tuples of length k, no equal neighbours}| for the current
+ * scene and mask (differt2d/scene.py:122-175; differt-core 0.0.31 CompleteGraph.all_paths). */
+int d2d_num_candidates(d2d_ctx* ctx, int32_t min_order, int32_t max_order, int64_t* count);
+
+/* Writes the candidate list itself (row-major [count][D2D_MAX_ORDER], -1 padded) and each
+ * candidate's order, in the reference's enumeration order. Either pointer may be NULL. */
+int d2d_list_candidates(d2d_ctx* ctx, int32_t min_order, int32_t max_order, int32_t* cand, int32_t* order,
+                        int64_t capacity);
+
+/* ---- grid sweep (replaces Scene.accumulate_on_receivers_grid_over_paths, differt2d/scene.py:1803-1953,
+ *      for one transmitter at a time; X, Y as produced by Plottable.grid, differt2d/abc.py:57-81) -------- */
+
+/* Uploads the receiver grid (row-major [m][n], any coordinates) and (re)allocates the resident
+ * output maps; the value map is zeroed. */
+int d2d_set_grid(d2d_ctx* ctx, const float* X, const float* Y, int32_t m, int32_t n);
+
+/* Launches the fused forward sweep for transmitter tx[2] on the ctx stream (asynchronous).
+ * Inputs and outputs stay resident in HBM. */
+int d2d_power_map_launch(d2d_ctx* ctx, const d2d_params* params, const float* tx);
+
+/* Synchronises and copies the resident value map to out[m*n]. */
+int d2d_get_map(d2d_ctx* ctx, float* out);
+
+/* Convenience: d2d_set_grid + d2d_power_map_launch + d2d_get_map. */
+int d2d_power_map(d2d_ctx* ctx, const d2d_params* params, const float* tx, const float* X, const float* Y,
+                  int32_t m, int32_t n, float* out);
+
+/* ---- timing on the ctx stream (HIP events) -------------------------------------------------- */
+
+int d2d_timer_begin(d2d_ctx* ctx);
+int d2d_timer_end(d2d_ctx* ctx, float* elapsed_ms); /* synchronises on the end event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2D_H */

@@ -1,0 +1,163 @@
+"""
+GPU parity: the HIP forward sweep (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bar: bit-exact in hard and hard_sigmoid modes (identical fp32 op chain, IEEE
+divide/sqrt, no contraction); sigmoid mode within rtol 2e-5 / atol 1e-5 (expf implementations
+differ by an ulp; BASELINE.json's tolerance is 1e-5).
+"""
+
+import numpy as np
+import pytest
+
+from conftest import random_scene, unit_grid
+
+pytestmark = pytest.mark.gpu
+
+F = np.float32
+MODES = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from differt2d_amd.engine import Context
+
+    with Context(0) as c:
+        yield c
+
+
+def _oracle(walls, tx, X, Y, **kw):
+    from oracle import c_oracle as CO
+
+    return CO.power_map(walls, tx, X, Y, prune=True, **kw)
+
+
+def _compare(got, want, function):
+    assert got.shape == want.shape and got.dtype == np.float32
+    if function == "sigmoid":
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-5)
+    else:
+        bad = ~((got == want) | (np.isnan(got) & np.isnan(want)))
+        assert not bad.any(), f"{bad.sum()} of {bad.size} cells differ; max abs {np.nanmax(np.abs(got - want))}"
+
+
+@pytest.mark.parametrize("approx,function", MODES)
+def test_cfg1_square_scene_64(ctx, approx, function):
+    """BASELINE.json configs[0]: Scene.square_scene(), 1 TX, 64x64 RX grid, order <= 1."""
+    from oracle import ref as R
+
+    walls, tx = R.square_scene_walls(), np.array([0.2, 0.2], F)
+    X, Y = unit_grid(64)
+    ctx.set_scene(walls)
+    got = ctx.power_map(tx, X, Y, min_order=0, max_order=1, approx=approx, function=function)
+    _compare(got, _oracle(walls, tx, X, Y, min_order=0, max_order=1, approx=approx, function=function), function)
+
+
+@pytest.mark.parametrize("approx,function", MODES)
+@pytest.mark.parametrize("fun", ["received_power", "one", "length_squared", "length"])
+def test_random_scene_order2(ctx, approx, function, fun):
+    tx, walls = random_scene(12, seed=11)
+    X, Y = unit_grid(37, 29)  # ragged: not a multiple of the 8x8 wave tile
+    ctx.set_scene(walls)
+    kw = dict(min_order=0, max_order=2, approx=approx, function=function, fun=fun)
+    _compare(ctx.power_map(tx, X, Y, **kw), _oracle(walls, tx, X, Y, **kw), function)
+
+
+@pytest.mark.parametrize("approx,function", MODES)
+def test_order3_and_order4(ctx, approx, function):
+    tx, walls = random_scene(6, seed=5)
+    X, Y = unit_grid(16, 9)
+    ctx.set_scene(walls)
+    for lo, hi in [(3, 3), (0, 3), (4, 4)]:
+        kw = dict(min_order=lo, max_order=hi, approx=approx, function=function)
+        _compare(ctx.power_map(tx, X, Y, **kw), _oracle(walls, tx, X, Y, **kw), function)
+
+
+@pytest.mark.parametrize("approx,function", MODES)
+def test_kwargs_alpha_patch_tol_filter(ctx, approx, function):
+    tx, walls = random_scene(8, seed=21)
+    X, Y = unit_grid(24)
+    allowed = np.array([1, 0, 1, 1, 0, 1, 1, 1], np.uint8)
+    ctx.set_scene(walls)
+    ctx.set_candidate_mask(allowed)
+    kw = dict(min_order=1, max_order=2, approx=approx, function=function, alpha=50.0, patch=0.02, tol=0.05,
+              r_coef=0.3, height=0.25)
+    got = ctx.power_map(tx, X, Y, **kw)
+    ctx.set_candidate_mask(None)
+    _compare(got, _oracle(walls, tx, X, Y, allowed=allowed, **kw), function)
+
+
+@pytest.mark.parametrize("approx,function", MODES[:2])
+def test_degenerate_rx_on_walls_endpoints_and_tx(ctx, approx, function):
+    from oracle import ref as R
+
+    walls, tx = R.square_scene_with_wall_walls(), np.array([0.2, 0.5], F)
+    X, Y = np.meshgrid(np.array([0.0, 0.2, 0.5, 1.0], F), np.array([0.0, 0.2, 0.5, 0.8, 1.0], F))
+    ctx.set_scene(walls)
+    kw = dict(min_order=0, max_order=2, approx=approx, function=function)
+    _compare(ctx.power_map(tx, X, Y, **kw), _oracle(walls, tx, X, Y, **kw), function)
+
+
+def test_empty_scene_los_analytic(ctx):
+    """tests/test_scene.py:558-627 of the reference: no objects, fun = length**2 -> X^2 + Y^2."""
+    x = np.linspace(-3, 3, 10).astype(F)
+    X, Y = np.meshgrid(x, x)
+    ctx.set_scene(np.zeros((0, 2, 2), F))
+    Z0 = ctx.power_map([0.0, 0.0], X, Y, max_order=1, fun="length_squared")
+    Z1 = ctx.power_map([1.0, 0.0], X, Y, max_order=1, fun="length_squared")
+    np.testing.assert_allclose(Z0, X**2 + Y**2, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(Z1, (X - 1) ** 2 + Y**2, rtol=1e-6, atol=1e-6)
+
+
+def test_notebook_valid_count_on_gpu(ctx):
+    """6 valid order-2 candidates on square_scene_with_obstacle at rx (0.5, 0.6) (notebook cell 6)."""
+    from oracle import ref as R
+
+    ctx.set_scene(R.square_scene_with_obstacle_walls())
+    got = ctx.power_map([0.2, 0.2], np.array([[0.5]], F), np.array([[0.6]], F), order=2, fun="one")
+    assert got.shape == (1, 1) and got[0, 0] == 6.0
+
+
+def test_out_mode_add_two_transmitters(ctx):
+    """reduce_all over transmitters: Z = (0 + p0) + p1 (reference scene.py:1948-1952)."""
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import make_params
+
+    tx, walls = random_scene(7, seed=2)
+    X, Y = unit_grid(20)
+    ctx.set_scene(walls)
+    ctx.set_grid(X, Y)
+    ctx.launch(make_params(max_order=2), tx)
+    ctx.launch(make_params(max_order=2, out_mode=L.OUT_ADD), tx[::-1].copy())
+    got = ctx.get_map()
+    want = _oracle(walls, tx, X, Y, max_order=2) + _oracle(walls, tx[::-1].copy(), X, Y, max_order=2)
+    _compare(got, want, "hard_sigmoid")
+
+
+@pytest.mark.parametrize("approx,function", MODES)
+def test_cfg2_subgrid_50_walls_order2(ctx, approx, function):
+    """BASELINE.json configs[1] scene (50 random walls, order <= 2) on a 96x96 sub-grid of the
+    1024x1024 grid (the oracle needs seconds there); intersection counts are bit-exact."""
+    tx, walls = random_scene(50, seed=1234)
+    x = np.linspace(0.0, 1.0, 1024).astype(F)[::11][:96]
+    X, Y = np.meshgrid(x, x)
+    ctx.set_scene(walls)
+    kw = dict(min_order=0, max_order=2, approx=approx, function=function)
+    _compare(ctx.power_map(tx, X, Y, **kw), _oracle(walls, tx, X, Y, **kw), function)
+    if not approx:
+        kw["fun"] = "one"
+        got = ctx.power_map(tx, X, Y, **kw)
+        want = _oracle(walls, tx, X, Y, **kw)
+        assert np.array_equal(got, want), f"{(got != want).sum()} cells disagree on the valid-path count"
+
+
+def test_errors_are_loud(ctx):
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import make_params
+
+    ctx.set_scene(np.zeros((1, 2, 2), F), kind=[L.D2D_RIS])
+    ctx.set_grid(*unit_grid(4))
+    with pytest.raises(L.D2DUnsupported):
+        ctx.launch(make_params(max_order=1), [0.1, 0.1])
+    with pytest.raises(L.D2DError):
+        ctx.launch(make_params(max_order=7), [0.1, 0.1])
+    with pytest.raises(L.D2DError):
+        ctx.launch(make_params(approx=True, alpha=0.0), [0.1, 0.1])
