@@ -43,16 +43,38 @@ def algorithmic_flop_per_rx(n_walls, min_order, max_order, approx):
     return total
 
 
+def executed_flop(stats, approx):
+    """Prices the kernel's executed-work counters (include/d2d.h, d2d_power_map_stats; one count =
+    one 64-lane wave) with SURVEY.md section 8(d)'s per-unit figures: solver 16k + on_objects 20k per
+    evaluated candidate, loss 29k, F_seg per evaluated segment/wall test, length/power/validity 9k + 23."""
+    f_seg = 41 if approx else 17
+    s = [int(v) for v in stats]
+    per_wave = s[6] * 36 + s[7] * 29 + s[4] * f_seg + (s[8] - s[3]) * 9 + s[3] * 23
+    return per_wave * 64
+
+
 def num_candidates(n_walls, min_order, max_order):
     return sum(1 if k == 0 else n_walls * (n_walls - 1) ** (k - 1) for k in range(min_order, max_order + 1))
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask, capped by a cgroup v2 CPU quota if any."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(tx, walls, X, Y, max_order, approx, budget_rows=24):
-    """Oracle (C restatement, OpenMP, all host cores) timed on a bounded row sample of the same grid."""
+    """Oracle (C restatement, OpenMP, all usable host cores) timed on a bounded row sample of the same grid."""
     from oracle import c_oracle as CO
 
     CO.build()
-    cores = CO.max_threads()
+    cores = min(CO.max_threads(), usable_cores())
     rows = np.linspace(0, X.shape[0] - 1, budget_rows).astype(int)
     Xs, Ys = np.ascontiguousarray(X[rows]), np.ascontiguousarray(Y[rows])
     t0 = time.perf_counter()
@@ -105,7 +127,9 @@ def main():
     ms_per_step = wall * 1e3 / args.steps
 
     cells = X.size
-    flop = algorithmic_flop_per_rx(args.walls, 0, args.max_order, bool(args.approx)) * cells
+    stats = ctx.launch_stats(params, tx)  # instrumented build, outside the timed region (deterministic counts)
+    flop_unpruned = algorithmic_flop_per_rx(args.walls, 0, args.max_order, bool(args.approx)) * cells
+    flop = executed_flop(stats, bool(args.approx))
     achieved_tflops = flop / (kernel_ms * 1e-3) / 1e12
     line = {
         "metric": "ray-path candidates/s",
@@ -134,7 +158,16 @@ def main():
             "traffic": None,
             "kernel_ms": kernel_ms,
             "algorithmic_flop_per_launch": flop,
+            "unpruned_flop_per_launch": flop_unpruned,
+            "unpruned_equiv_TFLOPs": flop_unpruned / (kernel_ms * 1e-3) / 1e12,
+            "executed": {
+                "candidates": int(stats[0]) * 64, "reached_loss": int(stats[1]) * 64,
+                "reached_occlusion": int(stats[2]) * 64, "reached_fun": int(stats[3]) * 64,
+                "segment_tests": int(stats[4]) * 64, "exact_divide_tests": int(stats[5]) * 64,
+            },
+            "hbm_algorithmic_bytes": cells * 12,
             "hbm_algorithmic_GBps": cells * 12 / (kernel_ms * 1e-3) / 1e9,
+            "hbm_peak_GBps": PEAK_HBM_GBPS,
         },
     }
     if not args.no_cpu_baseline and rank == 0 and args.gpus == 1:

@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libd2d.so")
 
 D2D_MAX_ORDER = 4
+D2D_NUM_STATS = 9
 D2D_ABI_VERSION = 1
 
 D2D_WALL, D2D_RIS, D2D_VERTEX = 0, 1, 2
@@ -88,6 +89,7 @@ SYMBOLS = [
     ("d2d_list_candidates", C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     ("d2d_set_grid", C.c_int, [_ctx, _f32p, _f32p, C.c_int32, C.c_int32]),
     ("d2d_power_map_launch", C.c_int, [_ctx, C.POINTER(Params), _f32p]),
+    ("d2d_power_map_stats", C.c_int, [_ctx, C.POINTER(Params), _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]),
     ("d2d_get_map", C.c_int, [_ctx, _f32p]),
     ("d2d_power_map", C.c_int, [_ctx, C.POINTER(Params), _f32p, _f32p, _f32p, C.c_int32, C.c_int32, _f32p]),
     ("d2d_timer_begin", C.c_int, [_ctx]),

@@ -91,6 +91,7 @@ struct d2d_ctx {
     int m = 0, n = 0;
     bool have_grid = false;
     DevBuf<float> d_X, d_Y, d_out;
+    DevBuf<unsigned long long> d_stats;
 };
 
 namespace {
@@ -246,6 +247,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_X.release();
     c->d_Y.release();
     c->d_out.release();
+    c->d_stats.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -367,7 +369,7 @@ int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t 
     return D2D_OK;
 }
 
-int d2d_power_map_launch(d2d_ctx* c, const d2d_params* p, const float* tx) {
+static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsigned long long* d_stats) {
     if (!c || !tx) return fail(D2D_ERR_INVALID, "NULL argument");
     int rc = check_params(p);
     if (rc) return rc;
@@ -423,19 +425,43 @@ int d2d_power_map_launch(d2d_ctx* c, const d2d_params* p, const float* tx) {
     a.h2 = p->height * p->height;
     a.fun_id = p->fun_id;
     a.out_mode = p->out_mode;
-    a.stats = nullptr;
+    a.stats = d_stats;
 
     const int tiles_x = (c->n + d2d::TILE_W - 1) / d2d::TILE_W;
     const int tiles_y = (c->m + d2d::TILE_H - 1) / d2d::TILE_H;
     const long long tiles = (long long)tiles_x * tiles_y;
     if (tiles > 0x7fffffffLL) return fail(D2D_ERR_INVALID, "grid too large: %lld tiles", tiles);
     dim3 grid((unsigned)tiles), block(64);
-    switch (mode) {
-        case d2d::MODE_HARD: hipLaunchKernelGGL(d2d::power_fwd_kernel<d2d::MODE_HARD>, grid, block, 0, c->stream, a); break;
-        case d2d::MODE_HSIG: hipLaunchKernelGGL(d2d::power_fwd_kernel<d2d::MODE_HSIG>, grid, block, 0, c->stream, a); break;
-        default: hipLaunchKernelGGL(d2d::power_fwd_kernel<d2d::MODE_SIG>, grid, block, 0, c->stream, a); break;
+    if (d_stats) {
+        switch (mode) {
+            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HARD, true>), grid, block, 0, c->stream, a); break;
+            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HSIG, true>), grid, block, 0, c->stream, a); break;
+            default: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_SIG, true>), grid, block, 0, c->stream, a); break;
+        }
+    } else {
+        switch (mode) {
+            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HARD, false>), grid, block, 0, c->stream, a); break;
+            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HSIG, false>), grid, block, 0, c->stream, a); break;
+            default: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_SIG, false>), grid, block, 0, c->stream, a); break;
+        }
     }
     HIP_TRY(hipGetLastError());
+    return D2D_OK;
+}
+
+int d2d_power_map_launch(d2d_ctx* c, const d2d_params* p, const float* tx) { return sweep_launch(c, p, tx, nullptr); }
+
+int d2d_power_map_stats(d2d_ctx* c, const d2d_params* p, const float* tx, uint64_t* stats) {
+    if (!c || !stats) return fail(D2D_ERR_INVALID, "NULL argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = c->d_stats.ensure(D2D_NUM_STATS))) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_stats.p, 0, D2D_NUM_STATS * sizeof(unsigned long long), c->stream));
+    if ((rc = sweep_launch(c, p, tx, c->d_stats.p))) return rc;
+    unsigned long long h[D2D_NUM_STATS];
+    HIP_TRY(hipMemcpyAsync(h, c->d_stats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < D2D_NUM_STATS; ++i) stats[i] = h[i];
     return D2D_OK;
 }
 

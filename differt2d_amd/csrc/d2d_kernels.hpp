@@ -43,10 +43,20 @@ struct SweepArgs {
     float h2;                  // height * height
     int fun_id;
     int out_mode;
-    unsigned long long* stats; // optional [8] counters (debug), may be null
+    unsigned long long* stats; // [9] executed-work counters (STATS build only), may be null
 };
 
 #define D2D_EPS 1.1920929e-07f  // jnp.finfo(float32).eps, geometry.py:200
+
+// Executed-work counters of one wave (wave-uniform, live in SGPRs). Only the STATS build of the
+// kernel touches them; the timed kernel is compiled without.
+//   [0] candidates evaluated (points + on_objects)      [1] candidates that reached the loss stage
+//   [2] candidates that reached the occlusion loop      [3] candidates that reached valid*fun
+//   [4] segment/wall tests evaluated (filter)           [5] tests that took the exact-divide path
+//   [6] sum over [0] of the candidate order k           [7] sum over [1] of k   [8] sum over [3] of (k+1)
+struct WaveStats {
+    unsigned long long c[9];
+};
 
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p); }
 
@@ -75,10 +85,14 @@ __device__ __forceinline__ float clampact(float x, float alpha) {
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
-template <int K, int MODE>
+template <int K, int MODE, bool STATS>
 __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&cand)[D2D_MAX_ORDER],
                                                const float (&imgx)[D2D_MAX_ORDER], const float (&imgy)[D2D_MAX_ORDER],
-                                               float rxx, float rxy, bool lane_bad, float& acc) {
+                                               float rxx, float rxy, bool lane_bad, float& acc, WaveStats& st) {
+    if (STATS) {
+        st.c[0] += 1;
+        st.c[6] += K;
+    }
     float px[K + 2], py[K + 2];
     px[0] = a.txx;
     py[0] = a.txy;
@@ -137,6 +151,10 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     bool on_zero = (MODE == MODE_HARD) ? !on_b : (MODE == MODE_HSIG) ? (on_c == 0.0f) : (on_z <= -89.0f);
     if (K > 0 && !wave_any(!on_zero || bad)) return;  // valid == 0 in every lane: acc + 0.0
 
+    if (STATS) {
+        st.c[1] += 1;
+        st.c[7] += K;
+    }
     // ---- path loss, geometry.py:1077-1084 / 641-650 ---------------------------------------
     float loss = 0.0f;
 #pragma unroll
@@ -161,6 +179,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     else if (MODE == MODE_HSIG) live = !(on_zero || clampact(ok_x, a.alpha) == 0.0f) || bad;
     else live = !(on_zero || a.alpha * ok_x <= -89.0f) || bad;
     if (!wave_any(live)) return;
+    if (STATS) st.c[2] += 1;
 
     // ---- intersects_with_objects, geometry.py:856-906 / 623-639 / 82-173 -------------------
     float bx[K + 1], by[K + 1];
@@ -192,7 +211,10 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             float lo = a.flt_lo * D, hi = a.flt_hi * D;
             bool miss = (fd == 0.0f) || ((D >= 1e-30f) && ((ua < lo) || (ua > hi) || (ub < lo) || (ub > hi)));
             if (MODE == MODE_SIG) any_test = true;
-            if (wave_any(active && !miss)) {
+            if (STATS) st.c[4] += 1;
+            const bool need = wave_any(active && (!miss || bad));
+            if (STATS && need) st.c[5] += 1;
+            if (need) {
                 // exact path, geometry.py:163-171
                 bool dz = (fd == 0.0f);
                 float dd = dz ? 1.0f : fd;
@@ -221,6 +243,10 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         if (!wave_any(active)) break;
     }
 
+    if (STATS) {
+        st.c[3] += 1;
+        st.c[8] += K + 1;
+    }
     // ---- is_valid, geometry.py:947-963 -----------------------------------------------------
     float valid;
     if (MODE == MODE_HARD) {
@@ -257,19 +283,20 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
 
 // All candidates of order K in lexicographic order (scene.py:122-175), images built incrementally
 // (geometry.py:1086-1091, 1109).
-template <int K, int MODE>
-__device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float rxy, bool lane_bad, float& acc) {
+template <int K, int MODE, bool STATS>
+__device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float rxy, bool lane_bad, float& acc,
+                                            WaveStats& st) {
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
     float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];
     if (K == 0) {
-        eval_candidate<0, MODE>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc);
+        eval_candidate<0, MODE, STATS>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
         return;
     }
     for (int i0 = 0; i0 < a.Nc; ++i0) {
         cand[0] = a.cw[i0];
         image_of(a.refl[2 * cand[0]], a.txx, a.txy, imgx[0], imgy[0]);
         if (K == 1) {
-            eval_candidate<K, MODE>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc);
+            eval_candidate<K, MODE, STATS>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
             continue;
         }
         for (int i1 = 0; i1 < a.Nc; ++i1) {
@@ -277,7 +304,7 @@ __device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float
             if (cand[1] == cand[0]) continue;
             image_of(a.refl[2 * cand[1]], imgx[0], imgy[0], imgx[1], imgy[1]);
             if (K == 2) {
-                eval_candidate<K, MODE>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc);
+                eval_candidate<K, MODE, STATS>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
                 continue;
             }
             for (int i2 = 0; i2 < a.Nc; ++i2) {
@@ -285,14 +312,14 @@ __device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float
                 if (cand[2] == cand[1]) continue;
                 image_of(a.refl[2 * cand[2]], imgx[1], imgy[1], imgx[2], imgy[2]);
                 if (K == 3) {
-                    eval_candidate<K, MODE>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc);
+                    eval_candidate<K, MODE, STATS>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
                     continue;
                 }
                 for (int i3 = 0; i3 < a.Nc; ++i3) {
                     cand[3] = a.cw[i3];
                     if (cand[3] == cand[2]) continue;
                     image_of(a.refl[2 * cand[3]], imgx[2], imgy[2], imgx[3], imgy[3]);
-                    eval_candidate<(K >= 4 ? 4 : K), MODE>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc);
+                    eval_candidate<(K >= 4 ? 4 : K), MODE, STATS>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
                 }
             }
         }
@@ -302,7 +329,7 @@ __device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float
 constexpr int TILE_W = 8;  // a wave covers an 8 x 8 patch of RX cells: neighbouring cells share skips
 constexpr int TILE_H = 8;
 
-template <int MODE>
+template <int MODE, bool STATS>
 __global__ void __launch_bounds__(64) power_fwd_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
@@ -318,14 +345,21 @@ __global__ void __launch_bounds__(64) power_fwd_kernel(SweepArgs a) {
     const bool lane_bad = !(fabsf(rxx) < 1e18f) || !(fabsf(rxy) < 1e18f) || !(fabsf(a.txx) < 1e18f) ||
                           !(fabsf(a.txy) < 1e18f);
     float acc = 0.0f;  // scene.py:1893
-    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE>(a, rxx, rxy, lane_bad, acc);
-    if (a.min_order <= 1 && a.max_order >= 1) sweep_order<1, MODE>(a, rxx, rxy, lane_bad, acc);
-    if (a.min_order <= 2 && a.max_order >= 2) sweep_order<2, MODE>(a, rxx, rxy, lane_bad, acc);
-    if (a.min_order <= 3 && a.max_order >= 3) sweep_order<3, MODE>(a, rxx, rxy, lane_bad, acc);
-    if (a.min_order <= 4 && a.max_order >= 4) sweep_order<4, MODE>(a, rxx, rxy, lane_bad, acc);
+    WaveStats st;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) st.c[i] = 0;
+    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
+    if (a.min_order <= 1 && a.max_order >= 1) sweep_order<1, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
+    if (a.min_order <= 2 && a.max_order >= 2) sweep_order<2, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
+    if (a.min_order <= 3 && a.max_order >= 3) sweep_order<3, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
+    if (a.min_order <= 4 && a.max_order >= 4) sweep_order<4, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
     if (in_range) {
         if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
         else a.out[idx] = acc;
+    }
+    if (STATS && lane == 0 && a.stats) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicAdd(&a.stats[i], st.c[i]);
     }
 }
 

@@ -154,6 +154,13 @@ class Context:
         tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(2)
         L.check(self._lib.d2d_power_map_launch(self._ctx, C.byref(params), tx))
 
+    def launch_stats(self, params: L.Params, tx) -> np.ndarray:
+        """Runs the instrumented kernel build; returns the executed-work counters (include/d2d.h)."""
+        tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(2)
+        stats = np.zeros(L.D2D_NUM_STATS, np.uint64)
+        L.check(self._lib.d2d_power_map_stats(self._ctx, C.byref(params), tx, stats))
+        return stats
+
     def get_map(self) -> np.ndarray:
         out = np.empty(self.shape, np.float32)
         L.check(self._lib.d2d_get_map(self._ctx, out))

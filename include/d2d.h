@@ -127,6 +127,16 @@ int d2d_set_grid(d2d_ctx* ctx, const float* X, const float* Y, int32_t m, int32_
  * Inputs and outputs stay resident in HBM. */
 int d2d_power_map_launch(d2d_ctx* ctx, const d2d_params* params, const float* tx);
 
+/* Same sweep through the instrumented build of the kernel (same results, not for timing): fills
+ * stats[D2D_NUM_STATS] with executed-work counters summed over waves (one count = one 64-lane wave):
+ *   [0] candidates evaluated (interaction points + on_objects)   [1] ... that reached the loss stage
+ *   [2] ... that reached the occlusion loop                      [3] ... that reached valid * fun
+ *   [4] segment/wall tests evaluated                             [5] tests that took the exact-divide path
+ *   [6] sum of k over [0]    [7] sum of k over [1]    [8] sum of (k+1) over [3]
+ * bench.py prices these with SURVEY.md section 8(d)'s per-unit FLOP figures. */
+#define D2D_NUM_STATS 9
+int d2d_power_map_stats(d2d_ctx* ctx, const d2d_params* params, const float* tx, uint64_t* stats);
+
 /* Synchronises and copies the resident value map to out[m*n]. */
 int d2d_get_map(d2d_ctx* ctx, float* out);
 
