@@ -85,6 +85,8 @@ SYMBOLS = [
     ("d2d_synchronize", C.c_int, [_ctx]),
     ("d2d_set_scene", C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     ("d2d_set_candidate_mask", C.c_int, [_ctx, C.c_void_p]),
+    ("d2d_count_candidates", C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    ("d2d_enumerate_candidates", C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     ("d2d_num_candidates", C.c_int, [_ctx, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     ("d2d_list_candidates", C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     ("d2d_set_grid", C.c_int, [_ctx, _f32p, _f32p, C.c_int32, C.c_int32]),
@@ -92,6 +94,8 @@ SYMBOLS = [
     ("d2d_power_map_stats", C.c_int, [_ctx, C.POINTER(Params), _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]),
     ("d2d_get_map", C.c_int, [_ctx, _f32p]),
     ("d2d_power_map", C.c_int, [_ctx, C.POINTER(Params), _f32p, _f32p, _f32p, C.c_int32, C.c_int32, _f32p]),
+    ("d2d_trace_paths", C.c_int, [_ctx, C.POINTER(Params), _f32p, _f32p, C.c_int32, _i32p, _i32p, C.c_int32,
+                                  C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("d2d_timer_begin", C.c_int, [_ctx]),
     ("d2d_timer_end", C.c_int, [_ctx, C.POINTER(C.c_float)]),
 ]
@@ -142,3 +146,17 @@ def device_count() -> int:
     n = C.c_int(0)
     check(load().d2d_device_count(C.byref(n)))
     return n.value
+
+
+def enumerate_candidates(num_nodes: int, min_order: int = 0, max_order: int = 1, allowed=None):
+    """Host-native candidate enumeration (no GPU needed): list of int32 arrays of shape (k,)."""
+    lib = load()
+    a = None if allowed is None else np.ascontiguousarray(allowed, dtype=np.uint8)
+    ap = None if a is None else a.ctypes.data_as(C.c_void_p)
+    n = C.c_int64(0)
+    check(lib.d2d_count_candidates(int(num_nodes), ap, int(min_order), int(max_order), C.byref(n)))
+    cand = np.empty((max(n.value, 1), D2D_MAX_ORDER), np.int32)
+    order = np.empty(max(n.value, 1), np.int32)
+    check(lib.d2d_enumerate_candidates(int(num_nodes), ap, int(min_order), int(max_order),
+                                       cand.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p), n.value))
+    return [cand[i, : order[i]].copy() for i in range(n.value)]

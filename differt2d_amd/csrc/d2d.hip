@@ -87,6 +87,11 @@ struct d2d_ctx {
     // scene (device)
     DevBuf<float4> d_occl, d_refl;
     DevBuf<int> d_cw;
+    DevBuf<unsigned char> d_kind;
+    DevBuf<float> d_phi;
+    // trace scratch
+    DevBuf<int> d_tcand, d_torder;
+    DevBuf<float> d_ttx, d_trx, d_txys_in, d_tloss_in, d_txys, d_tloss, d_tvalid, d_ton, d_thit, d_tlen;
     // grid
     int m = 0, n = 0;
     bool have_grid = false;
@@ -121,7 +126,13 @@ int upload_refl(d2d_ctx* c) {
     }
     int rc = c->d_refl.ensure(refl.size());
     if (rc) return rc;
+    if ((rc = c->d_kind.ensure((size_t)c->N + 1))) return rc;
+    if ((rc = c->d_phi.ensure((size_t)c->N + 1))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_refl.p, refl.data(), refl.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    if (c->N > 0) {
+        HIP_TRY(hipMemcpyAsync(c->d_kind.p, c->kind.data(), (size_t)c->N, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_phi.p, c->phi.data(), (size_t)c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return D2D_OK;
 }
@@ -244,6 +255,11 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_occl.release();
     c->d_refl.release();
     c->d_cw.release();
+    c->d_kind.release();
+    c->d_phi.release();
+    c->d_tcand.release(); c->d_torder.release(); c->d_ttx.release(); c->d_trx.release();
+    c->d_txys_in.release(); c->d_tloss_in.release(); c->d_txys.release(); c->d_tloss.release();
+    c->d_tvalid.release(); c->d_ton.release(); c->d_thit.release(); c->d_tlen.release();
     c->d_X.release();
     c->d_Y.release();
     c->d_out.release();
@@ -297,25 +313,28 @@ int d2d_set_candidate_mask(d2d_ctx* c, const uint8_t* allowed) {
     return upload_mask(c);
 }
 
-int d2d_num_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int64_t* count) {
-    if (!c || !count) return fail(D2D_ERR_INVALID, "NULL argument");
-    if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
-    if (min_order < 0) return fail(D2D_ERR_INVALID, "min_order < 0");
+int d2d_count_candidates(int32_t n_objects, const uint8_t* allowed, int32_t min_order, int32_t max_order, int64_t* count) {
+    if (!count) return fail(D2D_ERR_INVALID, "count is NULL");
+    if (n_objects < 0 || min_order < 0) return fail(D2D_ERR_INVALID, "negative argument");
+    int64_t nc = 0;
+    for (int j = 0; j < n_objects; ++j) nc += (!allowed || allowed[j]) ? 1 : 0;
     int64_t total = 0;
-    for (int k = min_order; k <= max_order; ++k) total += count_order((int64_t)c->cw.size(), k);
+    for (int k = min_order; k <= max_order; ++k) total += count_order(nc, k);
     *count = total;
     return D2D_OK;
 }
 
-int d2d_list_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int32_t* cand, int32_t* order, int64_t capacity) {
-    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
-    if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
+int d2d_enumerate_candidates(int32_t n_objects, const uint8_t* allowed, int32_t min_order, int32_t max_order, int32_t* cand,
+                             int32_t* order, int64_t capacity) {
     if (min_order < 0 || max_order > D2D_MAX_ORDER) return fail(D2D_ERR_INVALID, "orders must lie in [0, %d]", D2D_MAX_ORDER);
     int64_t total = 0;
-    int rc = d2d_num_candidates(c, min_order, max_order, &total);
+    int rc = d2d_count_candidates(n_objects, allowed, min_order, max_order, &total);
     if (rc) return rc;
     if (capacity < total) return fail(D2D_ERR_INVALID, "capacity %lld < %lld candidates", (long long)capacity, (long long)total);
-    const int nc = (int)c->cw.size();
+    std::vector<int> cw;
+    for (int j = 0; j < n_objects; ++j)
+        if (!allowed || allowed[j]) cw.push_back(j);
+    const int nc = (int)cw.size();
     int64_t at = 0;
     for (int k = min_order; k <= max_order; ++k) {
         if (k == 0) {
@@ -324,7 +343,7 @@ int d2d_list_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int32_
             ++at;
             continue;
         }
-        // odometer over positions in the compact list, lexicographic, no equal neighbours
+        // odometer over positions in the compact list: lexicographic, no equal neighbours
         int pos[D2D_MAX_ORDER];
         int depth = 0;
         pos[0] = -1;
@@ -338,7 +357,7 @@ int d2d_list_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int32_
             pos[depth] = p;
             if (depth == k - 1) {
                 if (cand)
-                    for (int i = 0; i < D2D_MAX_ORDER; ++i) cand[at * D2D_MAX_ORDER + i] = (i < k) ? c->cw[pos[i]] : -1;
+                    for (int i = 0; i < D2D_MAX_ORDER; ++i) cand[at * D2D_MAX_ORDER + i] = (i < k) ? cw[pos[i]] : -1;
                 if (order) order[at] = k;
                 ++at;
             } else {
@@ -348,6 +367,18 @@ int d2d_list_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int32_
         }
     }
     return D2D_OK;
+}
+
+int d2d_num_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int64_t* count) {
+    if (!c || !count) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
+    return d2d_count_candidates(c->N, c->allowed.data(), min_order, max_order, count);
+}
+
+int d2d_list_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int32_t* cand, int32_t* order, int64_t capacity) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
+    return d2d_enumerate_candidates(c->N, c->allowed.data(), min_order, max_order, cand, order, capacity);
 }
 
 int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t n) {
@@ -462,6 +493,90 @@ int d2d_power_map_stats(d2d_ctx* c, const d2d_params* p, const float* tx, uint64
     HIP_TRY(hipMemcpyAsync(h, c->d_stats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < D2D_NUM_STATS; ++i) stats[i] = h[i];
+    return D2D_OK;
+}
+
+int d2d_trace_paths(d2d_ctx* c, const d2d_params* p, const float* tx, const float* rx, int32_t P, const int32_t* cand,
+                    const int32_t* order, int32_t C, const float* xys_in, const float* loss_in, float* xys, float* loss,
+                    float* valid, float* on, float* hit, float* length) {
+    if (!c || !tx || !rx || !cand || !order || !xys || !loss || !valid) return fail(D2D_ERR_INVALID, "NULL argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
+    if (P < 0 || C < 0) return fail(D2D_ERR_INVALID, "negative sizes");
+    if (p->solver != D2D_SOLVER_IMAGE && !xys_in) return fail(D2D_ERR_UNSUPPORTED, "solver %d is not available in this build", p->solver);
+    for (int i = 0; i < C; ++i) {
+        if (order[i] < 0 || order[i] > D2D_MAX_ORDER) return fail(D2D_ERR_INVALID, "candidate %d has order %d", i, order[i]);
+        for (int q = 0; q < order[i]; ++q) {
+            int w = cand[(size_t)i * D2D_MAX_ORDER + q];
+            if (w < 0 || w >= c->N) return fail(D2D_ERR_INVALID, "candidate %d references object %d of %d", i, w, c->N);
+            if (!xys_in && c->kind[w] != D2D_WALL)
+                return fail(D2D_ERR_UNSUPPORTED, "ImagePath needs Wall objects; object %d has kind %d", w, (int)c->kind[w]);
+        }
+    }
+    const size_t n = (size_t)P * (size_t)C;
+    if (n == 0) return D2D_OK;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = upload_occl(c, p->patch))) return rc;
+    constexpr size_t NP = D2D_MAX_ORDER + 2;
+    if ((rc = c->d_tcand.ensure((size_t)C * D2D_MAX_ORDER))) return rc;
+    if ((rc = c->d_torder.ensure((size_t)C))) return rc;
+    if ((rc = c->d_ttx.ensure(2 * (size_t)P))) return rc;
+    if ((rc = c->d_trx.ensure(2 * (size_t)P))) return rc;
+    if ((rc = c->d_txys.ensure(n * NP * 2))) return rc;
+    if ((rc = c->d_tloss.ensure(n))) return rc;
+    if ((rc = c->d_tvalid.ensure(n))) return rc;
+    if ((rc = c->d_ton.ensure(n))) return rc;
+    if ((rc = c->d_thit.ensure(n))) return rc;
+    if ((rc = c->d_tlen.ensure(n))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_tcand.p, cand, (size_t)C * D2D_MAX_ORDER * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_torder.p, order, (size_t)C * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_ttx.p, tx, 2 * (size_t)P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_trx.p, rx, 2 * (size_t)P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (xys_in) {
+        if ((rc = c->d_txys_in.ensure(n * NP * 2))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_txys_in.p, xys_in, n * NP * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        if (loss_in) {
+            if ((rc = c->d_tloss_in.ensure(n))) return rc;
+            HIP_TRY(hipMemcpyAsync(c->d_tloss_in.p, loss_in, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        }
+    }
+    d2d::TraceArgs a;
+    memset(&a, 0, sizeof a);
+    a.occl = c->d_occl.p;
+    a.refl = c->d_refl.p;
+    a.kind = c->d_kind.p;
+    a.phi = c->d_phi.p;
+    a.N = c->N;
+    a.cand = c->d_tcand.p;
+    a.order = c->d_torder.p;
+    a.C = C;
+    a.tx = c->d_ttx.p;
+    a.rx = c->d_trx.p;
+    a.P = P;
+    a.xys_in = xys_in ? c->d_txys_in.p : nullptr;
+    a.loss_in = (xys_in && loss_in) ? c->d_tloss_in.p : nullptr;
+    a.xys = c->d_txys.p;
+    a.loss = c->d_tloss.p;
+    a.valid = c->d_tvalid.p;
+    a.on = c->d_ton.p;
+    a.hit = c->d_thit.p;
+    a.length = c->d_tlen.p;
+    a.mode = p->approx ? (p->act == D2D_ACT_HARD_SIGMOID ? d2d::MODE_HSIG : d2d::MODE_SIG) : d2d::MODE_HARD;
+    a.alpha = p->alpha;
+    a.tol = p->tol;
+    a.seg_lo = -p->seg_tol;
+    a.seg_hi = 1.0f + p->seg_tol;
+    const unsigned blocks = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL(d2d::trace_kernel, dim3(blocks), dim3(64), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(xys, c->d_txys.p, n * NP * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(loss, c->d_tloss.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(valid, c->d_tvalid.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (on) HIP_TRY(hipMemcpyAsync(on, c->d_ton.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (hit) HIP_TRY(hipMemcpyAsync(hit, c->d_thit.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (length) HIP_TRY(hipMemcpyAsync(length, c->d_tlen.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return D2D_OK;
 }
 

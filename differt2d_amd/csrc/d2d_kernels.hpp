@@ -364,3 +364,214 @@ __global__ void __launch_bounds__(64) power_fwd_kernel(SweepArgs a) {
 }
 
 }  // namespace d2d
+
+// =====================================================================================
+// Path tracing kernel ("emit paths"): one thread per (tx/rx pair, candidate); writes the
+// interaction points, the loss and the validity of every candidate.  Serves
+// Scene.all_paths / all_valid_paths / accumulate_over_paths (scene.py:1156-1334),
+// ImagePath.from_tx_objects_rx (geometry.py:1013-1114) and Path.is_valid / on_objects /
+// intersects_with_objects (geometry.py:821-963) of the host mirror.  Small problem sizes:
+// written literally (every activation evaluated, NaN-propagating min/max), no skipping.
+// =====================================================================================
+namespace d2d {
+
+struct TraceArgs {
+    const float4* __restrict__ occl;
+    const float4* __restrict__ refl;
+    const unsigned char* __restrict__ kind;  // [N] D2D_WALL / D2D_RIS / D2D_VERTEX
+    const float* __restrict__ phi;           // [N]
+    int N;
+    const int* __restrict__ cand;   // [C][D2D_MAX_ORDER]
+    const int* __restrict__ order;  // [C]
+    int C;
+    const float* __restrict__ tx;  // [P][2]
+    const float* __restrict__ rx;  // [P][2]
+    int P;
+    const float* __restrict__ xys_in;   // [P][C][D2D_MAX_ORDER+2][2] or null: validate these paths instead of solving
+    const float* __restrict__ loss_in;  // [P][C] or null
+    float* __restrict__ xys;    // [P][C][D2D_MAX_ORDER+2][2]
+    float* __restrict__ loss;   // [P][C]
+    float* __restrict__ valid;  // [P][C]   final is_valid
+    float* __restrict__ on;     // [P][C]   on_objects            (may be null)
+    float* __restrict__ hit;    // [P][C]   intersects_with_objects (may be null)
+    float* __restrict__ length; // [P][C]   path_length           (may be null)
+    int mode;  // MODE_*
+    float alpha, tol, seg_lo, seg_hi;
+};
+
+// NaN-propagating min / max (jnp.minimum / jnp.maximum)
+__device__ __forceinline__ float minp(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : (a < b ? a : b); }
+__device__ __forceinline__ float maxp(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : (a > b ? a : b); }
+
+struct Truth {
+    int mode;
+    float alpha;
+    __device__ float act(float x) const {
+        float z = alpha * x;
+        if (mode == MODE_HSIG) return minp(maxp(z + 3.0f, 0.0f), 6.0f) / 6.0f;
+        return 1.0f / (1.0f + expf(-z));
+    }
+    __device__ float t_and(float a, float b) const { return mode ? minp(a, b) : ((a != 0.0f && b != 0.0f) ? 1.0f : 0.0f); }
+    __device__ float t_or(float a, float b) const { return mode ? maxp(a, b) : ((a != 0.0f || b != 0.0f) ? 1.0f : 0.0f); }
+    __device__ float t_not(float a) const { return mode ? (1.0f - a) : (a != 0.0f ? 0.0f : 1.0f); }
+    __device__ float ge(float x, float y) const { return mode ? act(x - y) : (x >= y ? 1.0f : 0.0f); }
+    __device__ float le(float x, float y) const { return mode ? act(y - x) : (x <= y ? 1.0f : 0.0f); }
+    __device__ float lt(float x, float y) const { return mode ? act(y - x) : (x < y ? 1.0f : 0.0f); }
+};
+
+__global__ void __launch_bounds__(64) trace_kernel(TraceArgs a) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long)a.P * a.C) return;
+    const int p = (int)(tid / a.C), c = (int)(tid % a.C);
+    const int k = a.order[c];
+    int cd[D2D_MAX_ORDER];
+#pragma unroll
+    for (int i = 0; i < D2D_MAX_ORDER; ++i) cd[i] = a.cand[c * D2D_MAX_ORDER + i];
+    constexpr int NP = D2D_MAX_ORDER + 2;
+    float px[NP], py[NP];
+    const float txx = a.tx[2 * p], txy = a.tx[2 * p + 1], rxx = a.rx[2 * p], rxy = a.rx[2 * p + 1];
+    const Truth T{a.mode, a.alpha};
+    float loss = 0.0f;
+
+    if (a.xys_in) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            px[i] = a.xys_in[(tid * NP + i) * 2];
+            py[i] = a.xys_in[(tid * NP + i) * 2 + 1];
+        }
+        loss = a.loss_in ? a.loss_in[tid] : 0.0f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) px[i] = py[i] = __builtin_nanf("");
+        px[0] = txx;
+        py[0] = txy;
+        // forward images, geometry.py:1086-1091
+        float imx[D2D_MAX_ORDER], imy[D2D_MAX_ORDER];
+        float ix = txx, iy = txy;
+#pragma unroll
+        for (int i = 0; i < D2D_MAX_ORDER; ++i) {
+            if (i < k) {
+                float ox, oy;
+                image_of(a.refl[2 * cd[i]], ix, iy, ox, oy);
+                ix = ox;
+                iy = oy;
+                imx[i] = ix;
+                imy[i] = iy;
+            }
+        }
+        // backward scan, geometry.py:1093-1110
+        float ptx = rxx, pty = rxy;
+#pragma unroll
+        for (int i = D2D_MAX_ORDER - 1; i >= 0; --i) {
+            if (i < k) {
+                const float4 r0 = a.refl[2 * cd[i]];
+                float ux = ptx - imx[i], uy = pty - imy[i];
+                float vx = r0.x - ptx, vy = r0.y - pty;
+                float un = ux * r0.z + uy * r0.w;
+                float vn = vx * r0.z + vy * r0.w;
+                bool z = (un == 0.0f);
+                float den = z ? 1.0f : un;
+                float incx = z ? 0.0f : (vn * ux) / den;
+                float incy = z ? 0.0f : (vn * uy) / den;
+                ptx = ptx + incx;
+                pty = pty + incy;
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    if (q == i + 1) {
+                        px[q] = ptx;
+                        py[q] = pty;
+                    }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            if (q == k + 1) {
+                px[q] = rxx;
+                py[q] = rxy;
+            }
+        // path loss, geometry.py:1077-1084
+#pragma unroll
+        for (int i = 0; i < D2D_MAX_ORDER; ++i) {
+            if (i < k) {
+                const float4 r0 = a.refl[2 * cd[i]];
+                float ix_, iy_, rx_, ry_;
+                normalize2(px[i + 1] - px[i], py[i + 1] - py[i], ix_, iy_);
+                normalize2(px[i + 2] - px[i + 1], py[i + 2] - py[i + 1], rx_, ry_);
+                float din = ix_ * r0.z + iy_ * r0.w;
+                float s2 = 2.0f * din;
+                float ex = rx_ - (ix_ - s2 * r0.z);
+                float ey = ry_ - (iy_ - s2 * r0.w);
+                loss = loss + (ex * ex + ey * ey);
+            }
+        }
+    }
+
+    // on_objects, geometry.py:821-854
+    float on = 1.0f;
+#pragma unroll
+    for (int i = 0; i < D2D_MAX_ORDER; ++i) {
+        if (i < k) {
+            float cval;
+            if (a.kind[cd[i]] == D2D_VERTEX) {
+                cval = 1.0f;  // geometry.py:397-403
+            } else {
+                const float4 r0 = a.refl[2 * cd[i]];
+                const float4 r1 = a.refl[2 * cd[i] + 1];
+                float dx = px[i + 1] - r0.x, dy = py[i + 1] - r0.y;
+                float s = (r1.x * dx + r1.y * dy) / r1.z;
+                cval = T.t_and(T.ge(s, 0.0f), T.le(s, 1.0f));
+            }
+            on = T.t_and(on, cval);
+        }
+    }
+    // intersects_with_objects, geometry.py:856-906
+    float hit = 0.0f;
+#pragma unroll
+    for (int i = 0; i <= D2D_MAX_ORDER; ++i) {
+        if (i <= k) {
+            const int ig0 = (i == 0) ? -1 : cd[i - 1];
+            const int ig1 = (i == k) ? -1 : cd[i < D2D_MAX_ORDER ? i : 0];
+            const float bx = px[i] - px[i + 1], by = py[i] - py[i + 1];
+            for (int j = 0; j < a.N; ++j) {
+                if (j == ig0 || j == ig1) continue;
+                if (a.kind[j] == D2D_VERTEX) continue;  // geometry.py:407-414: false_value, or() leaves hit unchanged
+                const float4 w = a.occl[j];
+                float Cx = w.x - px[i], Cy = w.y - py[i];
+                float fa = by * Cx - bx * Cy;
+                float fb = w.z * Cy - w.w * Cx;
+                float fd = w.w * bx - w.z * by;
+                bool dz = (fd == 0.0f);
+                float dd = dz ? 1.0f : fd;
+                float ta = dz ? __builtin_inff() : fa / dd;
+                float tb = dz ? __builtin_inff() : fb / dd;
+                float h = T.t_and(T.t_and(T.ge(ta, a.seg_lo), T.le(ta, a.seg_hi)), T.t_and(T.ge(tb, a.seg_lo), T.le(tb, a.seg_hi)));
+                hit = T.t_or(hit, h);
+            }
+        }
+    }
+    float ok = T.lt(loss, a.tol);
+    float valid = T.t_and(T.t_and(on, T.t_not(hit)), ok);
+    if (valid != valid) valid = 0.0f;  // jnp.nan_to_num
+    // path length, geometry.py:176-203
+    float r = 0.0f;
+#pragma unroll
+    for (int i = 0; i <= D2D_MAX_ORDER; ++i) {
+        if (i <= k) {
+            float vx = (px[i + 1] - px[i]) + D2D_EPS;
+            float vy = (py[i + 1] - py[i]) + D2D_EPS;
+            r = r + sqrtf(vx * vx + vy * vy);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        a.xys[(tid * NP + i) * 2] = px[i];
+        a.xys[(tid * NP + i) * 2 + 1] = py[i];
+    }
+    a.loss[tid] = loss;
+    a.valid[tid] = valid;
+    if (a.on) a.on[tid] = on;
+    if (a.hit) a.hit[tid] = hit;
+    if (a.length) a.length[tid] = r;
+}
+
+}  // namespace d2d

@@ -175,6 +175,49 @@ class Context:
         self.launch(make_params(**kw), tx)
         return self.get_map()
 
+    # -- individual paths -------------------------------------------------------------
+    def trace_paths(self, params: L.Params, tx, rx, candidates, xys_in=None, loss_in=None):
+        """Solves (or validates ``xys_in``) every candidate for every (tx, rx) pair on the GPU.
+
+        ``tx``/``rx``: (P, 2); ``candidates``: list of int arrays. Returns a dict of arrays with leading
+        shape (P, C): ``xys`` (P, C, D2D_MAX_ORDER+2, 2), ``loss``, ``valid``, ``on``, ``hit``, ``length``."""
+        tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(-1, 2)
+        rx = np.ascontiguousarray(rx, dtype=np.float32).reshape(-1, 2)
+        if tx.shape != rx.shape:
+            raise ValueError("tx and rx must pair up")
+        P, Cn = tx.shape[0], len(candidates)
+        cand = np.full((max(Cn, 1), L.D2D_MAX_ORDER), -1, np.int32)
+        order = np.zeros(max(Cn, 1), np.int32)
+        for i, c in enumerate(candidates):
+            c = np.asarray(c, dtype=np.int32).reshape(-1)
+            if c.size > L.D2D_MAX_ORDER:
+                raise L.D2DError(-1, f"candidate order {c.size} exceeds D2D_MAX_ORDER={L.D2D_MAX_ORDER}")
+            cand[i, : c.size] = c
+            order[i] = c.size
+        NP = L.D2D_MAX_ORDER + 2
+        out = {
+            "xys": np.full((P, Cn, NP, 2), np.nan, np.float32),
+            "loss": np.zeros((P, Cn), np.float32),
+            "valid": np.zeros((P, Cn), np.float32),
+            "on": np.zeros((P, Cn), np.float32),
+            "hit": np.zeros((P, Cn), np.float32),
+            "length": np.zeros((P, Cn), np.float32),
+        }
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        if xys_in is not None:
+            xys_in = np.ascontiguousarray(xys_in, dtype=np.float32).reshape(P, Cn, NP, 2)
+        if loss_in is not None:
+            loss_in = np.ascontiguousarray(loss_in, dtype=np.float32).reshape(P, Cn)
+        L.check(
+            self._lib.d2d_trace_paths(
+                self._ctx, C.byref(params), tx, rx, P, cand, order, Cn, vp(xys_in), vp(loss_in),
+                out["xys"].reshape(-1), out["loss"].reshape(-1), out["valid"].reshape(-1),
+                vp(out["on"]), vp(out["hit"]), vp(out["length"]),
+            )
+        )
+        out["order"] = order[:Cn]
+        return out
+
     # -- timing -----------------------------------------------------------------------
     def timer_begin(self):
         L.check(self._lib.d2d_timer_begin(self._ctx))

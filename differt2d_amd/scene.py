@@ -1,0 +1,459 @@
+"""
+``Scene`` with the reference's constructors, container semantics and accumulate entry points
+(``differt2d/scene.py``), NumPy in / NumPy out, computing on an MI355X through ``libd2d.so``.
+
+What runs where
+---------------
+* container methods (``with_*``, ``add_objects``, canned scenes ...) are plain host code;
+* candidate enumeration is host-native C++ (``d2d_enumerate_candidates``), as it is host-native Rust in
+  the reference;
+* ``accumulate_on_receivers_grid_over_paths`` with a natively fused ``fun`` (``utils.received_power``,
+  ``utils.path_length_squared`` ...) is ONE fused kernel launch per transmitter (``d2d_power_map_launch``);
+* ``all_paths`` / ``all_valid_paths`` / ``accumulate_over_paths`` and grid sweeps with an arbitrary Python
+  ``fun`` trace every (pair, candidate) on the GPU (``d2d_trace_paths``) and call ``fun`` on the host.
+
+No CPU implementation of the path solve / validity exists in this package.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import operator
+from collections.abc import Iterator, Mapping, Sequence
+from itertools import groupby, product
+from typing import Any, Callable, Optional, Union
+
+import numpy as np
+
+from . import _lib as L
+from . import logic
+from .abc import Object, Plottable, key_to_generator
+from .engine import Context, default_context, make_params
+from .geometry import (
+    FermatPath, ImagePath, MinPath, Path, Point, RIS, Vertex, Wall, _validity_kwargs, closest_point,
+    objects_to_tables, stack_leaves, unstack_leaves,
+)
+
+__all__ = ("Scene", "SceneName", "PyTreeDict", "all_path_candidates")
+
+F = np.float32
+SceneName = str
+PathFun = Callable[..., Any]
+
+#: grid cells x candidates above which a non-native ``fun`` is refused (host memory / time)
+EMIT_LIMIT = 8_000_000
+
+
+class PyTreeDict(Mapping):
+    """Immutable ordered mapping (reference scene.py:72-119); indexing is linear in its size."""
+
+    def __init__(self, _keys=(), _values=()):
+        self._keys = tuple(_keys)
+        self._values = tuple(_values)
+        if len(self._keys) != len(self._values):
+            raise ValueError(
+                f"Number of keys must match number of values, got {len(self._keys)} and {len(self._values)}."
+            )
+
+    @classmethod
+    def from_mapping(cls, mapping: Mapping) -> "PyTreeDict":
+        return cls(_keys=mapping.keys(), _values=mapping.values())
+
+    def __getitem__(self, key):
+        try:
+            return self._values[self._keys.index(key)]
+        except ValueError as e:
+            raise KeyError(key) from e
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __len__(self):
+        return len(self._keys)
+
+    def __repr__(self):
+        return f"PyTreeDict({dict(self)!r})"
+
+
+def all_path_candidates(num_nodes: int, min_order: int = 0, max_order: int = 1, *, order: Optional[int] = None,
+                        filter_nodes: Optional[Sequence[int]] = None) -> list:
+    """All path candidates as a list of int32 arrays (reference scene.py:122-175): for each order ascending,
+    every tuple of object indices with no two equal neighbours, lexicographic; ``filter_nodes`` are never
+    visited."""
+    if order is not None:
+        min_order = max_order = order
+    allowed = None
+    if filter_nodes is not None:
+        allowed = np.ones(num_nodes, np.uint8)
+        allowed[list(filter_nodes)] = 0
+    return L.enumerate_candidates(num_nodes, min_order, max_order, allowed)
+
+
+def _native_fun(fun, fun_args, fun_kwargs):
+    """(fun name, kwargs for make_params) if ``fun`` is fused natively, else None."""
+    name = getattr(fun, "_d2d_native", None)
+    if name is None or fun_args:
+        return None
+    extra = dict(fun_kwargs or {})
+    if name != "received_power" and extra:
+        return None
+    if set(extra) - {"r_coef", "height"}:
+        return None
+    return name, extra
+
+
+@dataclasses.dataclass(frozen=True, eq=False)
+class Scene(Plottable):
+    """2-D scene: named transmitters, named receivers and a sequence of objects (reference scene.py:178-192)."""
+
+    transmitters: Mapping = dataclasses.field(default_factory=lambda: PyTreeDict())
+    receivers: Mapping = dataclasses.field(default_factory=lambda: PyTreeDict())
+    objects: Sequence = ()
+
+    def __post_init__(self):
+        object.__setattr__(self, "transmitters", PyTreeDict.from_mapping(self.transmitters))
+        object.__setattr__(self, "receivers", PyTreeDict.from_mapping(self.receivers))
+        object.__setattr__(self, "objects", tuple(self.objects))
+
+    # ---------------------------------------------------------------- container methods
+    def with_transmitters(self, **transmitters: Point) -> "Scene":
+        return dataclasses.replace(self, transmitters=transmitters)
+
+    def with_receivers(self, **receivers: Point) -> "Scene":
+        return dataclasses.replace(self, receivers=receivers)
+
+    def with_objects(self, *objects: Object) -> "Scene":
+        return dataclasses.replace(self, objects=tuple(objects))
+
+    def filter_objects(self, filter_spec: Callable[[Object], bool]) -> "Scene":
+        return dataclasses.replace(self, objects=tuple(filter(filter_spec, self.objects)))
+
+    def update_transmitters(self, **transmitters: Point) -> "Scene":
+        return dataclasses.replace(self, transmitters={**self.transmitters, **transmitters})
+
+    def update_receivers(self, **receivers: Point) -> "Scene":
+        return dataclasses.replace(self, receivers={**self.receivers, **receivers})
+
+    def add_objects(self, *objects: Object) -> "Scene":
+        return self.with_objects(*self.objects, *objects)
+
+    def get_object(self, index) -> Object:
+        """Object at ``index`` (clamped like ``lax.switch``); homogeneous scenes only (reference scene.py:330-345)."""
+        if any(type(o) is not type(self.objects[0]) for o in self.objects):
+            raise TypeError("get_object needs objects of one type (reference: lax.switch raises)")
+        return self.objects[int(np.clip(int(index), 0, len(self.objects) - 1))]
+
+    def stacked_objects(self):
+        return stack_leaves(self.objects)
+
+    def rename_transmitters(self, **names: str) -> "Scene":
+        return self.with_transmitters(**{names.get(k, k): v for k, v in self.transmitters.items()})
+
+    def rename_receivers(self, **names: str) -> "Scene":
+        return self.with_receivers(**{names.get(k, k): v for k, v in self.receivers.items()})
+
+    @classmethod
+    def from_stacked_objects(cls, objects) -> "Scene":
+        return cls(transmitters={}, receivers={}, objects=unstack_leaves(objects))
+
+    @classmethod
+    def from_walls_array(cls, walls) -> "Scene":
+        """Empty scene from an array ``[num_walls, 2, 2]`` (reference scene.py:413-426)."""
+        return cls(transmitters={}, receivers={}, objects=[Wall(xys=xys) for xys in np.asarray(walls, dtype=F)])
+
+    @classmethod
+    def from_geojson(cls, *args, **kwargs):
+        raise NotImplementedError("Scene.from_geojson is outside the accelerated path (SURVEY.md section 8f, row 4)")
+
+    @classmethod
+    def from_scene_name(cls, scene_name: SceneName, *args, **kwargs) -> "Scene":
+        return getattr(cls, scene_name)(*args, **kwargs)
+
+    # ---------------------------------------------------------------------- canned scenes
+    @classmethod
+    def random_uniform_scene(cls, n_transmitters: int = 1, n_walls: int = 1, n_receivers: int = 1, *, key) -> "Scene":
+        """Random scene with the reference's layout (scene.py:718-733): one uniform draw of
+        ``n_transmitters + 2 n_walls + n_receivers`` points. The PRNG is NumPy's (``key`` seeds it), not Threefry."""
+        pts = key_to_generator(key).random((n_transmitters + 2 * n_walls + n_receivers, 2), dtype=F)
+        txs = {f"tx_{i}": Point(xy=pts[i, :]) for i in range(n_transmitters)}
+        rxs = {f"rx_{i}": Point(xy=pts[-(i + 1), :]) for i in range(n_receivers)}
+        walls = [Wall(xys=pts[2 * i + n_transmitters : 2 * i + 2 + n_transmitters, :]) for i in range(n_walls)]
+        return cls(transmitters=txs, receivers=rxs, objects=walls)
+
+    @classmethod
+    def basic_scene(cls, tx_coords=(0.1, 0.1), rx_coords=(0.302, 0.2147)) -> "Scene":
+        """Main room plus an inner room with a small entrance (reference scene.py:735-787)."""
+        coords = [
+            [[0.0, 0.0], [1.0, 0.0]], [[1.0, 0.0], [1.0, 1.0]], [[1.0, 1.0], [0.0, 1.0]], [[0.0, 1.0], [0.0, 0.0]],
+            [[0.4, 0.0], [0.4, 0.4]], [[0.4, 0.4], [0.3, 0.4]], [[0.1, 0.4], [0.0, 0.4]],
+        ]
+        return cls(transmitters={"tx": Point(xy=tx_coords)}, receivers={"rx": Point(xy=rx_coords)},
+                   objects=[Wall(xys=c) for c in coords])
+
+    @classmethod
+    def square_scene(cls, tx_coords=(0.2, 0.2), rx_coords=(0.5, 0.6)) -> "Scene":
+        """One square room (reference scene.py:789-836)."""
+        coords = [[[0.0, 0.0], [1.0, 0.0]], [[1.0, 0.0], [1.0, 1.0]], [[1.0, 1.0], [0.0, 1.0]], [[0.0, 1.0], [0.0, 0.0]]]
+        return cls(transmitters={"tx": Point(xy=tx_coords)}, receivers={"rx": Point(xy=rx_coords)},
+                   objects=[Wall(xys=c) for c in coords])
+
+    @classmethod
+    def square_scene_with_wall(cls, ratio: float = 0.6, tx_coords=(0.2, 0.5), rx_coords=(0.8, 0.5)) -> "Scene":
+        """Square room with a vertical wall in the middle (reference scene.py:838-882)."""
+        scene = cls.square_scene(tx_coords=tx_coords, rx_coords=rx_coords)
+        return scene.add_objects(Wall(xys=[[0.5, 0.5 * (1 - ratio)], [0.5, 0.5 * (1 + ratio)]]))
+
+    @classmethod
+    def square_scene_with_obstacle(cls, ratio: float = 0.1, **kwargs) -> "Scene":
+        """Square room with a square obstacle in its centre (reference scene.py:884-935)."""
+        scene = cls.square_scene(**kwargs)
+        hl = 0.5 * ratio
+        x0, x1, y0, y1 = 0.5 - hl, 0.5 + hl, 0.5 - hl, 0.5 + hl
+        return scene.add_objects(
+            Wall(xys=[[x0, y0], [x1, y0]]), Wall(xys=[[x1, y0], [x1, y1]]),
+            Wall(xys=[[x1, y1], [x0, y1]]), Wall(xys=[[x0, y1], [x0, y0]]),
+        )
+
+    # ------------------------------------------------------------------- plotting / extents
+    def plot(self, ax, *args, transmitters: bool = True, transmitters_args=(), transmitters_kwargs=None,
+             objects: bool = True, objects_args=(), objects_kwargs=None, receivers: bool = True, receivers_args=(),
+             receivers_kwargs=None, annotate: bool = True, **kwargs):
+        """Draws transmitters, objects and receivers (reference scene.py:937-1021)."""
+        transmitters_kwargs = {**kwargs, **(transmitters_kwargs or {})}
+        objects_kwargs = {**kwargs, **(objects_kwargs or {})}
+        receivers_kwargs = {**kwargs, **(receivers_kwargs or {})}
+        artists = []
+        if transmitters:
+            for name, tx in self.transmitters.items():
+                kw = dict(transmitters_kwargs)
+                if annotate:
+                    kw.setdefault("annotate", name)
+                artists.extend(tx.plot(ax, *args, *transmitters_args, **kw))
+        if objects:
+            for obj in self.objects:
+                artists.extend(obj.plot(ax, *args, *objects_args, **objects_kwargs))
+        if receivers:
+            for name, rx in self.receivers.items():
+                kw = dict(receivers_kwargs)
+                if annotate:
+                    kw.setdefault("annotate", name)
+                artists.extend(rx.plot(ax, *args, *receivers_args, **kw))
+        return artists
+
+    def bounding_box(self) -> np.ndarray:
+        boxes = ([t.bounding_box() for t in self.transmitters.values()] + [r.bounding_box() for r in self.receivers.values()]
+                 + [o.bounding_box() for o in self.objects])
+        boxes = np.stack(boxes)
+        return np.vstack([np.min(boxes[:, 0, :], axis=0), np.max(boxes[:, 1, :], axis=0)]).astype(F)
+
+    def get_closest_transmitter(self, coords):
+        items = list(self.transmitters.items())
+        i, d = closest_point(np.vstack([p.xy for _, p in items]), coords)
+        return items[int(i)][0], d
+
+    def get_closest_receiver(self, coords):
+        items = list(self.receivers.items())
+        i, d = closest_point(np.vstack([p.xy for _, p in items]), coords)
+        return items[int(i)][0], d
+
+    def all_transmitter_receiver_pairs(self):
+        return product(self.transmitters.items(), self.receivers.items())
+
+    # ------------------------------------------------------------------- path candidates
+    def _allowed_mask(self, filter_objects):
+        if filter_objects is None:
+            return None
+        return np.array([1 if filter_objects(o) else 0 for o in self.objects], np.uint8)
+
+    def all_path_candidates(self, min_order: int = 0, max_order: int = 1, *, order: Optional[int] = None,
+                            filter_objects: Optional[Callable[[Object], bool]] = None) -> list:
+        """Reference scene.py:1089-1134."""
+        if order is not None:
+            min_order = max_order = order
+        return L.enumerate_candidates(len(self.objects), min_order, max_order, self._allowed_mask(filter_objects))
+
+    def get_interacting_objects(self, path_candidate) -> list:
+        """Objects a candidate visits, in order (reference scene.py:1136-1154)."""
+        return [self.objects[int(i)] for i in path_candidate]
+
+    # --------------------------------------------------------------------------- GPU glue
+    @staticmethod
+    def _ctx(device: int = 0) -> Context:
+        return default_context(device)
+
+    def _upload(self, ctx: Context, filter_objects=None):
+        ctx.set_scene(*objects_to_tables(self.objects))
+        mask = self._allowed_mask(filter_objects)
+        if mask is not None:
+            ctx.set_candidate_mask(mask)
+
+    @staticmethod
+    def _solver_of(path_cls) -> str:
+        solver = getattr(path_cls, "solver", None)
+        if solver != "image":
+            raise L.D2DUnsupported(-4, f"path_cls={path_cls.__name__} has no native solver in this build (ImagePath has)")
+        return solver
+
+    def _trace(self, pairs_tx, pairs_rx, candidates, path_cls, path_cls_kwargs, key, validity):
+        """GPU trace of every candidate for every (tx, rx) pair -> dict of arrays, leading shape (P, C)."""
+        ctx = self._ctx()
+        self._upload(ctx)
+        params = make_params(max_order=L.D2D_MAX_ORDER, solver=self._solver_of(path_cls), **validity)
+        return ctx.trace_paths(params, pairs_tx, pairs_rx, candidates)
+
+    # ------------------------------------------------------------------- individual paths
+    def all_paths(self, path_cls: type = ImagePath, path_cls_kwargs: Optional[Mapping] = None, min_order: int = 0,
+                  max_order: int = 1, order: Optional[int] = None, filter_objects=None, *, key=None, **kwargs) -> Iterator:
+        """Yields ``(tx name, rx name, valid, path, path_candidate)`` for every pair and candidate
+        (reference scene.py:1156-1228)."""
+        validity = _validity_kwargs(**kwargs)
+        candidates = self.all_path_candidates(min_order=min_order, max_order=max_order, order=order, filter_objects=filter_objects)
+        pairs = list(self.all_transmitter_receiver_pairs())
+        if not pairs or not candidates:
+            return
+        txs = np.stack([t.xy for (_, t), _ in pairs])
+        rxs = np.stack([r.xy for _, (_, r) in pairs])
+        out = self._trace(txs, rxs, candidates, path_cls, path_cls_kwargs, key, validity)
+        hard = not validity["approx"]
+        for p, ((tx_key, _), (rx_key, _)) in enumerate(pairs):
+            for c, cand in enumerate(candidates):
+                k = len(cand)
+                valid = out["valid"][p, c]
+                path = path_cls(xys=out["xys"][p, c, : k + 2], loss=out["loss"][p, c])
+                yield tx_key, rx_key, (np.bool_(valid != 0) if hard else valid), path, cand
+
+    def all_valid_paths(self, approx: Optional[bool] = None, **kwargs) -> Iterator:
+        """Only the paths for which ``is_true(valid)`` (reference scene.py:1230-1248)."""
+        for tx_key, rx_key, valid, path, cand in self.all_paths(approx=approx, **kwargs):
+            if logic.is_true(valid, approx=approx):
+                yield tx_key, rx_key, path, cand
+
+    def accumulate_over_paths(self, fun: PathFun, fun_args: tuple = (), fun_kwargs: Optional[Mapping] = None, *,
+                              reduce_all: bool = False, **kwargs):
+        """Sum of ``valid * fun(...)`` over all candidates, per (tx, rx) pair (reference scene.py:1272-1334)."""
+        fun_kwargs = dict(fun_kwargs or {})
+
+        def results():
+            for (tx_key, rx_key), group in groupby(self.all_paths(**kwargs), operator.itemgetter(slice(2))):
+                acc = F(0.0)
+                tx, rx = self.transmitters[tx_key], self.receivers[rx_key]
+                for _, _, valid, path, cand in group:
+                    inter = self.get_interacting_objects(cand)
+                    acc = F(acc + F(valid) * F(fun(tx, rx, path, inter, *fun_args, **fun_kwargs)))
+                yield tx_key, rx_key, acc
+
+        if reduce_all:
+            Z = F(0.0)
+            for _, _, p in results():
+                Z = F(Z + p)
+            return Z
+        return results()
+
+    # ------------------------------------------------------------------------ grid sweeps
+    def _sweep_params(self, fun, fun_args, fun_kwargs, path_cls, path_cls_kwargs, min_order, max_order, order, kwargs):
+        validity = _validity_kwargs(**kwargs)
+        native = _native_fun(fun, fun_args, fun_kwargs)
+        common = dict(min_order=min_order, max_order=max_order, order=order, solver=self._solver_of(path_cls), **validity)
+        return native, common
+
+    def _emit_grid(self, X, Y, fixed: Point, grid_is_rx: bool, point_cls, fun, fun_args, fun_kwargs, common,
+                   filter_objects, path_cls):
+        """Arbitrary Python ``fun`` on a grid: trace all (cell, candidate) on the GPU, call ``fun`` once per
+        candidate on the batched paths, accumulate in candidate order (fp32)."""
+        candidates = self.all_path_candidates(common["min_order"], common["max_order"], order=common.get("order"),
+                                              filter_objects=filter_objects)
+        cells = X.size
+        if cells * max(len(candidates), 1) > EMIT_LIMIT:
+            raise L.D2DUnsupported(-4, f"fun={fun!r} is not fused natively and {cells} cells x {len(candidates)} candidates "
+                                       f"exceed the emit limit; use a function from differt2d_amd.utils")
+        grid = np.stack([X.reshape(-1), Y.reshape(-1)], axis=-1).astype(F)
+        other = np.broadcast_to(fixed.xy, grid.shape)
+        txs, rxs = (other, grid) if grid_is_rx else (grid, other)
+        ctx = self._ctx()
+        self._upload(ctx)
+        p = dict(common)
+        p.pop("order", None)
+        p["min_order"], p["max_order"] = 0, L.D2D_MAX_ORDER
+        out = ctx.trace_paths(make_params(**p), txs, rxs, candidates)
+        acc = np.zeros(X.shape, F)
+        for c, cand in enumerate(candidates):
+            k = len(cand)
+            path = path_cls(xys=out["xys"][:, c, : k + 2].reshape(*X.shape, k + 2, 2), loss=out["loss"][:, c].reshape(X.shape))
+            inter = self.get_interacting_objects(cand)
+            moving = point_cls(xy=grid.reshape(*X.shape, 2))
+            a, b = (fixed, moving) if grid_is_rx else (moving, fixed)
+            val = np.asarray(fun(a, b, path, inter, *fun_args, **(fun_kwargs or {})), dtype=F)
+            acc = (acc + out["valid"][:, c].reshape(X.shape) * val).astype(F)
+        return acc
+
+    def accumulate_on_receivers_grid_over_paths(
+        self, X, Y, fun: PathFun, fun_args: tuple = (), fun_kwargs: Optional[Mapping] = None, *, reduce_all: bool = False,
+        grad: bool = False, value_and_grad: bool = False, path_cls: type = ImagePath,
+        path_cls_kwargs: Optional[Mapping] = None, receiver_cls: type = Point, min_order: int = 0, max_order: int = 1,
+        order: Optional[int] = None, filter_objects: Optional[Callable[[Object], bool]] = None, key=None, **kwargs,
+    ):
+        """Power-map sweep: for every transmitter, ``Z[i, j] = sum_candidates valid * fun`` with the receiver at
+        ``(X[i, j], Y[i, j])`` (reference scene.py:1803-1953). Returns an iterator of ``(tx name, Z)``, or their
+        sum if ``reduce_all``. One fused kernel launch per transmitter when ``fun`` is native."""
+        X = np.ascontiguousarray(X, dtype=F)
+        Y = np.ascontiguousarray(Y, dtype=F)
+        if grad or value_and_grad:
+            raise L.D2DUnsupported(-4, "grad / value_and_grad need the gradient kernels (not in this build)")
+        native, common = self._sweep_params(fun, fun_args, fun_kwargs, path_cls, path_cls_kwargs, min_order, max_order,
+                                            order, kwargs)
+        txs = list(self.transmitters.items())
+
+        if native is None:
+            gen = ((name, self._emit_grid(X, Y, tx, True, receiver_cls, fun, fun_args, fun_kwargs, common, filter_objects,
+                                          path_cls)) for name, tx in txs)
+            if reduce_all:
+                Z = F(0.0)
+                for _, p in gen:
+                    Z = (Z + p).astype(F)
+                return Z
+            return gen
+
+        name, extra = native
+        ctx = self._ctx()
+        self._upload(ctx, filter_objects)
+        ctx.set_grid(X, Y)
+        if reduce_all:
+            if not txs:
+                return F(0.0)
+            for i, (_, tx) in enumerate(txs):
+                ctx.launch(make_params(fun=name, out_mode=L.OUT_ADD if i else L.OUT_OVERWRITE, **extra, **common), tx.xy)
+            Z = ctx.get_map()
+            ctx.set_candidate_mask(None)
+            return Z
+
+        def results():
+            for tx_name, tx in txs:
+                self._upload(ctx, filter_objects)
+                if ctx.shape != X.shape:
+                    ctx.set_grid(X, Y)
+                ctx.launch(make_params(fun=name, **extra, **common), tx.xy)
+                yield tx_name, ctx.get_map()
+
+        return results()
+
+    def accumulate_on_transmitters_grid_over_paths(
+        self, X, Y, fun: PathFun, fun_args: tuple = (), fun_kwargs: Optional[Mapping] = None, *, reduce_all: bool = False,
+        grad: bool = False, value_and_grad: bool = False, path_cls: type = ImagePath,
+        path_cls_kwargs: Optional[Mapping] = None, transmitter_cls: type = Point, min_order: int = 0, max_order: int = 1,
+        order: Optional[int] = None, filter_objects: Optional[Callable[[Object], bool]] = None, key=None, **kwargs,
+    ):
+        """Transmitter-grid twin (reference scene.py:1489-1648): one map per receiver. Traced on the GPU per
+        (cell, candidate); ``fun`` is evaluated on the host (no fused kernel for this orientation yet)."""
+        X = np.ascontiguousarray(X, dtype=F)
+        Y = np.ascontiguousarray(Y, dtype=F)
+        if grad or value_and_grad:
+            raise L.D2DUnsupported(-4, "grad / value_and_grad need the gradient kernels (not in this build)")
+        _, common = self._sweep_params(fun, fun_args, fun_kwargs, path_cls, path_cls_kwargs, min_order, max_order, order, kwargs)
+        gen = ((name, self._emit_grid(X, Y, rx, False, transmitter_cls, fun, fun_args, fun_kwargs, common, filter_objects,
+                                      path_cls)) for name, rx in self.receivers.items())
+        if reduce_all:
+            Z = F(0.0)
+            for _, p in gen:
+                Z = (Z + p).astype(F)
+            return Z
+        return gen

@@ -107,6 +107,15 @@ int d2d_set_scene(d2d_ctx* ctx, const float* xys, const uint8_t* kind, const flo
  * means object i may appear in a path candidate; NULL = all. Filtered objects still occlude. */
 int d2d_set_candidate_mask(d2d_ctx* ctx, const uint8_t* allowed);
 
+/* Context-free candidate enumeration (pure host integer code, replaces the Rust
+ * differt_core.rt.CompleteGraph / DiGraph.all_paths calls at differt2d/scene.py:153-175): for each order
+ * k ascending, every tuple of k allowed object indices with no two equal neighbours, lexicographic
+ * (recorded order: docs/source/notebooks/cost20120_helsinki_model.ipynb cell 20). cand is row-major
+ * [count][D2D_MAX_ORDER], -1 padded; either output pointer may be NULL. */
+int d2d_count_candidates(int32_t n_objects, const uint8_t* allowed, int32_t min_order, int32_t max_order, int64_t* count);
+int d2d_enumerate_candidates(int32_t n_objects, const uint8_t* allowed, int32_t min_order, int32_t max_order, int32_t* cand,
+                             int32_t* order, int64_t capacity);
+
 /* Number of path candidates sum_k |{tuples of length k, no equal neighbours}| for the current
  * scene and mask (differt2d/scene.py:122-175; differt-core 0.0.31 CompleteGraph.all_paths). */
 int d2d_num_candidates(d2d_ctx* ctx, int32_t min_order, int32_t max_order, int64_t* count);
@@ -143,6 +152,20 @@ int d2d_get_map(d2d_ctx* ctx, float* out);
 /* Convenience: d2d_set_grid + d2d_power_map_launch + d2d_get_map. */
 int d2d_power_map(d2d_ctx* ctx, const d2d_params* params, const float* tx, const float* X, const float* Y,
                   int32_t m, int32_t n, float* out);
+
+/* ---- individual paths (replaces Scene.all_paths / all_valid_paths / accumulate_over_paths,
+ *      differt2d/scene.py:1156-1334; ImagePath.from_tx_objects_rx, differt2d/geometry.py:1013-1114;
+ *      Path.on_objects / intersects_with_objects / is_valid / length, differt2d/geometry.py:811-963) ---- */
+
+/* For each of the P (tx, rx) pairs and each of the C candidates (cand[C][D2D_MAX_ORDER] object
+ * indices, order[C] their lengths) solves the path (or, when xys_in != NULL, takes the given points
+ * xys_in[P][C][D2D_MAX_ORDER+2][2] and losses loss_in[P][C] (NULL = 0)) and evaluates it against the
+ * current scene. Outputs (row-major, [P][C] leading): xys[..][D2D_MAX_ORDER+2][2] (unused rows NaN),
+ * loss, valid (is_valid after nan_to_num; 0/1 in hard mode), and optionally on (on_objects),
+ * hit (intersects_with_objects) and length (path_length). Synchronous. */
+int d2d_trace_paths(d2d_ctx* ctx, const d2d_params* params, const float* tx, const float* rx, int32_t P,
+                    const int32_t* cand, const int32_t* order, int32_t C, const float* xys_in, const float* loss_in,
+                    float* xys, float* loss, float* valid, float* on, float* hit, float* length);
 
 /* ---- timing on the ctx stream (HIP events) -------------------------------------------------- */
 

@@ -1,0 +1,227 @@
+"""
+GPU tests of the Scene / Path API mirror.  They read like the reference's own tests
+(tests/test_scene.py, tests/test_geometry.py of DiffeRT2d v0.4.0) with NumPy in place of JAX, and
+add oracle comparisons where the reference has no numeric expectation.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F = np.float32
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    from differt2d_amd import _lib as L
+
+    assert L.device_count() > 0
+
+
+def _scene_walls(scene):
+    return np.stack([o.xys for o in scene.objects]) if scene.objects else np.zeros((0, 2, 2), F)
+
+
+# ---- reference tests/test_geometry.py -------------------------------------------------------
+
+
+def test_image_path_loss_is_zero():
+    # tests/test_geometry.py:493-500
+    from differt2d_amd.geometry import ImagePath
+    from differt2d_amd.scene import Scene
+    from oracle import ref as R
+
+    scene = Scene.square_scene()
+    got = ImagePath.from_tx_objects_rx(scene.transmitters["tx"], scene.objects, scene.receivers["rx"])
+    assert abs(float(got.loss)) <= 1e-13
+    assert got.xys.shape == (6, 2)
+    pts, loss = R.image_path(np.array([0.2, 0.2], F), R.walls_to_objs(R.square_scene_walls()), np.array([0.5, 0.6], F))
+    assert np.array_equal(got.xys, np.stack(pts)) and got.loss == loss
+
+
+def test_image_path_no_object_and_mixed_types():
+    # tests/test_geometry.py:391-400, 90-98
+    from differt2d_amd.geometry import RIS, ImagePath, Point, Wall
+
+    path = ImagePath.from_tx_objects_rx(Point(xy=[0, 1]), [], Point(xy=[2, 1]))
+    np.testing.assert_allclose(path.length(), 2.0, rtol=1e-6)
+    with pytest.raises(ValueError):
+        ImagePath.from_tx_objects_rx(Point(xy=[0, 1]), [Wall(), RIS()], Point(xy=[2, 1]))
+
+
+@pytest.mark.parametrize("approx", [True, False])
+def test_path_validity_methods(approx):
+    # tests/test_geometry.py:402-467
+    from differt2d_amd import logic
+    from differt2d_amd.geometry import ImagePath, Path, Wall
+    from differt2d_amd.scene import Scene
+
+    with logic.enable_approx(approx):
+        scene = Scene.random_uniform_scene(key=1234, n_walls=5)
+        path = Path.from_tx_objects_rx(scene.transmitters["tx_0"], scene.objects, scene.receivers["rx_0"])
+        np.testing.assert_allclose(F(path.on_objects(scene.objects)), F(logic.true_value()), atol=1e-8)
+        got = path.on_objects([Wall(xys=[[10.0, 10.0], [20.0, 20.0]])] * 5)
+        np.testing.assert_allclose(F(got), F(logic.false_value()), atol=1e-8)
+
+        scene = Scene.random_uniform_scene(key=1234, n_walls=10)
+        path = Path.from_tx_objects_rx(scene.transmitters["tx_0"], scene.objects[:4], scene.receivers["rx_0"])
+        got = path.intersects_with_objects(scene.objects, np.arange(4, dtype=np.int32))
+        np.testing.assert_allclose(F(got), F(logic.true_value()), atol=1e-8)
+
+        scene = Scene.square_scene()
+        cand = np.arange(4, dtype=np.int32)
+        path = Path.from_tx_objects_rx(scene.transmitters["tx"], scene.objects, scene.receivers["rx"])
+        got = path.intersects_with_objects(scene.objects, cand)
+        np.testing.assert_allclose(F(got), F(logic.false_value()), atol=1e-8)
+
+        for cls in (Path, ImagePath):
+            p = cls.from_tx_objects_rx(scene.transmitters["tx"], scene.objects, scene.receivers["rx"])
+            assert logic.is_true(p.is_valid(scene.objects, cand, scene.get_interacting_objects(cand)))
+
+
+# ---- reference tests/test_scene.py ------------------------------------------------------------
+
+
+@pytest.mark.parametrize("min_order,max_order", [(0, 0), (1, 1), (2, 2), (0, 2)])
+def test_all_paths_and_valid_paths(min_order, max_order):
+    # tests/test_scene.py:401-441
+    from differt2d_amd import logic
+    from differt2d_amd.scene import Scene
+
+    scene = Scene.square_scene()
+    valid_paths = scene.all_valid_paths(approx=False, min_order=min_order, max_order=max_order, key=1234)
+    n_valid = 0
+    for tx_key, rx_key, got_valid, path, cand in scene.all_paths(min_order=min_order, max_order=max_order, approx=False):
+        assert tx_key == "tx" and rx_key == "rx"
+        assert min_order <= path.xys.shape[0] - 2 <= max_order and min_order <= len(cand) <= max_order
+        expected = path.is_valid(scene.objects, cand, scene.get_interacting_objects(cand), approx=False)
+        assert bool(got_valid) == bool(expected)
+        if logic.is_true(got_valid, approx=False):
+            _, _, got_path, _ = next(valid_paths)
+            assert np.array_equal(got_path.xys, path.xys)
+            n_valid += 1
+    with pytest.raises(StopIteration):
+        next(valid_paths)
+    assert n_valid >= 1
+
+
+def test_notebook_valid_count_via_all_paths():
+    # docs/source/notebooks/cost20120_helsinki_model.ipynb cell 6: 6 valid, 50 invalid
+    from differt2d_amd import logic
+    from differt2d_amd.scene import Scene
+
+    scene = Scene.square_scene_with_obstacle()
+    flags = [bool(logic.is_true(v, approx=False)) for _, _, v, _, _ in scene.all_paths(min_order=2, max_order=2, approx=False)]
+    assert len(flags) == 56 and sum(flags) == 6
+    assert len(list(scene.all_valid_paths(order=2))) == 6
+
+
+def _length_sq(transmitter, receiver, path, interacting_objects):
+    return path.length() ** 2  # an arbitrary python fun: goes through the GPU trace + host fun path
+
+
+def test_accumulate_over_paths():
+    # tests/test_scene.py:443-485
+    from differt2d_amd.geometry import Point
+    from differt2d_amd.scene import Scene
+
+    scene = Scene(transmitters={"tx0": Point(xy=[0.0, 0.0]), "tx1": Point(xy=[1.0, 0.0])}, objects=[],
+                  receivers={"rx0": Point(xy=[1.0, 1.0]), "rx1": Point(xy=[0.0, 1.0])})
+    got = list(scene.accumulate_over_paths(fun=_length_sq, max_order=1, approx=False))
+    assert [(a, b) for a, b, _ in got] == [("tx0", "rx0"), ("tx0", "rx1"), ("tx1", "rx0"), ("tx1", "rx1")]
+    np.testing.assert_allclose([v for _, _, v in got], [2.0, 1.0, 1.0, 2.0], rtol=1e-6)
+    total = scene.accumulate_over_paths(fun=_length_sq, reduce_all=True, max_order=1, approx=False)
+    np.testing.assert_allclose(total, 6.0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_accumulate_on_receivers_grid_los(native):
+    # tests/test_scene.py:558-627 (values; gradients are tested with the gradient kernels)
+    from differt2d_amd.geometry import Point
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import path_length_squared
+
+    fun = path_length_squared if native else _length_sq
+    scene = Scene(transmitters={"tx0": Point(xy=[0.0, 0.0]), "tx1": Point(xy=[1.0, 0.0])}, objects=[], receivers={})
+    x = np.linspace(-3, 3, 10).astype(F)
+    X, Y = np.meshgrid(x, x)
+    got = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=fun, max_order=1, approx=False, key=1234)
+    k0, Z0 = next(got)
+    k1, Z1 = next(got)
+    assert (k0, k1) == ("tx0", "tx1") and Z0.shape == X.shape and Z0.dtype == np.float32
+    np.testing.assert_allclose(Z0, X**2 + Y**2, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(Z1, (X - 1.0) ** 2 + Y**2, rtol=1e-6, atol=1e-6)
+    Z = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=fun, reduce_all=True, max_order=1, approx=False)
+    np.testing.assert_allclose(Z, X**2 + Y**2 + (X - 1.0) ** 2 + Y**2, rtol=1e-6, atol=1e-5)
+
+
+def test_accumulate_on_transmitters_grid_los():
+    # tests/test_scene.py:487-556 (values)
+    from differt2d_amd.geometry import Point
+    from differt2d_amd.scene import Scene
+
+    scene = Scene(transmitters={}, objects=[], receivers={"rx0": Point(xy=[0.0, 0.0]), "rx1": Point(xy=[0.0, 1.0])})
+    x = np.linspace(-3, 3, 10).astype(F)
+    X, Y = np.meshgrid(x, x)
+    got = dict(scene.accumulate_on_transmitters_grid_over_paths(X, Y, fun=_length_sq, max_order=1, approx=False))
+    np.testing.assert_allclose(got["rx0"], X**2 + Y**2, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got["rx1"], X**2 + (Y - 1.0) ** 2, rtol=1e-6, atol=1e-6)
+
+
+# ---- power maps with walls: Scene API == oracle (the reference has no numeric pin here) --------
+
+
+@pytest.mark.parametrize("approx", [False, True])
+@pytest.mark.parametrize("scene_name", ["square_scene_with_wall", "basic_scene", "square_scene_with_obstacle"])
+def test_power_map_examples_match_oracle(scene_name, approx):
+    # call pattern of examples/plot_power_map.py:60-67 at a smaller grid
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import received_power
+    from oracle import c_oracle as CO
+
+    scene = Scene.from_scene_name(scene_name)
+    X, Y = scene.grid(n=40)
+    P = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, reduce_all=True, approx=approx, key=1234)
+    want = CO.power_map(_scene_walls(scene), scene.transmitters["tx"].xy, X, Y, min_order=0, max_order=1, approx=approx)
+    assert np.array_equal(P, want)
+    # same thing through the non-fused route (GPU trace + host fun) agrees to fp32 rounding of the host fun
+    Pe = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=lambda *a: received_power(*a), reduce_all=True, approx=approx)
+    np.testing.assert_allclose(Pe, want, rtol=1e-6, atol=1e-6)
+
+
+def test_sweep_kwargs_and_filter_objects():
+    from differt2d_amd import logic
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import received_power
+    from oracle import c_oracle as CO
+
+    scene = Scene.basic_scene()
+    X, Y = scene.grid(m=33, n=21)
+    keep = lambda o: float(o.xys[0, 0]) != 0.4  # drop the two walls starting at x = 0.4 from the candidates
+    allowed = np.array([1 if keep(o) else 0 for o in scene.objects], np.uint8)
+    got = scene.accumulate_on_receivers_grid_over_paths(
+        X, Y, fun=received_power, fun_kwargs={"r_coef": 0.7, "height": 0.2}, reduce_all=True, min_order=1, max_order=2,
+        filter_objects=keep, approx=True, alpha=50.0, function=logic.hard_sigmoid, tol=0.02, patch=0.01)
+    want = CO.power_map(_scene_walls(scene), scene.transmitters["tx"].xy, X, Y, allowed=allowed, min_order=1, max_order=2,
+                        approx=True, alpha=50.0, tol=0.02, patch=0.01, r_coef=0.7, height=0.2)
+    assert np.array_equal(got, want)
+    # approx=None follows the module flag (reference logic.py:333-334)
+    with logic.enable_approx(True):
+        a = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, reduce_all=True)
+    b = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, reduce_all=True, approx=True)
+    assert np.array_equal(a, b)
+
+
+def test_unsupported_is_loud():
+    from differt2d_amd import _lib as L
+    from differt2d_amd.geometry import MinPath
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import received_power
+
+    scene = Scene.square_scene()
+    X, Y = scene.grid(n=4)
+    with pytest.raises(L.D2DUnsupported):
+        scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, key=1)
+    with pytest.raises(L.D2DUnsupported):
+        scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, function=lambda x, a: x, approx=True)

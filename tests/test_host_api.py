@@ -1,0 +1,212 @@
+"""CPU-only tests of the host mirror: container semantics, candidate enumeration (host-native C++),
+soft logic, per-object accessors, C-ABI symbol export, and the no-fallback rule.
+Expected values are the reference's own (file:line relative to the DiffeRT2d checkout)."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from differt2d_amd import _lib as L
+from differt2d_amd import logic
+from differt2d_amd.geometry import (
+    RIS, ImagePath, Path, Point, Ray, Vertex, Wall, closest_point, normalize, path_length, segments_intersect,
+)
+from differt2d_amd.scene import PyTreeDict, Scene, all_path_candidates
+from differt2d_amd.utils import P0, received_power
+from oracle import ref as R
+
+F = np.float32
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- C ABI ---------------------------------------------------------------------------
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "d2d.h")).read()
+    declared = set(re.findall(r"\b(d2d_[a-z_0-9]+)\s*\(", header))
+    lib = ctypes.CDLL(L.LIB_PATH)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, f"declared in include/d2d.h but not exported: {missing}"
+    bound = {name for name, _, _ in L.SYMBOLS}
+    assert declared == bound, f"ctypes table out of sync with the header: {declared ^ bound}"
+    assert lib.d2d_abi_version() == L.D2D_ABI_VERSION
+
+
+def test_params_struct_layout_matches_header():
+    assert ctypes.sizeof(L.Params) == 4 * 14 + 16
+
+
+def test_no_cpu_fallback_without_gpu():
+    if L.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from differt2d_amd.engine import Context
+
+    with pytest.raises(L.D2DError, match="NO_DEVICE"):
+        Context(0)
+    scene = Scene.square_scene()
+    X, Y = scene.grid(n=4)
+    with pytest.raises(L.D2DError):
+        scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, reduce_all=True)
+    with pytest.raises(L.D2DError):
+        ImagePath.from_tx_objects_rx(scene.transmitters["tx"], scene.objects, scene.receivers["rx"])
+
+
+# ---- candidates (reference tests/test_scene.py:372-399, notebook cell 20) ----------------
+
+
+def test_candidates_match_oracle_and_reference_order():
+    for n, lo, hi in [(1, 0, 0), (4, 0, 2), (7, 2, 2), (5, 1, 3), (3, 0, 4), (0, 0, 2)]:
+        got = all_path_candidates(n, lo, hi)
+        want = R.all_path_candidates(n, lo, hi)
+        assert len(got) == len(want)
+        assert all(np.array_equal(a, b) and a.dtype == np.int32 for a, b in zip(got, want))
+    got = [tuple(int(i) for i in c) for c in all_path_candidates(7, order=2)]
+    assert got == [(i, j) for i in range(7) for j in range(7) if i != j]
+    assert len(all_path_candidates(50, 0, 2)) == 2501
+
+
+def test_scene_candidates_filter_objects():
+    scene = Scene(objects=[Wall(), Wall(), Wall()]).add_objects(RIS(), Wall(), Wall())
+    assert len(scene.objects) == 6
+    got = scene.all_path_candidates(filter_objects=lambda o: isinstance(o, RIS), min_order=0, max_order=2)
+    assert [list(map(int, c)) for c in got] == [[], [3]]
+    got = scene.all_path_candidates(order=0)
+    assert len(got) == 1 and len(got[0]) == 0
+    with pytest.raises(L.D2DError):
+        all_path_candidates(3, 0, L.D2D_MAX_ORDER + 1)
+
+
+# ---- scenes (reference scene.py doctests) ------------------------------------------------
+
+
+@pytest.mark.parametrize("name,n,tx", [("basic_scene", 7, (0.1, 0.1)), ("square_scene", 4, (0.2, 0.2)),
+                                       ("square_scene_with_wall", 5, (0.2, 0.5)), ("square_scene_with_obstacle", 8, (0.2, 0.2))])
+def test_canned_scenes(name, n, tx):
+    scene = Scene.from_scene_name(name)
+    assert len(scene.objects) == n
+    assert np.array_equal(scene.bounding_box(), np.array([[0, 0], [1, 1]], F))
+    assert np.array_equal(scene.transmitters["tx"].xy, np.array(tx, F))
+    walls = getattr(R, name + "_walls")()
+    assert np.array_equal(np.stack([o.xys for o in scene.objects]), walls)
+
+
+def test_container_semantics():
+    scene = Scene.square_scene()
+    s2 = scene.with_transmitters(a=Point(xy=[0, 0]), b=Point(xy=[1, 1]))
+    assert list(s2.transmitters) == ["a", "b"] and list(scene.transmitters) == ["tx"]
+    s3 = s2.update_transmitters(c=Point(xy=[2, 2])).rename_transmitters(a="z")
+    assert list(s3.transmitters) == ["z", "b", "c"]
+    assert len(scene.add_objects(Wall()).objects) == 5
+    assert len(scene.filter_objects(lambda o: False).objects) == 0
+    assert scene.get_object(2) is scene.objects[2] and scene.get_object(99) is scene.objects[3]
+    with pytest.raises(TypeError):
+        scene.add_objects(RIS()).get_object(0)
+    with pytest.raises(ValueError):
+        PyTreeDict(_keys=("a",), _values=())
+    with pytest.raises(KeyError):
+        scene.transmitters["nope"]
+    pairs = list(s2.all_transmitter_receiver_pairs())
+    assert [(a[0], b[0]) for a, b in pairs] == [("a", "rx"), ("b", "rx")]
+    assert scene.get_closest_transmitter(np.array([0.0, 0.0], F))[0] == "tx"
+    sc = Scene.from_walls_array(R.square_scene_walls())
+    assert len(sc.objects) == 4 and len(sc.transmitters) == 0
+    sc = Scene.random_uniform_scene(n_walls=5, key=1234)
+    assert len(sc.objects) == 5 and list(sc.transmitters) == ["tx_0"] and list(sc.receivers) == ["rx_0"]
+
+
+def test_grid_shapes_xy_indexing():
+    # reference tests/test_abc.py:22-25: X.shape == (len(y), len(x))
+    scene = Scene.square_scene()
+    X, Y = scene.grid(m=7, n=5)
+    assert X.shape == Y.shape == (5, 7) and X.dtype == np.float32
+    assert np.array_equal(X[0], (np.arange(7) / 6).astype(F)) and np.array_equal(Y[:, 0], (np.arange(5) / 4).astype(F))
+    assert np.array_equal(scene.center(), np.array([0.5, 0.5], F))
+    assert np.array_equal(scene.get_location("NE"), np.array([1, 1], F))
+
+
+# ---- geometry accessors (reference doctests / tests/test_geometry.py) ---------------------
+
+
+def test_geometry_known_answers():
+    P = [np.array(v, F) for v in ([0, 0], [1, 0], [0.5, -1], [0.5, 1])]
+    assert segments_intersect(*P, approx=True) == F(1.0)
+    assert bool(segments_intersect(*P, approx=False))
+    assert segments_intersect(*P, approx=True, function=logic.sigmoid) == F(1.0)
+    assert path_length(np.array([[0, 0], [1, 0], [1, 1], [0, 0]], F)) == F(3.4142137)
+    assert path_length(np.array([[0, 0], [1, 0], [1, 1], [0, 1], [0, 0]], F)) == F(4.0)
+    v, l = normalize(np.array([1, 1], F))
+    assert np.array_equal(v, np.array([0.70710677, 0.70710677], F)) and l == F(1.4142135)
+    i, d = closest_point(np.array([[0, 0], [1, 0], [1, 1], [0, 1]], F), np.array([0.6, 0.3], F))
+    assert int(i) == 1 and d == F(0.49999997)
+    w = Wall(xys=[[0, 0], [1, 0]])
+    assert np.array_equal(w.image_of(np.array([0, 1], F)), np.array([0, -1], F))
+    w = Wall(xys=[[0, 0], [4, 2]])
+    for p, s in [((2, 1), 0.5), ((0, 0), 0.0), ((4, 2), 1.0), ((8, 4), 2.0), ((-4, -2), -1.0)]:
+        got = w.cartesian_to_parametric(np.array(p, F))
+        assert got.shape == (1,) and got[0] == F(s)
+    for approx in (True, False):
+        assert logic.is_true(w.contains_parametric(np.array([0.5], F), approx=approx), approx=approx)
+        assert logic.is_false(w.contains_parametric(np.array([2.0], F), approx=approx), approx=approx)
+        assert logic.is_true(w.intersects_cartesian(np.array([[0, 2], [4, 0]], F), approx=approx), approx=approx)
+        assert logic.is_false(w.intersects_cartesian(np.array([[0, 1], [4, 3]], F), approx=approx), approx=approx)
+    w = Wall(xys=[[0, 0], [4, 0]])
+    assert abs(w.evaluate_cartesian(np.array([[0, 1], [2, 0], [4, 1]], F))) < 1e-6
+    ris = RIS(xys=[[0, 0], [4, 0]], phi=0.0)
+    assert abs(ris.evaluate_cartesian(np.array([[0, 1], [2, 0], [2, 1]], F))) < 1e-6
+    v0, v1 = w.get_vertices()
+    assert isinstance(v0, Vertex) and np.array_equal(v1.xy, np.array([4, 0], F)) and Vertex.parameters_count() == 0
+    ray = Ray(xys=[[0, 0], [1, 0]]).rotate(np.pi)
+    np.testing.assert_allclose(ray.xys, [[0, 0], [-1, 0]], atol=1e-6)
+    path = Path.from_tx_objects_rx(Point(xy=[0, 1]), [Wall(xys=[[0, 0], [2, 0]])], Point(xy=[2, 1]))
+    np.testing.assert_allclose(path.length(), 2 * np.sqrt(2), rtol=1e-6)
+
+
+def test_received_power_and_p0():
+    # reference tests/test_utils.py:8-22
+    path = Path(xys=[[0, 0], [1, 0], [1, 1]])
+    got = received_power(None, None, path, [], r_coef=0.3, height=0.0)
+    np.testing.assert_allclose(got, 0.3 / 4.0, rtol=1e-6)
+    assert P0 == 100.0
+
+
+# ---- logic (reference tests/test_logic.py) ------------------------------------------------
+
+
+@pytest.mark.parametrize("alpha", [1e-3, 1.0, 10.0, 100.0])
+def test_logic_matches_oracle(alpha):
+    x = np.linspace(-5, 5, 101).astype(F)
+    y = x[::-1].copy()
+    assert np.array_equal(logic.hard_sigmoid(x, alpha), R.hard_sigmoid(x, alpha))
+    np.testing.assert_allclose(logic.sigmoid(x, alpha), R.sigmoid(x, alpha), rtol=1e-6)
+    for approx in (True, False):
+        for name in ("greater", "greater_equal", "less", "less_equal"):
+            a = getattr(logic, name)(x, y, approx=approx, alpha=alpha) if approx else getattr(logic, name)(x, y, approx=False)
+            b = getattr(R, name)(x, y, approx, alpha=alpha) if approx else getattr(R, name)(x, y, approx)
+            assert np.array_equal(a, b)
+    u, v = logic.hard_sigmoid(x, 1.0), logic.hard_sigmoid(y, 1.0)
+    assert np.array_equal(logic.logical_and(u, v, approx=True), np.minimum(u, v))
+    assert np.array_equal(logic.logical_or(u, v, approx=True), np.maximum(u, v))
+    assert np.array_equal(logic.logical_not(u, approx=True), F(1.0) - u)
+    assert np.array_equal(logic.logical_all(u, v, approx=True, axis=0), np.minimum(u, v))
+    assert np.array_equal(logic.logical_any(u > 0.5, v > 0.5, approx=False, axis=0), (u > 0.5) | (v > 0.5))
+
+
+def test_approx_flag_semantics():
+    # reference logic.py:58-215
+    assert logic.ENABLE_APPROX is ("ENABLE_APPROX" in os.environ)
+    before = logic.ENABLE_APPROX
+    with logic.enable_approx(True):
+        assert logic.true_value() == F(1.0) and logic.false_value() == F(0.0)
+        with logic.disable_approx():
+            assert logic.true_value() is np.bool_(True)
+        assert logic.ENABLE_APPROX is True
+    assert logic.ENABLE_APPROX is before
+    logic.set_approx(True)
+    assert logic.is_true(F(0.9)) and logic.is_false(F(0.1))
+    logic.set_approx(before)
+    with pytest.raises(L.D2DUnsupported):
+        logic.native_activation_name(lambda x, a: x)
