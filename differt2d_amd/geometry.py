@@ -366,6 +366,8 @@ class Path(Plottable):
         cand = np.asarray(path_candidate, dtype=np.int32).reshape(-1)
         if self.xys.ndim != 2 or self.xys.shape[0] != cand.size + 2:
             raise ValueError(f"a path with {cand.size} interactions needs {cand.size + 2} points, got {self.xys.shape}")
+        if cand.size > L.D2D_MAX_ORDER:
+            raise L.D2DError(-1, f"paths with more than D2D_MAX_ORDER={L.D2D_MAX_ORDER} interactions are not supported")
         ctx = default_context()
         ctx.set_scene(*objects_to_tables(objects))
         NP = L.D2D_MAX_ORDER + 2
