@@ -91,6 +91,10 @@ SYMBOLS = [
     ("d2d_list_candidates", C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     ("d2d_set_grid", C.c_int, [_ctx, _f32p, _f32p, C.c_int32, C.c_int32]),
     ("d2d_power_map_launch", C.c_int, [_ctx, C.POINTER(Params), _f32p]),
+    ("d2d_set_cotangent", C.c_int, [_ctx, C.c_void_p]),
+    ("d2d_power_map_vg_launch", C.c_int, [_ctx, C.POINTER(Params), _f32p, C.c_int32]),
+    ("d2d_get_grad_rx", C.c_int, [_ctx, _f32p]),
+    ("d2d_get_scene_vjp", C.c_int, [_ctx, _f32p, C.c_void_p]),
     ("d2d_power_map_stats", C.c_int, [_ctx, C.POINTER(Params), _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]),
     ("d2d_get_map", C.c_int, [_ctx, _f32p]),
     ("d2d_power_map", C.c_int, [_ctx, C.POINTER(Params), _f32p, _f32p, _f32p, C.c_int32, C.c_int32, _f32p]),

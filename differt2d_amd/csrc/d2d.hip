@@ -97,6 +97,11 @@ struct d2d_ctx {
     bool have_grid = false;
     DevBuf<float> d_X, d_Y, d_out;
     DevBuf<unsigned long long> d_stats;
+    // value+grad
+    DevBuf<float> d_grad, d_cot, d_partial;
+    DevBuf<double> d_vjp;
+    bool have_cot = false;
+    bool have_vjp = false;
 };
 
 namespace {
@@ -122,7 +127,7 @@ int upload_refl(d2d_ctx* c) {
         float sq = tx * tx + ty * ty;
         if (sq == 0.0f) sq = 1.0f;
         refl[2 * j] = make_float4(ox, oy, nx, ny);
-        refl[2 * j + 1] = make_float4(tx, ty, sq, 0.0f);
+        refl[2 * j + 1] = make_float4(tx, ty, sq, len);
     }
     int rc = c->d_refl.ensure(refl.size());
     if (rc) return rc;
@@ -264,6 +269,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_Y.release();
     c->d_out.release();
     c->d_stats.release();
+    c->d_grad.release(); c->d_cot.release(); c->d_partial.release(); c->d_vjp.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -397,10 +403,12 @@ int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t 
     c->m = m;
     c->n = n;
     c->have_grid = true;
+    c->have_cot = false;
+    c->have_vjp = false;
     return D2D_OK;
 }
 
-static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsigned long long* d_stats) {
+static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsigned long long* d_stats, int grad_mode = 0) {
     if (!c || !tx) return fail(D2D_ERR_INVALID, "NULL argument");
     int rc = check_params(p);
     if (rc) return rc;
@@ -456,6 +464,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     a.h2 = p->height * p->height;
     a.fun_id = p->fun_id;
     a.out_mode = p->out_mode;
+    a.patch = p->patch;
     a.stats = d_stats;
 
     const int tiles_x = (c->n + d2d::TILE_W - 1) / d2d::TILE_W;
@@ -463,6 +472,34 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     const long long tiles = (long long)tiles_x * tiles_y;
     if (tiles > 0x7fffffffLL) return fail(D2D_ERR_INVALID, "grid too large: %lld tiles", tiles);
     dim3 grid((unsigned)tiles), block(64);
+    if (grad_mode) {
+        const size_t cells = (size_t)c->m * c->n;
+        if ((rc = c->d_grad.ensure(2 * cells))) return rc;
+        a.grad = c->d_grad.p;
+        a.cot = c->have_cot ? c->d_cot.p : nullptr;
+        a.partial = nullptr;
+        const int n_elem = 4 * c->N + 2;
+        if (grad_mode == 2) {
+            if ((rc = c->d_partial.ensure((size_t)tiles * n_elem))) return rc;
+            if ((rc = c->d_vjp.ensure((size_t)n_elem))) return rc;
+            a.partial = c->d_partial.p;
+        }
+        if (p->out_mode == D2D_OUT_OVERWRITE) c->have_vjp = false;
+        const size_t lds = (size_t)(4 * c->N + 4) * sizeof(float);
+        switch (mode) {
+            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_HARD>), grid, block, lds, c->stream, a); break;
+            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_HSIG>), grid, block, lds, c->stream, a); break;
+            default: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_SIG>), grid, block, lds, c->stream, a); break;
+        }
+        HIP_TRY(hipGetLastError());
+        if (grad_mode == 2) {
+            hipLaunchKernelGGL(d2d::vjp_reduce_kernel, dim3((unsigned)n_elem), dim3(256), 0, c->stream, c->d_partial.p,
+                               (long)tiles, n_elem, c->d_vjp.p, (p->out_mode == D2D_OUT_ADD && c->have_vjp) ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+            c->have_vjp = true;
+        }
+        return D2D_OK;
+    }
     if (d_stats) {
         switch (mode) {
             case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HARD, true>), grid, block, 0, c->stream, a); break;
@@ -481,6 +518,53 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
 }
 
 int d2d_power_map_launch(d2d_ctx* c, const d2d_params* p, const float* tx) { return sweep_launch(c, p, tx, nullptr); }
+
+int d2d_set_cotangent(d2d_ctx* c, const float* cot) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (!c->have_grid) return fail(D2D_ERR_STATE, "d2d_set_grid must come first");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (!cot) {
+        c->have_cot = false;
+        return D2D_OK;
+    }
+    const size_t cells = (size_t)c->m * c->n;
+    if ((rc = c->d_cot.ensure(cells))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_cot.p, cot, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_cot = true;
+    return D2D_OK;
+}
+
+int d2d_power_map_vg_launch(d2d_ctx* c, const d2d_params* p, const float* tx, int32_t want_scene_vjp) {
+    return sweep_launch(c, p, tx, nullptr, want_scene_vjp ? 2 : 1);
+}
+
+int d2d_get_grad_rx(d2d_ctx* c, float* out) {
+    if (!c || !out) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (!c->have_grid || !c->d_grad.p) return fail(D2D_ERR_STATE, "no value+grad sweep has run on this grid");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->d_grad.p, 2 * (size_t)c->m * c->n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D2D_OK;
+}
+
+int d2d_get_scene_vjp(d2d_ctx* c, float* tx_bar, float* xys_bar) {
+    if (!c || !tx_bar) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (!c->have_vjp) return fail(D2D_ERR_STATE, "no scene-VJP sweep has run");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const int n_elem = 4 * c->N + 2;
+    std::vector<double> h((size_t)n_elem);
+    HIP_TRY(hipMemcpyAsync(h.data(), c->d_vjp.p, (size_t)n_elem * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (xys_bar)
+        for (int i = 0; i < 4 * c->N; ++i) xys_bar[i] = (float)h[(size_t)i];
+    tx_bar[0] = (float)h[(size_t)4 * c->N];
+    tx_bar[1] = (float)h[(size_t)4 * c->N + 1];
+    return D2D_OK;
+}
 
 int d2d_power_map_stats(d2d_ctx* c, const d2d_params* p, const float* tx, uint64_t* stats) {
     if (!c || !stats) return fail(D2D_ERR_INVALID, "NULL argument");

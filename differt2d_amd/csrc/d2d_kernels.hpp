@@ -43,6 +43,12 @@ struct SweepArgs {
     float h2;                  // height * height
     int fun_id;
     int out_mode;
+    float patch;               // geometry.py:916 (gradient kernel: chain rule through the patched end points)
+    // value+grad kernel only
+    float* __restrict__ grad;        // [m][n][2] d Z / d rx per cell
+    const float* __restrict__ cot;   // [m][n] cotangent for the scene VJP, or null (= ones)
+    float* __restrict__ partial;     // [n_waves][4 N + 2] per-wave partial sums of the scene VJP, or null
+
     unsigned long long* stats; // [9] executed-work counters (STATS build only), may be null
 };
 
@@ -85,14 +91,56 @@ __device__ __forceinline__ float clampact(float x, float alpha) {
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
-template <int K, int MODE, bool STATS>
+// Per-lane gradient state of the value+grad kernel (GRAD build of eval_candidate).
+struct GradCtx {
+    float grx, gry;  // d acc / d rx of this cell (seed 1), scene.py:1920-1923 (argnums=1)
+    float tbx, tby;  // cot * d acc / d tx, summed over candidates (scene-parameter VJP)
+    float cot;       // cotangent of this cell's accumulated value
+    float* wl;       // LDS [4 N] of this wave: sum over lanes/candidates of cot * (d/d origin.xy, d/d dest.xy)
+    bool scene;      // accumulate tbx/tby/wl ?
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// d activation(x) / d x as JAX differentiates it: hard_sigmoid = relu6(alpha x + 3) / 6 -> alpha/6 strictly inside
+// the ramp; sigmoid = lax.logistic(alpha x) -> alpha * s * (1 - s).
+template <int MODE>
+__device__ __forceinline__ float dact(float x, float alpha) {
+    float z = alpha * x;
+    if (MODE == MODE_HSIG) {
+        float y = z + 3.0f;
+        return (y > 0.0f && y < 6.0f) ? alpha / 6.0f : 0.0f;
+    }
+    float s = sigmoidf_(z);
+    return alpha * (s * (1.0f - s));
+}
+
+// adjoint of (ox, oy) = normalize2(vx, vy): vbar = (obar - (obar . o) o) / len   (len guarded like the forward)
+__device__ __forceinline__ void normalize2_bwd(float vx, float vy, float obx, float oby, float& vbx, float& vby) {
+    float len = sqrtf(vx * vx + vy * vy);
+    bool z = (len == 0.0f);
+    len = z ? 1.0f : len;
+    float ox = vx / len, oy = vy / len;
+    float d = z ? 0.0f : (obx * ox + oby * oy);
+    vbx = (obx - d * ox) / len;
+    vby = (oby - d * oy) / len;
+}
+
+template <int K, int MODE, bool STATS, bool GRAD = false>
 __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&cand)[D2D_MAX_ORDER],
                                                const float (&imgx)[D2D_MAX_ORDER], const float (&imgy)[D2D_MAX_ORDER],
-                                               float rxx, float rxy, bool lane_bad, float& acc, WaveStats& st) {
+                                               float rxx, float rxy, bool lane_bad, float& acc, WaveStats& st,
+                                               GradCtx* g = nullptr) {
     if (STATS) {
         st.c[0] += 1;
         st.c[6] += K;
     }
+    int on_i = 0, on_w = 0, hit_i = 0, hit_j = -1;  // GRAD: which activation carries the min / max
+    bool znan = false;  // GRAD: the reference's autodiff yields NaN for this (cell, candidate), see below
     float px[K + 2], py[K + 2];
     px[0] = a.txx;
     py[0] = a.txy;
@@ -117,6 +165,32 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             pty = pty + incy;
             px[i + 1] = ptx;
             py[i + 1] = pty;
+            // jnp.where(un == 0, 0, vn*u/un): reverse mode sends a zero cotangent through the untaken
+            // division by zero -> 0/0 = NaN (geometry.py:1105)
+            if (GRAD) znan = znan || z;
+        }
+    }
+    if (GRAD && MODE != MODE_HARD && K > 0) {
+        // normalize() of a zero-length segment inside the differentiated loss: sqrt'(0) * 0 = NaN
+        // (geometry.py:227-228, 647-648); in hard mode the loss only feeds a boolean and is not differentiated
+#pragma unroll
+        for (int i = 0; i <= K; ++i) znan = znan || (px[i + 1] == px[i] && py[i + 1] == py[i]);
+    }
+    if (GRAD && wave_any(znan)) {
+        const float qnan = __builtin_nanf("");
+        if (znan) {
+            g->grx = qnan;
+            g->gry = qnan;
+        }
+        if (g->scene) {
+            if (znan) g->tbx = g->tby = qnan;
+            if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    float* w4 = g->wl + 4 * cand[i];
+                    w4[0] = w4[1] = w4[2] = w4[3] = qnan;
+                }
+            }
         }
     }
 
@@ -141,10 +215,22 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             on_b = on_b && (s >= 0.0f) && (s <= 1.0f);
         } else if (MODE == MODE_HSIG) {
             nanflag = nanflag || (s != s);
-            on_c = fminf(on_c, fminf(clampact(s - 0.0f, a.alpha), clampact(1.0f - s, a.alpha)));
+            float c1 = clampact(s - 0.0f, a.alpha), c2 = clampact(1.0f - s, a.alpha);
+            float cm = fminf(c1, c2);
+            if (GRAD && cm < on_c) {
+                on_i = i;
+                on_w = (c2 < c1) ? 1 : 0;
+            }
+            on_c = fminf(on_c, cm);
         } else {
             nanflag = nanflag || (s != s);
-            on_z = fminf(on_z, fminf(a.alpha * (s - 0.0f), a.alpha * (1.0f - s)));
+            float z1 = a.alpha * (s - 0.0f), z2 = a.alpha * (1.0f - s);
+            float zm = fminf(z1, z2);
+            if (GRAD && zm < on_z) {
+                on_i = i;
+                on_w = (z2 < z1) ? 1 : 0;
+            }
+            on_z = fminf(on_z, zm);
         }
     }
     // sigmoid(z) is exactly 0 only once exp(-z) overflows: z <= -89
@@ -227,11 +313,19 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     nanflag = nanflag || (ta != ta) || (tb != tb);
                     float c = fminf(fminf(clampact(ta - a.seg_lo, a.alpha), clampact(a.seg_hi - ta, a.alpha)),
                                     fminf(clampact(tb - a.seg_lo, a.alpha), clampact(a.seg_hi - tb, a.alpha)));
+                    if (GRAD && c > hit_c) {
+                        hit_i = i;
+                        hit_j = j;
+                    }
                     hit_c = fmaxf(hit_c, c);
                 } else {
                     nanflag = nanflag || (ta != ta) || (tb != tb);
                     float z = fminf(fminf(a.alpha * (ta - a.seg_lo), a.alpha * (a.seg_hi - ta)),
                                     fminf(a.alpha * (tb - a.seg_lo), a.alpha * (a.seg_hi - tb)));
+                    if (GRAD && z > hit_z) {
+                        hit_i = i;
+                        hit_j = j;
+                    }
                     hit_z = fmaxf(hit_z, z);
                 }
             }
@@ -249,19 +343,22 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     }
     // ---- is_valid, geometry.py:947-963 -----------------------------------------------------
     float valid;
+    float on_v = 1.0f, nh_v = 1.0f, ok_v = 1.0f;
     if (MODE == MODE_HARD) {
         valid = (on_b && !hit_b && ok_b) ? 1.0f : 0.0f;
     } else if (MODE == MODE_HSIG) {
-        float on_v = on_c / 6.0f;
+        on_v = on_c / 6.0f;
         float hit_v = hit_c / 6.0f;
-        float ok_v = clampact(ok_x, a.alpha) / 6.0f;
-        valid = fminf(fminf(on_v, 1.0f - hit_v), ok_v);
+        ok_v = clampact(ok_x, a.alpha) / 6.0f;
+        nh_v = 1.0f - hit_v;
+        valid = fminf(fminf(on_v, nh_v), ok_v);
         valid = nanflag ? 0.0f : valid;  // NaN-propagating min, then nan_to_num
     } else {
-        float on_v = (K == 0) ? 1.0f : sigmoidf_(on_z);
+        on_v = (K == 0) ? 1.0f : sigmoidf_(on_z);
         float hit_v = any_test ? fmaxf(0.0f, sigmoidf_(hit_z)) : 0.0f;
-        float ok_v = sigmoidf_(a.alpha * ok_x);
-        valid = fminf(fminf(on_v, 1.0f - hit_v), ok_v);
+        ok_v = sigmoidf_(a.alpha * ok_x);
+        nh_v = 1.0f - hit_v;
+        valid = fminf(fminf(on_v, nh_v), ok_v);
         valid = nanflag ? 0.0f : valid;
     }
 
@@ -279,24 +376,252 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     else if (a.fun_id == D2D_FUN_LENGTH) f = r;
     else f = 1.0f;
     acc = acc + valid * f;  // scene.py:1909
+
+    if (GRAD) {
+        // =========================== reverse mode, hand derived ===========================
+        // acc += valid * f   ->   fbar = valid, vbar = f (valid is a constant in hard mode / after nan_to_num(NaN))
+        const float fbar = valid;
+        const float vbar = (MODE == MODE_HARD || nanflag) ? 0.0f : f;
+        float rbar;
+        if (a.fun_id == D2D_FUN_RECEIVED_POWER) {
+            float Dn = a.h2 + r * r;
+            rbar = -(fbar * (f / Dn)) * (2.0f * r);
+        } else if (a.fun_id == D2D_FUN_LENGTH_SQUARED) rbar = fbar * (2.0f * r);
+        else if (a.fun_id == D2D_FUN_LENGTH) rbar = fbar;
+        else rbar = 0.0f;
+
+        float pbx[K + 2], pby[K + 2];
+#pragma unroll
+        for (int i = 0; i < K + 2; ++i) pbx[i] = pby[i] = 0.0f;
+        // path_length
+#pragma unroll
+        for (int i = 0; i <= K; ++i) {
+            float wx = (px[i + 1] - px[i]) + D2D_EPS, wy = (py[i + 1] - py[i]) + D2D_EPS;
+            float len = sqrtf(wx * wx + wy * wy);
+            float gx = rbar * (wx / len), gy = rbar * (wy / len);
+            pbx[i + 1] += gx; pby[i + 1] += gy;
+            pbx[i] -= gx; pby[i] -= gy;
+        }
+        // adjoints of the candidate's walls: origin, normal, direction t (the latter through on_objects only)
+        constexpr int KK = (K > 0) ? K : 1;
+        float obx[KK], oby[KK], nbx[KK], nby[KK], tbx[KK], tby[KK];
+#pragma unroll
+        for (int i = 0; i < KK; ++i) obx[i] = oby[i] = nbx[i] = nby[i] = tbx[i] = tby[i] = 0.0f;
+        // adjoint of the selected occluder (per lane): patched origin P1 and A = P2 - P1
+        float p1bx = 0.0f, p1by = 0.0f, abx = 0.0f, aby = 0.0f;
+        bool occ = false;
+
+        if (MODE != MODE_HARD) {
+            const int sel = (on_v <= nh_v && on_v <= ok_v) ? 0 : ((nh_v <= ok_v) ? 1 : 2);
+            // ---- ok = activation(tol - loss)
+            float lossbar = (sel == 2) ? -(vbar * dact<MODE>(ok_x, a.alpha)) : 0.0f;
+            if (K > 0 && wave_any(lossbar != 0.0f)) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const float4 r0 = a.refl[2 * cand[i]];
+                    float v1x = px[i + 1] - px[i], v1y = py[i + 1] - py[i];
+                    float v2x = px[i + 2] - px[i + 1], v2y = py[i + 2] - py[i + 1];
+                    float ix, iy, rx_, ry_;
+                    normalize2(v1x, v1y, ix, iy);
+                    normalize2(v2x, v2y, rx_, ry_);
+                    float din = ix * r0.z + iy * r0.w;
+                    float s2 = 2.0f * din;
+                    float ex = rx_ - (ix - s2 * r0.z), ey = ry_ - (iy - s2 * r0.w);
+                    float ebx = 2.0f * ex * lossbar, eby = 2.0f * ey * lossbar;
+                    // e = r - i + s2 n
+                    float rbx = ebx, rby = eby;
+                    float ibx = -ebx, iby = -eby;
+                    float s2b = ebx * r0.z + eby * r0.w;
+                    nbx[i] += s2 * ebx; nby[i] += s2 * eby;
+                    float dinb = 2.0f * s2b;
+                    ibx += dinb * r0.z; iby += dinb * r0.w;
+                    nbx[i] += dinb * ix; nby[i] += dinb * iy;
+                    float a1x, a1y, a2x, a2y;
+                    normalize2_bwd(v1x, v1y, ibx, iby, a1x, a1y);
+                    normalize2_bwd(v2x, v2y, rbx, rby, a2x, a2y);
+                    pbx[i + 1] += a1x; pby[i + 1] += a1y; pbx[i] -= a1x; pby[i] -= a1y;
+                    pbx[i + 2] += a2x; pby[i + 2] += a2y; pbx[i + 1] -= a2x; pby[i + 1] -= a2y;
+                }
+            }
+            // ---- on_objects: the activation carrying the min
+            if (K > 0) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const float4 r0 = a.refl[2 * cand[i]];
+                    const float4 r1 = a.refl[2 * cand[i] + 1];
+                    float dx = px[i + 1] - r0.x, dy = py[i + 1] - r0.y;
+                    float s = (r1.x * dx + r1.y * dy) / r1.z;
+                    float x = on_w ? (1.0f - s) : (s - 0.0f);
+                    float sb = (sel == 0 && i == on_i) ? vbar * dact<MODE>(x, a.alpha) * (on_w ? -1.0f : 1.0f) : 0.0f;
+                    float q = sb / r1.z;
+                    pbx[i + 1] += q * r1.x; pby[i + 1] += q * r1.y;
+                    obx[i] -= q * r1.x; oby[i] -= q * r1.y;
+                    // t enters the numerator and sq = t.t (a constant 1 when the wall is degenerate)
+                    bool degenerate = (r1.x * r1.x + r1.y * r1.y == 0.0f);
+                    float sqb = degenerate ? 0.0f : -(q * s);
+                    tbx[i] += q * dx + 2.0f * sqb * r1.x;
+                    tby[i] += q * dy + 2.0f * sqb * r1.y;
+                }
+            }
+            // ---- not(intersects): the test carrying the max, and inside it the activation carrying the min
+            occ = (sel == 1) && (hit_j >= 0) && (vbar != 0.0f);
+            if (wave_any(occ)) {
+                const int jj = occ ? hit_j : 0;
+                const float4 w = a.occl[jj];
+                float qx = 0.0f, qy = 0.0f, q1x = 0.0f, q1y = 0.0f;  // P3 = p[hit_i], P4 = p[hit_i + 1]
+#pragma unroll
+                for (int i = 0; i <= K; ++i)
+                    if (i == hit_i) {
+                        qx = px[i]; qy = py[i]; q1x = px[i + 1]; q1y = py[i + 1];
+                    }
+                float Bx = qx - q1x, By = qy - q1y;
+                float Cx = w.x - qx, Cy = w.y - qy;
+                float fa = By * Cx - Bx * Cy, fb = w.z * Cy - w.w * Cx, fd = w.w * Bx - w.z * By;
+                bool dz = (fd == 0.0f);
+                float dd = dz ? 1.0f : fd;
+                float ta = dz ? __builtin_inff() : fa / dd, tb = dz ? __builtin_inff() : fb / dd;
+                float x0 = ta - a.seg_lo, x1 = a.seg_hi - ta, x2 = tb - a.seg_lo, x3 = a.seg_hi - tb;
+                float m0, m1, m2, m3;
+                if (MODE == MODE_HSIG) { m0 = clampact(x0, a.alpha); m1 = clampact(x1, a.alpha); m2 = clampact(x2, a.alpha); m3 = clampact(x3, a.alpha); }
+                else { m0 = a.alpha * x0; m1 = a.alpha * x1; m2 = a.alpha * x2; m3 = a.alpha * x3; }
+                int which = 0; float mm = m0;
+                if (m1 < mm) { mm = m1; which = 1; }
+                if (m2 < mm) { mm = m2; which = 2; }
+                if (m3 < mm) { mm = m3; which = 3; }
+                float xsel = (which == 0) ? x0 : (which == 1) ? x1 : (which == 2) ? x2 : x3;
+                // valid = ... 1 - hit ... : d valid / d hit = -1
+                float hb = (occ && !dz) ? -(vbar * dact<MODE>(xsel, a.alpha)) : 0.0f;
+                float tab = (which == 0) ? hb : (which == 1) ? -hb : 0.0f;
+                float tbb = (which == 2) ? hb : (which == 3) ? -hb : 0.0f;
+                float fab = tab / dd, fbb = tbb / dd;
+                float fdb = -(tab * ta + tbb * tb) / dd;
+                fdb = (hb != 0.0f) ? fdb : 0.0f;
+                // fa = By Cx - Bx Cy ; fb = Ax Cy - Ay Cx ; fd = Ay Bx - Ax By
+                float Bbx = -fab * Cy + fdb * w.w, Bby = fab * Cx - fdb * w.z;
+                float Cbx = fab * By - fbb * w.w, Cby = -fab * Bx + fbb * w.z;
+                abx = fbb * Cy - fdb * By;
+                aby = -fbb * Cx + fdb * Bx;
+                p1bx = Cbx; p1by = Cby;
+                float g3x = Bbx - Cbx, g3y = Bby - Cby;  // d/d P3
+                float g4x = -Bbx, g4y = -Bby;            // d/d P4
+#pragma unroll
+                for (int i = 0; i <= K; ++i)
+                    if (i == hit_i) {
+                        pbx[i] += g3x; pby[i] += g3y;
+                        pbx[i + 1] += g4x; pby[i + 1] += g4y;
+                    }
+            }
+        }
+
+        // ---- image method backward scan (reverse of geometry.py:1093-1110) -----------------
+        float ibx_[KK], iby_[KK];  // adjoints of the images
+#pragma unroll
+        for (int i = 0; i < KK; ++i) ibx_[i] = iby_[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const float4 r0 = a.refl[2 * cand[i]];
+            const float ptx = px[i + 2], pty = py[i + 2];  // the point the step started from
+            float ux = ptx - imgx[i], uy = pty - imgy[i];
+            float vx = r0.x - ptx, vy = r0.y - pty;
+            float un = ux * r0.z + uy * r0.w;
+            float vn = vx * r0.z + vy * r0.w;
+            const float qbx = pbx[i + 1], qby = pby[i + 1];
+            float ptbx = qbx, ptby = qby;  // p[i+1] = pt + inc
+            if (un != 0.0f) {
+                float incx = (vn * ux) / un, incy = (vn * uy) / un;
+                float mbx = qbx / un, mby = qby / un;
+                float unb = -(qbx * incx + qby * incy) / un;
+                float vnb = mbx * ux + mby * uy;
+                float ubx = mbx * vn + unb * r0.z, uby = mby * vn + unb * r0.w;
+                nbx[i] += unb * ux + vnb * vx; nby[i] += unb * uy + vnb * vy;
+                float vbx = vnb * r0.z, vby = vnb * r0.w;
+                ptbx += ubx - vbx; ptby += uby - vby;
+                ibx_[i] -= ubx; iby_[i] -= uby;
+                obx[i] += vbx; oby[i] += vby;
+            }
+            pbx[i + 2] += ptbx; pby[i + 2] += ptby;
+        }
+        // ---- forward image chain backward (reverse of geometry.py:1086-1091) ----------------
+        float txbx = pbx[0], txby = pby[0];
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) {
+            const float4 r0 = a.refl[2 * cand[i]];
+            const float prx = (i == 0) ? a.txx : imgx[i > 0 ? i - 1 : 0];
+            const float pry = (i == 0) ? a.txy : imgy[i > 0 ? i - 1 : 0];
+            float wx = prx - r0.x, wy = pry - r0.y;
+            float dn = wx * r0.z + wy * r0.w;
+            float s2 = 2.0f * dn;
+            float gx = ibx_[i], gy = iby_[i];
+            float s2b = -(gx * r0.z + gy * r0.w);
+            nbx[i] += -s2 * gx; nby[i] += -s2 * gy;
+            float dnb = 2.0f * s2b;
+            float wbx = dnb * r0.z, wby = dnb * r0.w;
+            nbx[i] += dnb * wx; nby[i] += dnb * wy;
+            float prbx = gx + wbx, prby = gy + wby;
+            obx[i] -= wbx; oby[i] -= wby;
+            if (i == 0) { txbx += prbx; txby += prby; }
+            else { ibx_[i > 0 ? i - 1 : 0] += prbx; iby_[i > 0 ? i - 1 : 0] += prby; }
+        }
+        g->grx += pbx[K + 1];
+        g->gry += pby[K + 1];
+
+        if (g->scene) {
+            g->tbx += g->cot * txbx;
+            g->tby += g->cot * txby;
+            // normals -> wall end points: n = m / len, m = (t_y, -t_x); t = dest - origin
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float4 r0 = a.refl[2 * cand[i]];
+                const float4 r1 = a.refl[2 * cand[i] + 1];
+                float len = r1.w;  // |t| guarded to 1
+                bool z = (r1.x * r1.x + r1.y * r1.y == 0.0f);
+                float d = z ? 0.0f : (nbx[i] * r0.z + nby[i] * r0.w);
+                float mbx = (nbx[i] - d * r0.z) / len, mby = (nby[i] - d * r0.w) / len;
+                float ttx = tbx[i] - mby, tty = tby[i] + mbx;  // m_x = t_y, m_y = -t_x
+                float dbx = ttx, dby = tty;
+                float ox_ = obx[i] - ttx, oy_ = oby[i] - tty;
+                float s0 = wave_sum(g->cot * ox_), s1 = wave_sum(g->cot * oy_);
+                float s2_ = wave_sum(g->cot * dbx), s3 = wave_sum(g->cot * dby);
+                if ((threadIdx.x & 63) == 0) {
+                    float* w4 = g->wl + 4 * cand[i];
+                    w4[0] += s0; w4[1] += s1; w4[2] += s2_; w4[3] += s3;
+                }
+            }
+            if (MODE != MODE_HARD && wave_any(occ)) {
+                // P1 = (1 + patch) o - patch d ; P2 = (1 + patch) d - patch o ; A = P2 - P1
+                float P2bx = abx, P2by = aby;
+                float P1bx = p1bx - abx, P1by = p1by - aby;
+                float pa = a.patch;
+                float ox_ = (1.0f + pa) * P1bx - pa * P2bx, oy_ = (1.0f + pa) * P1by - pa * P2by;
+                float dx_ = (1.0f + pa) * P2bx - pa * P1bx, dy_ = (1.0f + pa) * P2by - pa * P1by;
+                if (occ) {
+                    float* w4 = g->wl + 4 * hit_j;
+                    atomicAdd(&w4[0], g->cot * ox_);
+                    atomicAdd(&w4[1], g->cot * oy_);
+                    atomicAdd(&w4[2], g->cot * dx_);
+                    atomicAdd(&w4[3], g->cot * dy_);
+                }
+            }
+        }
+    }
 }
 
 // All candidates of order K in lexicographic order (scene.py:122-175), images built incrementally
 // (geometry.py:1086-1091, 1109).
-template <int K, int MODE, bool STATS>
+template <int K, int MODE, bool STATS, bool GRAD = false>
 __device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float rxy, bool lane_bad, float& acc,
-                                            WaveStats& st) {
+                                            WaveStats& st, GradCtx* g = nullptr) {
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
     float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];
     if (K == 0) {
-        eval_candidate<0, MODE, STATS>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
+        eval_candidate<0, MODE, STATS, GRAD>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st, g);
         return;
     }
     for (int i0 = 0; i0 < a.Nc; ++i0) {
         cand[0] = a.cw[i0];
         image_of(a.refl[2 * cand[0]], a.txx, a.txy, imgx[0], imgy[0]);
         if (K == 1) {
-            eval_candidate<K, MODE, STATS>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
+            eval_candidate<K, MODE, STATS, GRAD>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st, g);
             continue;
         }
         for (int i1 = 0; i1 < a.Nc; ++i1) {
@@ -304,7 +629,7 @@ __device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float
             if (cand[1] == cand[0]) continue;
             image_of(a.refl[2 * cand[1]], imgx[0], imgy[0], imgx[1], imgy[1]);
             if (K == 2) {
-                eval_candidate<K, MODE, STATS>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
+                eval_candidate<K, MODE, STATS, GRAD>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st, g);
                 continue;
             }
             for (int i2 = 0; i2 < a.Nc; ++i2) {
@@ -312,14 +637,14 @@ __device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float
                 if (cand[2] == cand[1]) continue;
                 image_of(a.refl[2 * cand[2]], imgx[1], imgy[1], imgx[2], imgy[2]);
                 if (K == 3) {
-                    eval_candidate<K, MODE, STATS>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
+                    eval_candidate<K, MODE, STATS, GRAD>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st, g);
                     continue;
                 }
                 for (int i3 = 0; i3 < a.Nc; ++i3) {
                     cand[3] = a.cw[i3];
                     if (cand[3] == cand[2]) continue;
                     image_of(a.refl[2 * cand[3]], imgx[2], imgy[2], imgx[3], imgy[3]);
-                    eval_candidate<(K >= 4 ? 4 : K), MODE, STATS>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
+                    eval_candidate<(K >= 4 ? 4 : K), MODE, STATS, GRAD>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st, g);
                 }
             }
         }
@@ -361,6 +686,82 @@ __global__ void __launch_bounds__(64) power_fwd_kernel(SweepArgs a) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) atomicAdd(&a.stats[i], st.c[i]);
     }
+}
+
+// Value + gradient sweep: same forward arithmetic as power_fwd_kernel (bit-identical values), plus the
+// hand-derived adjoint of every contributing candidate.  One wave per block; the wave's partial sums of
+// the scene-parameter VJP live in LDS and are written to `partial` (reduced in fixed order afterwards,
+// so results are reproducible run to run).
+template <int MODE>
+__global__ void __launch_bounds__(64) power_vg_kernel(SweepArgs a) {
+    extern __shared__ float wl[];  // [4 N]
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
+    const int tile = blockIdx.x;
+    const int tcol = tile % tiles_x, trow = tile / tiles_x;
+    const int col = tcol * TILE_W + (lane & (TILE_W - 1));
+    const int row = trow * TILE_H + (lane / TILE_W);
+    const bool in_range = (col < a.n) && (row < a.m);
+    const int ccol = col < a.n ? col : a.n - 1;
+    const int crow = row < a.m ? row : a.m - 1;
+    const long idx = (long)crow * a.n + ccol;
+    const float rxx = a.X[idx], rxy = a.Y[idx];
+    const bool lane_bad = !(fabsf(rxx) < 1e18f) || !(fabsf(rxy) < 1e18f) || !(fabsf(a.txx) < 1e18f) ||
+                          !(fabsf(a.txy) < 1e18f);
+    const bool scene = a.partial != nullptr;
+    if (scene) {
+        for (int i = lane; i < 4 * a.N; i += 64) wl[i] = 0.0f;
+        __syncthreads();
+    }
+    GradCtx g;
+    g.grx = g.gry = g.tbx = g.tby = 0.0f;
+    g.cot = in_range ? (a.cot ? a.cot[idx] : 1.0f) : 0.0f;  // clamped duplicate lanes contribute nothing
+    g.wl = wl;
+    g.scene = scene;
+    float acc = 0.0f;
+    WaveStats st;
+    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, true>(a, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 1 && a.max_order >= 1) sweep_order<1, MODE, false, true>(a, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 2 && a.max_order >= 2) sweep_order<2, MODE, false, true>(a, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 3 && a.max_order >= 3) sweep_order<3, MODE, false, true>(a, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 4 && a.max_order >= 4) sweep_order<4, MODE, false, true>(a, rxx, rxy, lane_bad, acc, st, &g);
+    if (in_range) {
+        if (a.out_mode == D2D_OUT_ADD) {
+            a.out[idx] = a.out[idx] + acc;
+            a.grad[2 * idx] = a.grad[2 * idx] + g.grx;
+            a.grad[2 * idx + 1] = a.grad[2 * idx + 1] + g.gry;
+        } else {
+            a.out[idx] = acc;
+            a.grad[2 * idx] = g.grx;
+            a.grad[2 * idx + 1] = g.gry;
+        }
+    }
+    if (scene) {
+        float sx = wave_sum(g.tbx), sy = wave_sum(g.tby);
+        __syncthreads();
+        float* dst = a.partial + (long)blockIdx.x * (4 * a.N + 2);
+        for (int i = lane; i < 4 * a.N; i += 64) dst[i] = wl[i];
+        if (lane == 0) {
+            dst[4 * a.N] = sx;
+            dst[4 * a.N + 1] = sy;
+        }
+    }
+}
+
+// Fixed-order reduction of the per-wave partials: out[e] (+)= sum_w partial[w][e], accumulated in fp64.
+__global__ void __launch_bounds__(256) vjp_reduce_kernel(const float* __restrict__ partial, long n_waves, int n_elem,
+                                                         double* __restrict__ out, int accumulate) {
+    __shared__ double sm[256];
+    const int e = blockIdx.x;
+    double s = 0.0;
+    for (long w = threadIdx.x; w < n_waves; w += 256) s += (double)partial[w * n_elem + e];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[e] = (accumulate ? out[e] : 0.0) + sm[0];
 }
 
 }  // namespace d2d

@@ -154,6 +154,42 @@ class Context:
         tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(2)
         L.check(self._lib.d2d_power_map_launch(self._ctx, C.byref(params), tx))
 
+    def set_cotangent(self, cot=None):
+        """Cotangent of the value map for the scene VJP (None = ones)."""
+        if cot is None:
+            L.check(self._lib.d2d_set_cotangent(self._ctx, None))
+            return
+        cot = np.ascontiguousarray(cot, dtype=np.float32)
+        if cot.shape != self.shape:
+            raise ValueError(f"cotangent must have the grid's shape {self.shape}, got {cot.shape}")
+        L.check(self._lib.d2d_set_cotangent(self._ctx, cot.ctypes.data_as(C.c_void_p)))
+
+    def launch_vg(self, params: L.Params, tx, scene_vjp: bool = False):
+        """Fused value+grad sweep (per-cell d/d rx; optionally the VJP w.r.t. tx and object end points)."""
+        tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(2)
+        L.check(self._lib.d2d_power_map_vg_launch(self._ctx, C.byref(params), tx, int(bool(scene_vjp))))
+
+    def get_grad_rx(self) -> np.ndarray:
+        out = np.empty((*self.shape, 2), np.float32)
+        L.check(self._lib.d2d_get_grad_rx(self._ctx, out.reshape(-1)))
+        return out
+
+    def get_scene_vjp(self):
+        """Returns (tx_bar[2], xys_bar[N,2,2])."""
+        tx_bar = np.zeros(2, np.float32)
+        xys_bar = np.zeros((max(self.n_objects, 1), 2, 2), np.float32)
+        L.check(self._lib.d2d_get_scene_vjp(self._ctx, tx_bar, xys_bar.ctypes.data_as(C.c_void_p)))
+        return tx_bar, xys_bar[: self.n_objects]
+
+    def value_and_grads(self, tx, X, Y, cotangent=None, **kw):
+        """One call: value map, per-cell grad_rx, tx_bar, walls_bar (mirrors oracle.ref.power_map_value_and_grads)."""
+        self.set_grid(X, Y)
+        self.set_cotangent(cotangent)
+        self.launch_vg(make_params(**kw), tx, scene_vjp=True)
+        value = self.get_map()
+        tx_bar, walls_bar = self.get_scene_vjp()
+        return {"value": value, "grad_rx": self.get_grad_rx(), "tx_bar": tx_bar, "walls_bar": walls_bar}
+
     def launch_stats(self, params: L.Params, tx) -> np.ndarray:
         """Runs the instrumented kernel build; returns the executed-work counters (include/d2d.h)."""
         tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(2)

@@ -136,6 +136,25 @@ int d2d_set_grid(d2d_ctx* ctx, const float* X, const float* Y, int32_t m, int32_
  * Inputs and outputs stay resident in HBM. */
 int d2d_power_map_launch(d2d_ctx* ctx, const d2d_params* params, const float* tx);
 
+/* ---- value + gradient (replaces grad=True / value_and_grad=True of the sweep, differt2d/scene.py:1920-1923,
+ *      and the user-side jax.value_and_grad over scene parameters, examples/plot_power_optimize.py:78-93) ---- */
+
+/* Cotangent of the value map for the scene-parameter VJP: cot[m*n], or NULL for all ones (the gradient of
+ * sum(Z)). Reset by d2d_set_grid. */
+int d2d_set_cotangent(d2d_ctx* ctx, const float* cot);
+
+/* Fused value+grad sweep (hand-derived reverse mode, no autodiff): writes the value map exactly as
+ * d2d_power_map_launch does, the per-cell gradient d Z[i,j] / d rx[i,j] (resident, [m][n][2]) and, when
+ * want_scene_vjp != 0, the VJP of the map w.r.t. the transmitter position and every object end point,
+ * contracted with the cotangent. out_mode D2D_OUT_ADD accumulates all of them (reduce_all). Asynchronous. */
+int d2d_power_map_vg_launch(d2d_ctx* ctx, const d2d_params* params, const float* tx, int32_t want_scene_vjp);
+
+/* Synchronises and copies the per-cell gradient map to out[m*n*2] (last axis d/dx, d/dy). */
+int d2d_get_grad_rx(d2d_ctx* ctx, float* out);
+
+/* Synchronises and copies the scene-parameter VJP: tx_bar[2] and xys_bar[N][2][2] (may be NULL). */
+int d2d_get_scene_vjp(d2d_ctx* ctx, float* tx_bar, float* xys_bar);
+
 /* Same sweep through the instrumented build of the kernel (same results, not for timing): fills
  * stats[D2D_NUM_STATS] with executed-work counters summed over waves (one count = one 64-lane wave):
  *   [0] candidates evaluated (interaction points + on_objects)   [1] ... that reached the loss stage

@@ -63,9 +63,17 @@ class NumpyBackend:
     def sqrt(self, x):
         return np.sqrt(x)
 
+    def div(self, a, b):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return a / b
+
     def exp(self, x):
         with np.errstate(over="ignore"):
             return np.exp(x)
+
+    def logistic(self, z):
+        """lax.logistic: 1 / (1 + exp(-z))."""
+        return self.c(1.0) / (self.c(1.0) + self.exp(-z))
 
     def sin(self, x):
         return np.sin(x)
@@ -140,8 +148,30 @@ class TorchBackend:
     def sqrt(self, x):
         return self.torch.sqrt(x)
 
+    def div(self, a, b):
+        return a / b
+
     def exp(self, x):
         return self.torch.exp(x)
+
+    def logistic(self, z):
+        """lax.logistic: value 1 / (1 + exp(-z)); JVP rule logistic(z) * (1 - logistic(z)) (jax/_src/lax/lax.py),
+        which stays finite where differentiating the quotient would give 0 * inf."""
+        torch = self.torch
+
+        class _Logistic(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                y = 1.0 / (1.0 + torch.exp(-x))
+                ctx.save_for_backward(y)
+                return y
+
+            @staticmethod
+            def backward(ctx, g):
+                (y,) = ctx.saved_tensors
+                return g * (y * (1.0 - y))
+
+        return _Logistic.apply(z)
 
     def sin(self, x):
         return self.torch.sin(self._t(x))
@@ -203,7 +233,7 @@ DEFAULT_TOL = 1e-2  # geometry.py:915
 def sigmoid(x, alpha, xp=NUMPY):
     """logic.py:218-235: jax.nn.sigmoid(alpha * x) = 1 / (1 + exp(-(alpha x)))."""
     z = xp.c(alpha) * x
-    return xp.c(1.0) / (xp.c(1.0) + xp.exp(-z))
+    return xp.logistic(z)
 
 
 def hard_sigmoid(x, alpha, xp=NUMPY):
@@ -528,10 +558,11 @@ def image_path(tx, objs, rx, xp=NUMPY):
         un = dot(u, nrm)
         vn = dot(v, nrm)
         un_zero = un == xp.c(0.0)
-        # jnp.where(un == 0, 0, vn * u / un) -- evaluated left to right: (vn*u)/un
-        safe = xp.where(un_zero, xp.c(1.0), un)
-        incx = xp.where(un_zero, xp.c(0.0), (vn * X(u)) / safe)
-        incy = xp.where(un_zero, xp.c(0.0), (vn * Y(u)) / safe)
+        # jnp.where(un == 0, 0, vn * u / un) -- evaluated left to right, (vn*u)/un, and divided by `un`
+        # itself (not by a guarded copy): under autodiff the untaken 0/0 branch poisons the gradient with NaN,
+        # exactly as in the reference (the classic `where` trap).
+        incx = xp.where(un_zero, xp.c(0.0), xp.div((vn * X(u)), un))
+        incy = xp.where(un_zero, xp.c(0.0), xp.div((vn * Y(u)), un))
         point = point + vec(incx, incy, xp)
         points[k] = point
     pts = [tx, *points, rx]

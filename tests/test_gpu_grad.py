@@ -1,0 +1,128 @@
+"""
+GPU parity of the hand-derived value+grad kernel against reverse-mode autodiff of the oracle's op chain
+(oracle/ref.py under torch.autograd, JAX-compatible where/min/max/logistic semantics).
+
+Tolerance: BASELINE.json asks value+grad within 1e-5 fp32.  Values are bit-exact (hard, hard_sigmoid).
+Gradients come out of a differently ordered fp32 backward pass, so they are compared against the fp64
+autodiff result with atol = 3e-5 * max|grad| and rtol = 1e-4 (fp32 autodiff itself sits at ~3e-6 * max from
+fp64).  NaN positions must coincide (the reference's `where`/sqrt(0) autodiff traps, mirrored on purpose).
+"""
+
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import random_scene, unit_grid
+
+pytestmark = pytest.mark.gpu
+
+F = np.float32
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from differt2d_amd.engine import Context
+
+    with Context(0) as c:
+        yield c
+
+
+def _close(got, want, name):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, name
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    assert np.array_equal(nan_g, nan_w), f"{name}: NaN positions differ ({nan_g.sum()} vs {nan_w.sum()})"
+    if nan_w.all():
+        return
+    scale = np.nanmax(np.abs(want))
+    err = np.nanmax(np.abs(got - want) - 1e-4 * np.abs(want))
+    assert err <= 3e-5 * scale + 1e-6, f"{name}: max abs err {np.nanmax(np.abs(got - want)):.3e} at scale {scale:.3e}"
+
+
+def _kwargs(d):
+    kw = eval(str(d["kwargs"]))  # written by scripts/make_golden.py
+    return kw
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_against_golden_fixtures(ctx, path):
+    d = np.load(path)
+    kw = _kwargs(d)
+    ctx.set_scene(d["walls"])
+    got = ctx.value_and_grads(d["tx"], d["X"], d["Y"], **kw)
+    if kw.get("function") == "sigmoid":
+        np.testing.assert_allclose(got["value"], d["value"], rtol=2e-5, atol=1e-5)
+    else:
+        assert np.array_equal(got["value"], d["value"])
+    _close(got["grad_rx"], d["grad_rx"], "grad_rx")
+    _close(got["tx_bar"], d["tx_bar"], "tx_bar")
+    _close(got["walls_bar"], d["walls_bar"], "walls_bar")
+    # non-trivial cotangent
+    got = ctx.value_and_grads(d["tx"], d["X"], d["Y"], cotangent=d["cot"], **kw)
+    _close(got["tx_bar"], d["tx_bar_cot"], "tx_bar (cotangent)")
+    _close(got["walls_bar"], d["walls_bar_cot"], "walls_bar (cotangent)")
+
+
+@pytest.mark.parametrize("approx,function", [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")])
+@pytest.mark.parametrize("fun", ["received_power", "length_squared", "length"])
+def test_against_live_autodiff(ctx, approx, function, fun):
+    from oracle import ref as R
+
+    tx, walls = random_scene(10, seed=17)
+    X, Y = unit_grid(19, 13)
+    kw = dict(min_order=0, max_order=2, approx=approx, function=function, fun=fun)
+    want = R.power_map_value_and_grads(walls, tx, X, Y, dtype="float64", **kw)
+    ctx.set_scene(walls)
+    got = ctx.value_and_grads(tx, X, Y, **kw)
+    np.testing.assert_allclose(got["value"], want["value"], rtol=2e-5, atol=1e-5)
+    for k in ("grad_rx", "tx_bar", "walls_bar"):
+        _close(got[k], want[k], k)
+
+
+def test_value_map_of_vg_kernel_is_bit_identical_to_forward(ctx):
+    tx, walls = random_scene(20, seed=4)
+    X, Y = unit_grid(64, 40)
+    from differt2d_amd.engine import make_params
+
+    ctx.set_scene(walls)
+    ctx.set_grid(X, Y)
+    for approx in (False, True):
+        p = make_params(max_order=2, approx=approx)
+        ctx.launch(p, tx)
+        a = ctx.get_map()
+        ctx.launch_vg(p, tx, scene_vjp=True)
+        b = ctx.get_map()
+        assert np.array_equal(a, b)
+
+
+def test_los_gradients_analytic(ctx):
+    # reference tests/test_scene.py:597-627: fun = length**2, no objects: grad = [2(X - tx_x), 2(Y - tx_y)]
+    x = np.linspace(-3, 3, 10).astype(F)
+    X, Y = np.meshgrid(x, x)
+    ctx.set_scene(np.zeros((0, 2, 2), F))
+    got = ctx.value_and_grads([1.0, 0.0], X, Y, max_order=1, fun="length_squared")
+    want = np.stack([2 * (X - 1.0), 2 * Y], axis=-1)
+    np.testing.assert_allclose(got["grad_rx"], want, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got["tx_bar"], -want.reshape(-1, 2).sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_reduce_all_accumulates_gradients(ctx):
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import make_params
+
+    tx, walls = random_scene(6, seed=8)
+    tx2 = tx[::-1].copy()
+    X, Y = unit_grid(16)
+    ctx.set_scene(walls)
+    a = ctx.value_and_grads(tx, X, Y, max_order=2, approx=True)
+    b = ctx.value_and_grads(tx2, X, Y, max_order=2, approx=True)
+    ctx.set_grid(X, Y)
+    ctx.launch_vg(make_params(max_order=2, approx=True), tx, scene_vjp=True)
+    ctx.launch_vg(make_params(max_order=2, approx=True, out_mode=L.OUT_ADD), tx2, scene_vjp=True)
+    np.testing.assert_array_equal(ctx.get_map(), a["value"] + b["value"])
+    np.testing.assert_array_equal(ctx.get_grad_rx(), a["grad_rx"] + b["grad_rx"])
+    _, wb = ctx.get_scene_vjp()
+    np.testing.assert_allclose(wb, a["walls_bar"] + b["walls_bar"], rtol=1e-5, atol=1e-4)
