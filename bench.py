@@ -1,14 +1,25 @@
 #!/usr/bin/env python3
 """
-bench.py -- ray-path candidates/s of the fused power-map sweep (BASELINE.json metric).
+bench.py -- ray-path candidates/s of the fused power-map sweep (BASELINE.json metric) on N MI355X.
 
-A "step" = one forward power map of the workload: 50 random walls, 1 TX, 1024 x 1024 RX grid,
-orders 0..2 (C = 2501 candidates per RX cell, BASELINE.json configs[1]), inputs resident in HBM.
-Prints ONE JSON line (rank 0).  N > 1: launched by torch.distributed.run, RX rows sharded over
-ranks (weak scaling = every rank sweeps a full 1024^2 grid shard of a N-times taller grid).
+Step      = one forward power map of the workload, inputs resident in HBM:
+            50 random walls (NumPy seed 1234), 1 TX, 1024 x 1024 RX grid over the unit square, orders 0..2
+            (C = 2501 candidates per cell) = BASELINE.json configs[1]; hard (reference default) validity.
+N > 1     = launched by torch.distributed.run, one process per GPU.  Weak scaling: the grid becomes
+            (1024 N) x 1024 cells over the same unit square, rows dealt to ranks in 8-row blocks round-robin
+            (differt2d_amd/parallel.py), so every rank sweeps 1024 x 1024 cells; each step ends with ONE RCCL
+            all-gather of the value map on the kernel's stream.  Control plane (rendezvous, barrier, max over
+            ranks): torch.distributed/gloo on the host; no torch tensor touches the GPU.
+value     = all cells of all ranks x C / wall time of the K timed steps (max over ranks).
+roofline  = the kernel is FP32-VALU bound (~1e6 FLOP per HBM byte, no MFMA-shaped work).
+            `achieved` prices the work the kernel actually executed (counters of its instrumented build, see
+            include/d2d.h) with SURVEY.md's per-unit FLOP figures; `peak` is the 157.3 TFLOP/s FP32 vector peak.
+cpu_baseline = the oracle's C/OpenMP restatement on a bounded row sample of the same grid (rank 0, N = 1).
+Prints ONE JSON line on rank 0.
 """
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -19,22 +30,27 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+PEAK_FP32_VECTOR_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBPS = 8000.0
 
 
-def workload(n_walls=50, grid=1024, seed=1234):
-    """layout of Scene.random_uniform_scene with a NumPy PRNG."""
+def workload(n_walls=50, grid=1024, seed=1234, rows=None):
+    """layout of Scene.random_uniform_scene with a NumPy PRNG; grid = linspace(0, 1)."""
     pts = np.random.default_rng(seed).random((1 + 2 * n_walls + 1, 2), dtype=np.float32)
     tx = pts[0].copy()
     walls = pts[1 : 1 + 2 * n_walls].reshape(n_walls, 2, 2).copy()
     x = np.linspace(0.0, 1.0, grid).astype(np.float32)
-    X, Y = np.meshgrid(x, x)
+    y = np.linspace(0.0, 1.0, rows or grid).astype(np.float32)
+    X, Y = np.meshgrid(x, y)
     return tx, walls, X, Y
 
 
-def algorithmic_flop_per_rx(n_walls, min_order, max_order, approx):
-    """FLOP(k, N) = (k+1) N F_seg + 74 k + 23, unpruned."""
+def num_candidates(n_walls, min_order, max_order):
+    return sum(1 if k == 0 else n_walls * (n_walls - 1) ** (k - 1) for k in range(min_order, max_order + 1))
+
+
+def unpruned_flop_per_rx(n_walls, min_order, max_order, approx):
+    """FLOP(k, N) = (k+1) N F_seg + 74 k + 23 per candidate, nothing skipped."""
     f_seg = 41 if approx else 17
     total = 0
     for k in range(min_order, max_order + 1):
@@ -44,17 +60,13 @@ def algorithmic_flop_per_rx(n_walls, min_order, max_order, approx):
 
 
 def executed_flop(stats, approx):
-    """Prices the kernel's executed-work counters (include/d2d.h, d2d_power_map_stats; one count =
-    one 64-lane wave) with SURVEY.md section 8(d)'s per-unit figures: solver 16k + on_objects 20k per
-    evaluated candidate, loss 29k, F_seg per evaluated segment/wall test, length/power/validity 9k + 23."""
+    """Prices the executed-work counters (d2d_power_map_stats; one count = one 64-lane wave) with SURVEY.md
+    section 8(d)'s per-unit figures: solver 16k + on_objects 20k per evaluated candidate, loss 29k,
+    F_seg per evaluated segment/wall test, length/power/validity 9k + 23."""
     f_seg = 41 if approx else 17
     s = [int(v) for v in stats]
     per_wave = s[6] * 36 + s[7] * 29 + s[4] * f_seg + (s[8] - s[3]) * 9 + s[3] * 23
     return per_wave * 64
-
-
-def num_candidates(n_walls, min_order, max_order):
-    return sum(1 if k == 0 else n_walls * (n_walls - 1) ** (k - 1) for k in range(min_order, max_order + 1))
 
 
 def usable_cores():
@@ -87,93 +99,181 @@ def cpu_baseline(tx, walls, X, Y, max_order, approx, budget_rows=24):
         "cores": cores,
         "kind": "port",
         "sample": f"{budget_rows} of {X.shape[0]} grid rows x {X.shape[1]} columns ({Xs.size} RX cells, "
-                  f"{cands:.3g} candidates), C/OpenMP restatement of DiffeRT2d v0.4.0 (not JAX), {dt:.1f} s",
+                  f"{cands:.3g} candidates, every candidate fully evaluated), C/OpenMP restatement of DiffeRT2d v0.4.0 "
+                  f"(the JAX reference cannot be installed here), {dt:.1f} s",
     }
+
+
+def measured_traffic_bytes(approx):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc.json: FETCH_SIZE + WRITE_SIZE,
+    KiB; 4-byte-per-lane accesses, for which the guide's x2 wide-read correction does not apply)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_a{int(approx)}_pmc.json")))
+    if not files:
+        return None
+    try:
+        pmc = json.load(open(files[-1]))
+        return (pmc["FETCH_SIZE"]["mean_per_dispatch"] + pmc["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
+    except (KeyError, ValueError):
+        return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=1024)
     ap.add_argument("--walls", type=int, default=50)
     ap.add_argument("--max-order", type=int, default=2)
     ap.add_argument("--approx", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grad", action="store_true", help="skip the value+grad (BASELINE.json configs[2]) timing")
     args = ap.parse_args()
 
+    # libd2d (system ROCm) must be loaded and the GPU initialised before torch is imported: torch bundles its
+    # own copies of libamdhip64 / librccl under the same SONAMEs.
     from differt2d_amd.engine import Context, make_params
+    from differt2d_amd.parallel import RowShards
 
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if distributed else 1
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    tx, walls, X, Y = workload(args.walls, args.grid)
-    C = num_candidates(args.walls, 0, args.max_order)
-    params = make_params(min_order=0, max_order=args.max_order, approx=bool(args.approx))
+    if distributed and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not distributed and args.gpus != 1:
+        raise SystemExit("N > 1 must be launched with torch.distributed.run (one process per GPU)")
 
     ctx = Context(local_rank)
-    ctx.set_scene(walls)
-    ctx.set_grid(X, Y)
-    for _ in range(args.warmup):
-        ctx.launch(params, tx)
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    ctx.timer_begin()
-    for _ in range(args.steps):
-        ctx.launch(params, tx)
-    kernel_ms = ctx.timer_end() / args.steps
-    ctx.synchronize()
-    wall = time.perf_counter() - t0
-    ms_per_step = wall * 1e3 / args.steps
+    dist = None
+    if distributed:
+        import torch  # noqa: F401  (host-side control plane only)
+        import torch.distributed as dist
 
-    cells = X.size
-    stats = ctx.launch_stats(params, tx)  # instrumented build, outside the timed region (deterministic counts)
-    flop_unpruned = algorithmic_flop_per_rx(args.walls, 0, args.max_order, bool(args.approx)) * cells
-    flop = executed_flop(stats, bool(args.approx))
-    achieved_tflops = flop / (kernel_ms * 1e-3) / 1e12
-    line = {
-        "metric": "ray-path candidates/s",
-        "value": cells * C / (ms_per_step * 1e-3),
-        "unit": "candidates/s",
-        "n_gpus": args.gpus,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {
-            "workload": f"{args.walls} random walls (NumPy seed 1234), 1 TX, {args.grid}x{args.grid} RX grid, "
-                        f"orders 0..{args.max_order} (C={C} candidates/cell), "
-                        f"{'approx hard_sigmoid alpha=100' if args.approx else 'hard'} validity, received_power",
-        },
-        "roofline": {
-            "bound": "valu_fp32",
-            "achieved": achieved_tflops,
-            "peak": PEAK_FP32_VECTOR_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": achieved_tflops / PEAK_FP32_VECTOR_TFLOPS,
-            "traffic": None,
-            "kernel_ms": kernel_ms,
-            "algorithmic_flop_per_launch": flop,
-            "unpruned_flop_per_launch": flop_unpruned,
-            "unpruned_equiv_TFLOPs": flop_unpruned / (kernel_ms * 1e-3) / 1e12,
-            "executed": {
-                "candidates": int(stats[0]) * 64, "reached_loss": int(stats[1]) * 64,
-                "reached_occlusion": int(stats[2]) * 64, "reached_fun": int(stats[3]) * 64,
-                "segment_tests": int(stats[4]) * 64, "exact_divide_tests": int(stats[5]) * 64,
-            },
-            "hbm_algorithmic_bytes": cells * 12,
-            "hbm_algorithmic_GBps": cells * 12 / (kernel_ms * 1e-3) / 1e9,
-            "hbm_peak_GBps": PEAK_HBM_GBPS,
-        },
-    }
-    if not args.no_cpu_baseline and rank == 0 and args.gpus == 1:
-        line["cpu_baseline"] = cpu_baseline(tx, walls, X, Y, args.max_order, bool(args.approx))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        ids = [Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], rank, world)
+
+    tx, walls, X, Y = workload(args.walls, args.grid, rows=args.grid * world)
+    shards = RowShards(X.shape[0], world)
+    Xl, Yl = shards.take(X, rank), shards.take(Y, rank)
+    C = num_candidates(args.walls, 0, args.max_order)
+    params = make_params(min_order=0, max_order=args.max_order, approx=bool(args.approx))
+    ctx.set_scene(walls)
+    ctx.set_grid(Xl, Yl)
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        ctx.launch(params, tx)
+        if world > 1:
+            ctx.comm_allgather_map()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        ctx.timer_begin()
+        for _ in range(steps):
+            fn()
+        stream_ms = ctx.timer_end()  # HIP events on the stream the kernels are launched on
+        barrier()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+
+            t = torch.tensor([wall], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t[0])
+        return wall, stream_ms / steps
+
+    wall, kernel_ms = timed(step, args.steps, args.warmup)
+    ms_per_step = wall * 1e3 / args.steps
+    cells_total = X.size
+    cells_local = Xl.size
+
+    grad_info = None
+    if not args.no_grad:
+        def step_vg():
+            ctx.launch_vg(params, tx, scene_vjp=True)
+            if world > 1:
+                ctx.comm_allgather_map()
+                ctx.comm_allreduce_vjp()
+
+        gwall, gkernel_ms = timed(step_vg, max(3, args.steps // 2), 1)
+        gsteps = max(3, args.steps // 2)
+        grad_info = {
+            "what": "value + per-cell d/d rx + VJP w.r.t. TX position and wall end points (reverse-mode kernel), "
+                    "BASELINE.json configs[2]",
+            "ms_per_step": gwall * 1e3 / gsteps,
+            "stream_ms_per_step": gkernel_ms,
+            "candidates_per_s": cells_total * C / (gwall / gsteps),
+        }
+
     if rank == 0:
-        print(json.dumps(line))
+        stats = ctx.launch_stats(params, tx)  # instrumented build, outside the timed region (deterministic counts)
+        flop_exec = executed_flop(stats, bool(args.approx))
+        flop_unpruned = unpruned_flop_per_rx(args.walls, 0, args.max_order, bool(args.approx)) * cells_local
+        achieved = flop_exec / (kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "ray-path candidates/s",
+            "value": cells_total * C / (ms_per_step * 1e-3),
+            "unit": "candidates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.walls} random walls (NumPy seed 1234), 1 TX, {X.shape[0]}x{X.shape[1]} RX grid over the "
+                            f"unit square ({args.grid}x{args.grid} per GPU), orders 0..{args.max_order} (C={C} candidates per "
+                            f"cell), {'approx hard_sigmoid alpha=100' if args.approx else 'hard'} validity, received_power; "
+                            f"BASELINE.json configs[1]",
+                "sharding": f"{world} rank(s), 8-row blocks round-robin" + ("; 1 RCCL all-gather of the value map per step" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "valu_fp32",
+                "achieved": achieved,
+                "peak": PEAK_FP32_VECTOR_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                "traffic": measured_traffic_bytes(args.approx),
+                "kernel": "d2d::power_fwd_kernel",
+                "kernel_ms": kernel_ms,
+                "algorithmic_flop_per_launch": flop_exec,
+                "unpruned_flop_per_launch": flop_unpruned,
+                "unpruned_equiv_TFLOPs": flop_unpruned / (kernel_ms * 1e-3) / 1e12,
+                "executed_lane_units": {
+                    "candidates": int(stats[0]) * 64, "reached_loss": int(stats[1]) * 64,
+                    "reached_occlusion": int(stats[2]) * 64, "reached_fun": int(stats[3]) * 64,
+                    "segment_tests": int(stats[4]) * 64, "exact_divide_tests": int(stats[5]) * 64,
+                },
+                "hbm_algorithmic_bytes": cells_local * 12,
+                "hbm_algorithmic_GBps": cells_local * 12 / (kernel_ms * 1e-3) / 1e9,
+                "hbm_peak_GBps": PEAK_HBM_GBPS,
+            },
+        }
+        if grad_info:
+            line["value_and_grad"] = grad_info
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(tx, walls, X, Y, args.max_order, bool(args.approx))
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        ctx.comm_destroy()
+        dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -1,6 +1,8 @@
 // libd2d.so -- host side of the C ABI declared in include/d2d.h (HIP runtime, gfx950 only).
 // No CPU fallback lives here: every sweep is a kernel launch.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -102,6 +104,11 @@ struct d2d_ctx {
     DevBuf<double> d_vjp;
     bool have_cot = false;
     bool have_vjp = false;
+    // RCCL (one communicator per ctx, collectives run on the ctx stream)
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    DevBuf<float> d_gather;
+    size_t gathered = 0;  // floats per rank in d_gather
 };
 
 namespace {
@@ -199,6 +206,47 @@ int check_params(const d2d_params* p) {
 
 }  // namespace
 
+namespace {
+
+// librccl is resolved at first use (dlopen), so single-GPU users never need it.
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    if (r.h) return r;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.h) break;
+    }
+    if (!r.h) return r;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.GetErrorString;
+    return r;
+}
+
+#define RCCL_TRY(expr)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t r_ = (expr);                                                                          \
+        if (r_ != ncclSuccess) return fail(D2D_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString(r_)); \
+    } while (0)
+
+}  // namespace
+
 extern "C" {
 
 int d2d_abi_version(void) { return D2D_ABI_VERSION; }
@@ -257,6 +305,8 @@ void d2d_destroy(d2d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
+    c->d_gather.release();
     c->d_occl.release();
     c->d_refl.release();
     c->d_cw.release();
@@ -680,6 +730,84 @@ int d2d_power_map(d2d_ctx* c, const d2d_params* p, const float* tx, const float*
     if (rc) return rc;
     if ((rc = d2d_power_map_launch(c, p, tx))) return rc;
     return d2d_get_map(c, out);
+}
+
+/* ---- RCCL --------------------------------------------------------------------------------- */
+
+int d2d_comm_unique_id(uint8_t* id) {
+    if (!id) return fail(D2D_ERR_INVALID, "id is NULL");
+    if (!rccl().ok) return fail(D2D_ERR_COMM, "librccl could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+    ncclUniqueId u;
+    RCCL_TRY(rccl().GetUniqueId(&u));
+    static_assert(sizeof(u) == D2D_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, &u, sizeof u);
+    return D2D_OK;
+}
+
+int d2d_comm_init(d2d_ctx* c, const uint8_t* id, int32_t rank, int32_t world) {
+    if (!c || !id) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(D2D_ERR_INVALID, "bad rank %d of %d", rank, world);
+    if (!rccl().ok) return fail(D2D_ERR_COMM, "librccl could not be loaded");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (c->comm) {
+        rccl().CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    RCCL_TRY(rccl().CommInitRank(&c->comm, world, u, rank));
+    c->rank = rank;
+    c->world = world;
+    return D2D_OK;
+}
+
+int d2d_comm_destroy(d2d_ctx* c) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (c->comm) {
+        (void)set_device(c);
+        (void)hipStreamSynchronize(c->stream);
+        rccl().CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->world = 1;
+    c->rank = 0;
+    return D2D_OK;
+}
+
+int d2d_comm_allgather_map(d2d_ctx* c, int32_t what) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (!c->comm) return fail(D2D_ERR_STATE, "d2d_comm_init must come first");
+    if (!c->have_grid) return fail(D2D_ERR_STATE, "no grid set");
+    if (what != 0 && what != 1) return fail(D2D_ERR_INVALID, "what must be 0 (value map) or 1 (grad_rx map)");
+    if (what == 1 && !c->d_grad.p) return fail(D2D_ERR_STATE, "no value+grad sweep has run");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t per_rank = (size_t)c->m * c->n * (what ? 2 : 1);
+    if ((rc = c->d_gather.ensure(per_rank * (size_t)c->world))) return rc;
+    RCCL_TRY(rccl().AllGather(what ? c->d_grad.p : c->d_out.p, c->d_gather.p, per_rank, ncclFloat32, c->comm, c->stream));
+    c->gathered = per_rank;
+    return D2D_OK;
+}
+
+int d2d_comm_get_gathered(d2d_ctx* c, float* out) {
+    if (!c || !out) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (!c->gathered) return fail(D2D_ERR_STATE, "nothing has been gathered");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->d_gather.p, c->gathered * (size_t)c->world * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D2D_OK;
+}
+
+int d2d_comm_allreduce_vjp(d2d_ctx* c) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (!c->comm) return fail(D2D_ERR_STATE, "d2d_comm_init must come first");
+    if (!c->have_vjp) return fail(D2D_ERR_STATE, "no scene-VJP sweep has run");
+    int rc = set_device(c);
+    if (rc) return rc;
+    RCCL_TRY(rccl().AllReduce(c->d_vjp.p, c->d_vjp.p, (size_t)(4 * c->N + 2), ncclFloat64, ncclSum, c->comm, c->stream));
+    return D2D_OK;
 }
 
 int d2d_timer_begin(d2d_ctx* c) {

@@ -254,6 +254,35 @@ class Context:
         out["order"] = order[:Cn]
         return out
 
+    # -- RCCL ---------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(L.D2D_COMM_ID_BYTES)
+        L.check(L.load().d2d_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != L.D2D_COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        buf = C.create_string_buffer(unique_id, L.D2D_COMM_ID_BYTES)
+        L.check(self._lib.d2d_comm_init(self._ctx, C.cast(buf, C.c_void_p), int(rank), int(world)))
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_destroy(self):
+        L.check(self._lib.d2d_comm_destroy(self._ctx))
+
+    def comm_allgather_map(self, grad: bool = False):
+        L.check(self._lib.d2d_comm_allgather_map(self._ctx, 1 if grad else 0))
+
+    def comm_get_gathered(self, world: int, grad: bool = False) -> np.ndarray:
+        shape = (world, *self.shape, 2) if grad else (world, *self.shape)
+        out = np.empty(shape, np.float32)
+        L.check(self._lib.d2d_comm_get_gathered(self._ctx, out.reshape(-1)))
+        return out
+
+    def comm_allreduce_vjp(self):
+        L.check(self._lib.d2d_comm_allreduce_vjp(self._ctx))
+
     # -- timing -----------------------------------------------------------------------
     def timer_begin(self):
         L.check(self._lib.d2d_timer_begin(self._ctx))

@@ -1,0 +1,132 @@
+"""
+Multi-GPU sweep: one process per GPU, RX rows sharded over ranks, maps assembled with ONE all-gather.
+
+The reference has no multi-device code (its only batching is ``jax.vmap`` over the grid,
+scene.py:1927-1932).  Every RX cell is independent, so the partition needs no data-path exchange other
+than assembling the final map:
+
+* rows are dealt to ranks in blocks of ``BLOCK_ROWS`` (= the kernel's 8-row wave tile) round-robin,
+  ``block b -> rank b % world``: neighbouring blocks have similar pruning rates, so interleaving
+  balances the load, and a block keeps the 8x8 tile coherence the kernel's wave-level skips rely on;
+* every rank pads its shard to the same number of rows (last row repeated) so that a plain
+  ``ncclAllGather`` applies; padded rows are dropped on assembly;
+* the scene (a few kB) and all parameters are replicated; candidates are enumerated on device.
+
+Data plane: RCCL directly on the library's device buffers (``d2d_comm_*``, xGMI on an MI355X node).
+Control plane (rendezvous, barrier, id broadcast): ``torch.distributed`` with the ``gloo`` backend.
+The ``GlooHostComm`` backend moves host arrays through gloo instead and exists for the CPU tests.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+BLOCK_ROWS = 8
+
+
+class RowShards:
+    """Index logic of the row-block round-robin partition (pure NumPy, no device)."""
+
+    def __init__(self, m: int, world: int, block: int = BLOCK_ROWS):
+        if m <= 0 or world <= 0 or block <= 0:
+            raise ValueError("m, world and block must be positive")
+        self.m, self.world, self.block = int(m), int(world), int(block)
+        self.n_blocks = -(-self.m // self.block)
+        self._rows = [self._rows_of(r) for r in range(self.world)]
+        self.pad_rows = max(1, max(len(r) for r in self._rows))
+
+    def _rows_of(self, rank: int) -> np.ndarray:
+        rows = [np.arange(b * self.block, min((b + 1) * self.block, self.m)) for b in range(rank, self.n_blocks, self.world)]
+        return np.concatenate(rows) if rows else np.zeros(0, np.int64)
+
+    def rows(self, rank: int) -> np.ndarray:
+        """Global row indices owned by ``rank`` (ascending)."""
+        return self._rows[rank]
+
+    def take(self, A: np.ndarray, rank: int) -> np.ndarray:
+        """Rows of ``A`` owned by ``rank``, padded to ``pad_rows`` rows by repeating the last owned row
+        (rank without rows: row 0), so that every rank sweeps a grid of the same shape."""
+        rows = self._rows[rank]
+        idx = np.empty(self.pad_rows, np.int64)
+        idx[: len(rows)] = rows
+        idx[len(rows):] = rows[-1] if len(rows) else 0
+        return np.ascontiguousarray(A[idx])
+
+    def assemble(self, gathered: np.ndarray) -> np.ndarray:
+        """``gathered[world, pad_rows, ...]`` -> ``[m, ...]`` (drops padding, undoes the interleave)."""
+        if gathered.shape[0] != self.world or gathered.shape[1] != self.pad_rows:
+            raise ValueError(f"expected leading shape ({self.world}, {self.pad_rows}), got {gathered.shape[:2]}")
+        out = np.empty((self.m, *gathered.shape[2:]), gathered.dtype)
+        for r in range(self.world):
+            rows = self._rows[r]
+            out[rows] = gathered[r, : len(rows)]
+        return out
+
+
+class GlooHostComm:
+    """Host-array all-gather / all-reduce over an initialised ``torch.distributed`` group (CPU tests)."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allgather(self, local: np.ndarray) -> np.ndarray:
+        t = self.torch.from_numpy(np.ascontiguousarray(local))
+        outs = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return np.stack([o.numpy() for o in outs])
+
+    def allreduce_sum(self, local: np.ndarray) -> np.ndarray:
+        t = self.torch.from_numpy(np.array(local, dtype=np.float64))
+        self.dist.all_reduce(t)
+        return t.numpy()
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def sharded_map(X: np.ndarray, Y: np.ndarray, compute_shard: Callable[[np.ndarray, np.ndarray], np.ndarray], comm,
+                block: int = BLOCK_ROWS) -> np.ndarray:
+    """Generic driver: every rank computes its row shard with ``compute_shard(X_local, Y_local)`` and
+    the full map is assembled on every rank with one all-gather."""
+    shards = RowShards(X.shape[0], comm.world, block)
+    local = compute_shard(shards.take(X, comm.rank), shards.take(Y, comm.rank))
+    return shards.assemble(comm.allgather(local))
+
+
+class ShardedSweep:
+    """Resident multi-GPU power-map sweep on top of one :class:`~differt2d_amd.engine.Context` per rank.
+
+    ``setup`` uploads this rank's row shard once; ``step`` = fused kernel + RCCL all-gather, both
+    asynchronous on the context's stream; ``result`` downloads and assembles the full map."""
+
+    def __init__(self, ctx, rank: int, world: int, unique_id: Optional[bytes] = None):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        if unique_id is not None:
+            ctx.comm_init(unique_id, rank, world)
+        self.shards = None
+
+    def setup(self, walls, X, Y, kind=None, phi=None):
+        self.shards = RowShards(X.shape[0], self.world)
+        self.ctx.set_scene(walls, kind, phi)
+        self.ctx.set_grid(self.shards.take(X, self.rank), self.shards.take(Y, self.rank))
+
+    def step(self, params, tx, grad: bool = False, gather: bool = True):
+        if grad:
+            self.ctx.launch_vg(params, tx, scene_vjp=False)
+        else:
+            self.ctx.launch(params, tx)
+        if gather and self.world > 1:
+            self.ctx.comm_allgather_map(grad=False)
+            if grad:
+                raise NotImplementedError("gather of the gradient map: call comm_allgather_map(grad=True) after fetching the value map")
+
+    def result(self) -> np.ndarray:
+        if self.world == 1:
+            return self.shards.assemble(self.ctx.get_map()[None])
+        return self.shards.assemble(self.ctx.comm_get_gathered(self.world))

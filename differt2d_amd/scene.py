@@ -397,13 +397,15 @@ class Scene(Plottable):
         sum if ``reduce_all``. One fused kernel launch per transmitter when ``fun`` is native."""
         X = np.ascontiguousarray(X, dtype=F)
         Y = np.ascontiguousarray(Y, dtype=F)
-        if grad or value_and_grad:
-            raise L.D2DUnsupported(-4, "grad / value_and_grad need the gradient kernels (not in this build)")
         native, common = self._sweep_params(fun, fun_args, fun_kwargs, path_cls, path_cls_kwargs, min_order, max_order,
                                             order, kwargs)
         txs = list(self.transmitters.items())
+        want_grad = bool(grad or value_and_grad)
 
         if native is None:
+            if want_grad:
+                raise L.D2DUnsupported(-4, "grad / value_and_grad need a natively fused fun (differt2d_amd.utils): an "
+                                           "arbitrary Python callable cannot be differentiated by the hand-derived kernels")
             gen = ((name, self._emit_grid(X, Y, tx, True, receiver_cls, fun, fun_args, fun_kwargs, common, filter_objects,
                                           path_cls)) for name, tx in txs)
             if reduce_all:
@@ -415,26 +417,62 @@ class Scene(Plottable):
 
         name, extra = native
         ctx = self._ctx()
-        self._upload(ctx, filter_objects)
-        ctx.set_grid(X, Y)
+
+        def fetch():
+            if value_and_grad:  # takes precedence over grad (reference scene.py:1920-1923)
+                return ctx.get_map(), ctx.get_grad_rx()
+            if grad:
+                return ctx.get_grad_rx()
+            return ctx.get_map()
+
+        def launch(tx, out_mode):
+            params = make_params(fun=name, out_mode=out_mode, **extra, **common)
+            if want_grad:
+                ctx.launch_vg(params, tx.xy, scene_vjp=False)
+            else:
+                ctx.launch(params, tx.xy)
+
         if reduce_all:
             if not txs:
-                return F(0.0)
+                return (F(0.0), F(0.0)) if value_and_grad else F(0.0)
+            self._upload(ctx, filter_objects)
+            ctx.set_grid(X, Y)
             for i, (_, tx) in enumerate(txs):
-                ctx.launch(make_params(fun=name, out_mode=L.OUT_ADD if i else L.OUT_OVERWRITE, **extra, **common), tx.xy)
-            Z = ctx.get_map()
-            ctx.set_candidate_mask(None)
-            return Z
+                launch(tx, L.OUT_ADD if i else L.OUT_OVERWRITE)
+            return fetch()
 
         def results():
             for tx_name, tx in txs:
                 self._upload(ctx, filter_objects)
-                if ctx.shape != X.shape:
-                    ctx.set_grid(X, Y)
-                ctx.launch(make_params(fun=name, **extra, **common), tx.xy)
-                yield tx_name, ctx.get_map()
+                ctx.set_grid(X, Y)
+                launch(tx, L.OUT_OVERWRITE)
+                yield tx_name, fetch()
 
         return results()
+
+    def receivers_grid_value_and_vjp(
+        self, X, Y, fun: PathFun, fun_kwargs: Optional[Mapping] = None, *, cotangent=None, path_cls: type = ImagePath,
+        min_order: int = 0, max_order: int = 1, order: Optional[int] = None,
+        filter_objects: Optional[Callable[[Object], bool]] = None, **kwargs,
+    ):
+        """Reverse-mode sweep w.r.t. the SCENE parameters (what users of the reference obtain by wrapping the sweep
+        in ``jax.value_and_grad``, e.g. examples/plot_power_optimize.py:78-93): for every transmitter returns
+        ``(name, dict(value=Z, grad_rx=dZ/drx, tx_bar=<cot, dZ/dtx>, objects_bar=<cot, dZ/dxys>[N,2,2]))`` where
+        ``cotangent`` (default ones, i.e. the gradient of ``Z.sum()``) has the grid's shape."""
+        X = np.ascontiguousarray(X, dtype=F)
+        Y = np.ascontiguousarray(Y, dtype=F)
+        native, common = self._sweep_params(fun, (), fun_kwargs, path_cls, None, min_order, max_order, order, kwargs)
+        if native is None:
+            raise L.D2DUnsupported(-4, "the scene VJP needs a natively fused fun (differt2d_amd.utils)")
+        name, extra = native
+        ctx = self._ctx()
+        for tx_name, tx in self.transmitters.items():
+            self._upload(ctx, filter_objects)
+            ctx.set_grid(X, Y)
+            ctx.set_cotangent(cotangent)
+            ctx.launch_vg(make_params(fun=name, **extra, **common), tx.xy, scene_vjp=True)
+            tx_bar, objects_bar = ctx.get_scene_vjp()
+            yield tx_name, {"value": ctx.get_map(), "grad_rx": ctx.get_grad_rx(), "tx_bar": tx_bar, "objects_bar": objects_bar}
 
     def accumulate_on_transmitters_grid_over_paths(
         self, X, Y, fun: PathFun, fun_args: tuple = (), fun_kwargs: Optional[Mapping] = None, *, reduce_all: bool = False,

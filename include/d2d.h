@@ -186,6 +186,25 @@ int d2d_trace_paths(d2d_ctx* ctx, const d2d_params* params, const float* tx, con
                     const int32_t* cand, const int32_t* order, int32_t C, const float* xys_in, const float* loss_in,
                     float* xys, float* loss, float* valid, float* on, float* hit, float* length);
 
+/* ---- multi-GPU (one process per GPU; the reference has no multi-device code: its only batching is jax.vmap
+ *      over the grid, differt2d/scene.py:1927-1932; RX rows are sharded over ranks and maps are assembled with one
+ *      RCCL all-gather on the ctx stream; the scene VJP with one all-reduce) ------------------------------------- */
+
+#define D2D_COMM_ID_BYTES 128
+/* Rank 0 creates the id (ncclGetUniqueId) and ships it to the other ranks out of band. */
+int d2d_comm_unique_id(uint8_t* id /* [D2D_COMM_ID_BYTES] */);
+/* Collective: ncclCommInitRank on the ctx's device. */
+int d2d_comm_init(d2d_ctx* ctx, const uint8_t* id, int32_t rank, int32_t world);
+int d2d_comm_destroy(d2d_ctx* ctx);
+/* Collective, asynchronous on the ctx stream: all-gathers this rank's resident map (what = 0: value map,
+ * m*n floats; what = 1: grad_rx map, m*n*2 floats; every rank must hold the same m, n) into a resident
+ * buffer [world][...]. */
+int d2d_comm_allgather_map(d2d_ctx* ctx, int32_t what);
+/* Synchronises and copies the gathered buffer to out[world * per_rank]. */
+int d2d_comm_get_gathered(d2d_ctx* ctx, float* out);
+/* Collective, asynchronous: sums the resident scene VJP (fp64, 4N+2 values) over ranks in place. */
+int d2d_comm_allreduce_vjp(d2d_ctx* ctx);
+
 /* ---- timing on the ctx stream (HIP events) -------------------------------------------------- */
 
 int d2d_timer_begin(d2d_ctx* ctx);

@@ -153,7 +153,20 @@ def test_accumulate_on_receivers_grid_los(native):
     np.testing.assert_allclose(Z0, X**2 + Y**2, rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(Z1, (X - 1.0) ** 2 + Y**2, rtol=1e-6, atol=1e-6)
     Z = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=fun, reduce_all=True, max_order=1, approx=False)
-    np.testing.assert_allclose(Z, X**2 + Y**2 + (X - 1.0) ** 2 + Y**2, rtol=1e-6, atol=1e-5)
+    expected_Z = X**2 + Y**2 + (X - 1.0) ** 2 + Y**2
+    np.testing.assert_allclose(Z, expected_Z, rtol=1e-6, atol=1e-5)
+    if not native:
+        return
+    # gradients, tests/test_scene.py:597-627
+    expected_dZ = np.stack([2 * X, 2 * Y], axis=-1) + np.stack([2 * (X - 1.0), 2 * Y], axis=-1)
+    dZ = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=fun, reduce_all=True, grad=True, max_order=1, approx=False)
+    np.testing.assert_allclose(dZ, expected_dZ, rtol=1e-5, atol=1e-5)
+    Z2, dZ2 = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=fun, reduce_all=True, value_and_grad=True,
+                                                            max_order=1, approx=False)
+    np.testing.assert_allclose(Z2, expected_Z, rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(dZ2, expected_dZ, rtol=1e-5, atol=1e-5)
+    per_tx = dict(scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=fun, grad=True, max_order=1, approx=False))
+    np.testing.assert_allclose(per_tx["tx1"], np.stack([2 * (X - 1.0), 2 * Y], axis=-1), rtol=1e-5, atol=1e-5)
 
 
 def test_accumulate_on_transmitters_grid_los():
@@ -225,3 +238,21 @@ def test_unsupported_is_loud():
         scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, key=1)
     with pytest.raises(L.D2DUnsupported):
         scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, function=lambda x, a: x, approx=True)
+
+
+def test_scene_vjp_entry_point_matches_autodiff():
+    # what examples/plot_power_optimize.py obtains with jax.value_and_grad over tx_coords
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import received_power
+    from oracle import ref as R
+
+    scene = Scene.basic_scene()
+    X, Y = scene.grid(m=18, n=14)
+    X, Y = X * F(0.97) + F(0.013), Y * F(0.97) + F(0.017)  # keep cells off the walls (the reference's NaN traps)
+    (name, out), = list(scene.receivers_grid_value_and_vjp(X, Y, fun=received_power, max_order=2, approx=True, alpha=50.0))
+    want = R.power_map_value_and_grads(_scene_walls(scene), scene.transmitters["tx"].xy, X, Y, dtype="float64",
+                                       min_order=0, max_order=2, approx=True, alpha=50.0)
+    assert name == "tx"
+    for k, w in (("grad_rx", "grad_rx"), ("tx_bar", "tx_bar"), ("objects_bar", "walls_bar")):
+        scale = np.abs(want[w]).max()
+        assert np.abs(out[k] - want[w]).max() <= 3e-5 * scale, k

@@ -1,0 +1,39 @@
+"""RCCL plumbing on one GPU (world_size 1): librccl is dlopen'ed, a communicator is created, the all-gather
+and all-reduce run on the context's stream and leave the data unchanged.  (Ranks > 1 need one GPU each; the
+partition logic for N > 1 is covered on CPU over gloo in test_parallel_cpu.py.)"""
+
+import numpy as np
+import pytest
+
+from conftest import random_scene, unit_grid
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_world_size_one_roundtrip():
+    from differt2d_amd.engine import Context, make_params
+    from differt2d_amd.parallel import ShardedSweep
+
+    tx, walls = random_scene(9, seed=5)
+    X, Y = unit_grid(40, 27)
+    with Context(0) as ctx:
+        uid = Context.comm_unique_id()
+        assert len(uid) == 128
+        sweep = ShardedSweep(ctx, 0, 1, unique_id=uid)
+        sweep.setup(walls, X, Y)
+        p = make_params(max_order=2, approx=True)
+        sweep.step(p, tx)
+        direct = ctx.get_map()
+        ctx.comm_allgather_map()
+        gathered = ctx.comm_get_gathered(1)
+        assert gathered.shape == (1, *X.shape) and np.array_equal(gathered[0], direct)
+        assert np.array_equal(sweep.result(), direct)
+        ctx.launch_vg(p, tx, scene_vjp=True)
+        before = ctx.get_scene_vjp()
+        ctx.comm_allreduce_vjp()
+        after = ctx.get_scene_vjp()
+        assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+        ctx.comm_allgather_map(grad=True)
+        g = ctx.comm_get_gathered(1, grad=True)
+        assert np.array_equal(g[0], ctx.get_grad_rx())
+        ctx.comm_destroy()
