@@ -9,7 +9,7 @@ N > 1     = launched by torch.distributed.run, one process per GPU.  Weak scalin
             (1024 N) x 1024 cells over the same unit square, rows dealt to ranks in 8-row blocks round-robin
             (differt2d_amd/parallel.py), so every rank sweeps 1024 x 1024 cells; each step ends with ONE RCCL
             all-gather of the value map on the kernel's stream.  Control plane (rendezvous, barrier, max over
-            ranks): torch.distributed/gloo on the host; no torch tensor touches the GPU.
+            ranks): RCCL too (d2d_comm_allreduce_host); rendezvous through a file in /tmp; torch is never imported.
 value     = all cells of all ranks x C / wall time of the K timed steps (max over ranks).
 roofline  = the kernel is FP32-VALU bound (~1e6 FLOP per HBM byte, no MFMA-shaped work).
             `achieved` prices the work the kernel actually executed (counters of its instrumented build, see
@@ -130,8 +130,6 @@ def main():
     ap.add_argument("--no-grad", action="store_true", help="skip the value+grad (BASELINE.json configs[2]) timing")
     args = ap.parse_args()
 
-    # libd2d (system ROCm) must be loaded and the GPU initialised before torch is imported: torch bundles its
-    # own copies of libamdhip64 / librccl under the same SONAMEs.
     from differt2d_amd.engine import Context, make_params
     from differt2d_amd.parallel import RowShards
 
@@ -145,16 +143,13 @@ def main():
         raise SystemExit("N > 1 must be launched with torch.distributed.run (one process per GPU)")
 
     ctx = Context(local_rank)
-    dist = None
     if distributed:
-        import torch  # noqa: F401  (host-side control plane only)
-        import torch.distributed as dist
+        # torch.distributed.run is only the launcher: rendezvous through /tmp, everything else through RCCL
+        from differt2d_amd.parallel import file_rendezvous, file_rendezvous_cleanup
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
-        ids = [Context.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(ids[0], rank, world)
+        ctx.comm_init(file_rendezvous(rank, world, Context.comm_unique_id), rank, world)
+        ctx.comm_barrier()
+        file_rendezvous_cleanup(rank)
 
     tx, walls, X, Y = workload(args.walls, args.grid, rows=args.grid * world)
     shards = RowShards(X.shape[0], world)
@@ -166,8 +161,8 @@ def main():
 
     def barrier():
         ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if distributed:
+            ctx.comm_barrier()
 
     def step():
         ctx.launch(params, tx)
@@ -185,12 +180,8 @@ def main():
         stream_ms = ctx.timer_end()  # HIP events on the stream the kernels are launched on
         barrier()
         wall = time.perf_counter() - t0
-        if dist is not None:
-            import torch
-
-            t = torch.tensor([wall], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall = float(t[0])
+        if distributed:
+            wall = float(ctx.comm_allreduce_host([wall], "max")[0])
         return wall, stream_ms / steps
 
     wall, kernel_ms = timed(step, args.steps, args.warmup)
@@ -269,10 +260,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(tx, walls, X, Y, args.max_order, bool(args.approx))
         print(json.dumps(line), flush=True)
 
-    if dist is not None:
-        dist.barrier()
+    if distributed:
+        ctx.comm_barrier()
         ctx.comm_destroy()
-        dist.destroy_process_group()
     ctx.close()
 
 

@@ -107,6 +107,7 @@ SYMBOLS = [
     ("d2d_comm_allgather_map", C.c_int, [_ctx, C.c_int32]),
     ("d2d_comm_get_gathered", C.c_int, [_ctx, _f32p]),
     ("d2d_comm_allreduce_vjp", C.c_int, [_ctx]),
+    ("d2d_comm_allreduce_host", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_int32, C.c_int32]),
     ("d2d_timer_begin", C.c_int, [_ctx]),
     ("d2d_timer_end", C.c_int, [_ctx, C.POINTER(C.c_float)]),
 ]

@@ -108,6 +108,7 @@ struct d2d_ctx {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     DevBuf<float> d_gather;
+    DevBuf<double> d_hostred;
     size_t gathered = 0;  // floats per rank in d_gather
 };
 
@@ -216,6 +217,7 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok = false;
 };
@@ -235,6 +237,7 @@ Rccl& rccl() {
     r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    r.GetVersion = (decltype(r.GetVersion))dlsym(r.h, "ncclGetVersion");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.GetErrorString;
     return r;
 }
@@ -307,6 +310,7 @@ void d2d_destroy(d2d_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
     c->d_gather.release();
+    c->d_hostred.release();
     c->d_occl.release();
     c->d_refl.release();
     c->d_cw.release();
@@ -807,6 +811,21 @@ int d2d_comm_allreduce_vjp(d2d_ctx* c) {
     int rc = set_device(c);
     if (rc) return rc;
     RCCL_TRY(rccl().AllReduce(c->d_vjp.p, c->d_vjp.p, (size_t)(4 * c->N + 2), ncclFloat64, ncclSum, c->comm, c->stream));
+    return D2D_OK;
+}
+
+int d2d_comm_allreduce_host(d2d_ctx* c, double* values, int32_t n, int32_t op) {
+    if (!c || !values) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (!c->comm) return fail(D2D_ERR_STATE, "d2d_comm_init must come first");
+    if (n <= 0 || n > 4096) return fail(D2D_ERR_INVALID, "n must lie in 1..4096");
+    if (op != 0 && op != 1) return fail(D2D_ERR_INVALID, "op must be 0 (sum) or 1 (max)");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = c->d_hostred.ensure((size_t)n))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_hostred.p, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RCCL_TRY(rccl().AllReduce(c->d_hostred.p, c->d_hostred.p, (size_t)n, ncclFloat64, op ? ncclMax : ncclSum, c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(values, c->d_hostred.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return D2D_OK;
 }
 

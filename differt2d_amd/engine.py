@@ -283,6 +283,16 @@ class Context:
     def comm_allreduce_vjp(self):
         L.check(self._lib.d2d_comm_allreduce_vjp(self._ctx))
 
+    def comm_allreduce_host(self, values, op: str = "sum") -> np.ndarray:
+        """All-reduces a few host doubles over ranks through RCCL (synchronous)."""
+        v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+        L.check(self._lib.d2d_comm_allreduce_host(self._ctx, v, v.size, {"sum": 0, "max": 1}[op]))
+        return v
+
+    def comm_barrier(self):
+        """Stream-synchronising barrier over all ranks of the communicator."""
+        self.comm_allreduce_host([1.0], "sum")
+
     # -- timing -----------------------------------------------------------------------
     def timer_begin(self):
         L.check(self._lib.d2d_timer_begin(self._ctx))

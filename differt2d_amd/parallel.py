@@ -12,9 +12,11 @@ than assembling the final map:
   ``ncclAllGather`` applies; padded rows are dropped on assembly;
 * the scene (a few kB) and all parameters are replicated; candidates are enumerated on device.
 
-Data plane: RCCL directly on the library's device buffers (``d2d_comm_*``, xGMI on an MI355X node).
-Control plane (rendezvous, barrier, id broadcast): ``torch.distributed`` with the ``gloo`` backend.
-The ``GlooHostComm`` backend moves host arrays through gloo instead and exists for the CPU tests.
+Data plane AND barrier / max-over-ranks: RCCL directly on the library's device buffers (``d2d_comm_*``, xGMI on
+an MI355X node).  Rendezvous (shipping the 128-byte unique id): a file in /tmp (:func:`file_rendezvous`), so the
+GPU processes import no torch -- torch bundles its own libamdhip64 / librccl under the system ROCm's SONAMEs and
+must stay out of a process that drives the system RCCL.  The ``GlooHostComm`` backend moves host arrays through
+``torch.distributed``/gloo instead and exists for the CPU tests of the partition logic.
 """
 
 from __future__ import annotations
@@ -63,6 +65,53 @@ class RowShards:
             rows = self._rows[r]
             out[rows] = gathered[r, : len(rows)]
         return out
+
+
+def file_rendezvous(rank: int, world: int, make_id: Callable[[], bytes], timeout: float = 300.0) -> bytes:
+    """Ships rank 0's 128-byte RCCL unique id to the other ranks of ONE node through a directory in /tmp, so that
+    the GPU processes need no torch / MPI at run time (torch.distributed.run is only the launcher).
+
+    The directory is ``$D2D_RDZV_DIR`` or ``/tmp/d2d_rdzv_<MASTER_PORT>_<parent pid>`` (all workers of one
+    torchrun agent share the parent pid).  Rank 0 writes ``id.bin`` atomically; it removes the directory in
+    :func:`file_rendezvous_cleanup` once every rank has initialised its communicator."""
+    import os
+    import time
+
+    d = rendezvous_dir()
+    path = os.path.join(d, "id.bin")
+    if rank == 0:
+        os.makedirs(d, exist_ok=True)
+        uid = make_id()
+        tmp = path + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except OSError:
+            pass
+        if time.time() - t0 > timeout:
+            raise TimeoutError(f"rank {rank}: no unique id at {path} after {timeout} s")
+        time.sleep(0.02)
+
+
+def rendezvous_dir() -> str:
+    import os
+
+    return os.environ.get("D2D_RDZV_DIR") or f"/tmp/d2d_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+
+
+def file_rendezvous_cleanup(rank: int):
+    import shutil
+
+    if rank == 0:
+        shutil.rmtree(rendezvous_dir(), ignore_errors=True)
 
 
 class GlooHostComm:

@@ -205,6 +205,10 @@ int d2d_comm_get_gathered(d2d_ctx* ctx, float* out);
 /* Collective, asynchronous: sums the resident scene VJP (fp64, 4N+2 values) over ranks in place. */
 int d2d_comm_allreduce_vjp(d2d_ctx* ctx);
 
+/* Collective, synchronous: all-reduces n host doubles over ranks through the GPUs (op 0 = sum, 1 = max).
+ * A sum of one value is the barrier; a max is how bench.py takes the slowest rank's time. */
+int d2d_comm_allreduce_host(d2d_ctx* ctx, double* values, int32_t n, int32_t op);
+
 /* ---- timing on the ctx stream (HIP events) -------------------------------------------------- */
 
 int d2d_timer_begin(d2d_ctx* ctx);

@@ -246,7 +246,9 @@ def test_scene_vjp_entry_point_matches_autodiff():
     from differt2d_amd.utils import received_power
     from oracle import ref as R
 
-    scene = Scene.basic_scene()
+    # (basic_scene has two collinear walls: reflecting in both gives coincident interaction points and the
+    #  reference's autodiff then returns NaN for every cell at order 2 -- not a useful comparison)
+    scene = Scene.square_scene_with_wall()
     X, Y = scene.grid(m=18, n=14)
     X, Y = X * F(0.97) + F(0.013), Y * F(0.97) + F(0.017)  # keep cells off the walls (the reference's NaN traps)
     (name, out), = list(scene.receivers_grid_value_and_vjp(X, Y, fun=received_power, max_order=2, approx=True, alpha=50.0))
@@ -254,5 +256,6 @@ def test_scene_vjp_entry_point_matches_autodiff():
                                        min_order=0, max_order=2, approx=True, alpha=50.0)
     assert name == "tx"
     for k, w in (("grad_rx", "grad_rx"), ("tx_bar", "tx_bar"), ("objects_bar", "walls_bar")):
+        assert not np.isnan(want[w]).any() and not np.isnan(out[k]).any(), k
         scale = np.abs(want[w]).max()
         assert np.abs(out[k] - want[w]).max() <= 3e-5 * scale, k

@@ -2,15 +2,29 @@
 and all-reduce run on the context's stream and leave the data unchanged.  (Ranks > 1 need one GPU each; the
 partition logic for N > 1 is covered on CPU over gloo in test_parallel_cpu.py.)"""
 
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
 from conftest import random_scene, unit_grid
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_rccl_world_size_one_roundtrip():
+def test_rccl_world_size_one_roundtrip_in_fresh_process():
+    """torch (imported by other tests for the autodiff oracle) bundles its own libamdhip64 / librccl under the
+    same SONAMEs as the system ROCm; the RCCL data plane therefore runs in torch-free processes, like bench.py's."""
+    code = "import sys; sys.path[:0] = [%r, %r]; import test_gpu_comm as t; t._roundtrip(); print('RCCL-OK')" % (
+        ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def _roundtrip():
     from differt2d_amd.engine import Context, make_params
     from differt2d_amd.parallel import ShardedSweep
 

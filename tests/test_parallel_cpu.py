@@ -84,3 +84,35 @@ def test_sharded_map_over_gloo(world):
     for rank, ok, vjp in sorted(results):
         assert ok is True, f"rank {rank}: {vjp}"
         assert vjp == [world * (world + 1) / 2, 2.0 * world]
+
+
+def _rdzv_worker(rank, world, d, q):
+    sys.path.insert(0, ROOT)
+    os.environ["D2D_RDZV_DIR"] = d
+    from differt2d_amd.parallel import file_rendezvous
+
+    uid = file_rendezvous(rank, world, lambda: bytes(range(128)), timeout=60)
+    q.put((rank, uid))
+
+
+def test_file_rendezvous_ships_the_unique_id(tmp_path):
+    import multiprocessing as mp
+
+    from differt2d_amd.parallel import file_rendezvous_cleanup
+
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    d = str(tmp_path / "rdzv")
+    procs = [mpctx.Process(target=_rdzv_worker, args=(r, 3, d, q)) for r in (2, 1, 0)]  # rank 0 starts last
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert all(got[r] == bytes(range(128)) for r in range(3))
+    os.environ["D2D_RDZV_DIR"] = d
+    try:
+        file_rendezvous_cleanup(0)
+    finally:
+        del os.environ["D2D_RDZV_DIR"]
+    assert not os.path.exists(d)
