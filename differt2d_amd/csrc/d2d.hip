@@ -87,7 +87,7 @@ struct d2d_ctx {
     std::vector<int> cw;           // compact list of allowed indices
     float occl_patch = NAN;        // patch the occlusion table was built for
     // scene (device)
-    DevBuf<float4> d_occl, d_refl;
+    DevBuf<float4> d_occl, d_refl, d_flt;
     DevBuf<int> d_cw;
     DevBuf<unsigned char> d_kind;
     DevBuf<float> d_phi;
@@ -124,6 +124,7 @@ int set_device(d2d_ctx* c) {
 // sq = where(t.t == 0, 1, t.t) (:596-597).
 int upload_refl(d2d_ctx* c) {
     std::vector<float4> refl(2 * (size_t)c->N + 2);
+    std::vector<float4> flt((size_t)c->N + 1);
     for (int j = 0; j < c->N; ++j) {
         const float* w = &c->xys[4 * (size_t)j];
         float ox = w[0], oy = w[1], dx = w[2], dy = w[3];
@@ -136,9 +137,14 @@ int upload_refl(d2d_ctx* c) {
         if (sq == 0.0f) sq = 1.0f;
         refl[2 * j] = make_float4(ox, oy, nx, ny);
         refl[2 * j + 1] = make_float4(tx, ty, sq, len);
+        // pre-filter constants: 1/sq and the error-bound coefficient (64 ulp of the magnitudes entering s)
+        const double rsq = 1.0 / (double)sq;
+        flt[j] = make_float4((float)rsq, (float)(64.0 * 1.1920929e-07 * rsq), 0.0f, 0.0f);
     }
     int rc = c->d_refl.ensure(refl.size());
     if (rc) return rc;
+    if ((rc = c->d_flt.ensure(flt.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_flt.p, flt.data(), flt.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     if ((rc = c->d_kind.ensure((size_t)c->N + 1))) return rc;
     if ((rc = c->d_phi.ensure((size_t)c->N + 1))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_refl.p, refl.data(), refl.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
@@ -313,6 +319,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_hostred.release();
     c->d_occl.release();
     c->d_refl.release();
+    c->d_flt.release();
     c->d_cw.release();
     c->d_kind.release();
     c->d_phi.release();
@@ -484,6 +491,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     memset(&a, 0, sizeof a);
     a.occl = c->d_occl.p;
     a.refl = c->d_refl.p;
+    a.flt = c->d_flt.p;
     a.cw = c->d_cw.p;
     a.N = c->N;
     a.Nc = (int)c->cw.size();
@@ -514,6 +522,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     double hi = 1.0 + (double)p->seg_tol + widen;
     a.flt_lo = (float)(lo * (1.0 + 1e-5) - 1e-30);
     a.flt_hi = (float)(hi * (1.0 + 1e-5) + 1e-30);
+    // on_objects is exactly 0 / False once s < -widen or s > 1 + widen (same saturation argument)
+    a.on_lo = (float)(-widen * (1.0 + 1e-5) - 1e-30);
+    a.on_hi = (float)((1.0 + widen) * (1.0 + 1e-5) + 1e-30);
     for (int k = 0; k <= D2D_MAX_ORDER; ++k) a.fnum[k] = integer_pow(p->r_coef, k);
     a.h2 = p->height * p->height;
     a.fun_id = p->fun_id;
@@ -617,6 +628,27 @@ int d2d_get_scene_vjp(d2d_ctx* c, float* tx_bar, float* xys_bar) {
         for (int i = 0; i < 4 * c->N; ++i) xys_bar[i] = (float)h[(size_t)i];
     tx_bar[0] = (float)h[(size_t)4 * c->N];
     tx_bar[1] = (float)h[(size_t)4 * c->N + 1];
+    return D2D_OK;
+}
+
+int d2d_selftest_div(d2d_ctx* c, const float* x, const float* y, int64_t n, float* q_fast, float* q_ref, float* q_hostr) {
+    if (!c || !x || !y || !q_fast || !q_ref || !q_hostr || n <= 0) return fail(D2D_ERR_INVALID, "bad argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    DevBuf<float> dx, dy, dr, d1, d2, d3;
+    std::vector<float> ry((size_t)n);
+    for (int64_t i = 0; i < n; ++i) ry[(size_t)i] = 1.0f / y[i];
+    if ((rc = dx.ensure(n)) || (rc = dy.ensure(n)) || (rc = dr.ensure(n)) || (rc = d1.ensure(n)) || (rc = d2.ensure(n)) || (rc = d3.ensure(n))) return rc;
+    HIP_TRY(hipMemcpy(dx.p, x, n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dy.p, y, n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dr.p, ry.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(d2d::selftest_div_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dx.p, dy.p, d1.p, d2.p, d3.p, dr.p, (long)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(q_fast, d1.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(q_ref, d2.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(q_hostr, d3.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    dx.release(); dy.release(); dr.release(); d1.release(); d2.release(); d3.release();
     return D2D_OK;
 }
 

@@ -26,6 +26,7 @@ struct SweepArgs {
     // scene tables (device, read-only, wave-uniform indexing -> scalar loads)
     const float4* __restrict__ occl;  // [N]  {p1x, p1y, Ax, Ay}: patched origin and P2-P1 (geometry.py:632-636)
     const float4* __restrict__ refl;  // [2N] {ox, oy, nx, ny}, {tx, ty, sq, 0}: reflection data
+    const float4* __restrict__ flt;   // [N]  {1/sq, margin * 1/sq, 0, 0}: constants of the on_objects pre-filter
     const int* __restrict__ cw;       // [Nc] object indices allowed in candidates (filter_objects)
     int N, Nc;
     // grid
@@ -39,6 +40,7 @@ struct SweepArgs {
     float alpha, tol;
     float seg_lo, seg_hi;      // -seg_tol, 1 + seg_tol (fp32, as geometry.py:168-169)
     float flt_lo, flt_hi;      // conservative "certainly outside the window" thresholds for the divide-free filter
+    float on_lo, on_hi;        // parametric coordinate certainly outside the wall: s < on_lo or s > on_hi => on_objects == 0
     float fnum[D2D_MAX_ORDER + 1];  // r_coef ** k (lax.integer_pow), k = 0..D2D_MAX_ORDER
     float h2;                  // height * height
     int fun_id;
@@ -61,10 +63,58 @@ struct SweepArgs {
 //   [4] segment/wall tests evaluated (filter)           [5] tests that took the exact-divide path
 //   [6] sum over [0] of the candidate order k           [7] sum over [1] of k   [8] sum over [3] of (k+1)
 struct WaveStats {
-    unsigned long long c[9];
+    unsigned long long c[10];  // [9] candidates that went through the on_objects pre-filter
 };
 
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p); }
+
+// ---- correctly rounded fp32 division without the range scaling of the generic expansion --------------
+// hipcc expands x / y (with -fhip-fp32-correctly-rounded-divide-sqrt) into v_div_scale x2, v_rcp, a Newton
+// step on the reciprocal, two residual corrections of the quotient (the last one in v_div_fmas) and
+// v_div_fixup.  When neither operand needs scaling (|x|, |y| in [2^-62, 2^62] or x == 0) the scale factors
+// are 1 and the fixup is the identity, so the bare fma chain below returns the same correctly rounded
+// quotient; it costs 8 VALU ops instead of 11 and lets several numerators share one refined reciprocal.
+// d2d_selftest_div checks bit-equality with x / y on the GPU (tests/test_gpu_selftest.py).
+#ifndef D2D_FAST_DIV
+#define D2D_FAST_DIV 1
+#endif
+__device__ __forceinline__ bool div_in_range(float x) {
+    float ax = fabsf(x);
+    return ax >= 2.168404345e-19f && ax <= 4.611686018e18f;  // [2^-62, 2^62]
+}
+__device__ __forceinline__ float rcp_refined(float y) {
+    float r = __builtin_amdgcn_rcpf(y);
+    float e = __builtin_fmaf(-y, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_with_rcp(float x, float y, float r) {
+    float q = x * r;
+    float e = __builtin_fmaf(-y, q, x);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-y, q, x);
+    return __builtin_fmaf(e, r, q);
+}
+// x1 / y and x2 / y, correctly rounded; wave-uniform choice between the bare chain and the generic expansion
+__device__ __forceinline__ void div2_exact(float x1, float x2, float y, float& q1, float& q2) {
+#if D2D_FAST_DIV
+    const bool ok = div_in_range(y) && (x1 == 0.0f || div_in_range(x1)) && (x2 == 0.0f || div_in_range(x2));
+    if (!wave_any(!ok)) {
+        const float r = rcp_refined(y);
+        q1 = div_with_rcp(x1, y, r);
+        q2 = div_with_rcp(x2, y, r);
+        return;
+    }
+#endif
+    q1 = x1 / y;
+    q2 = x2 / y;
+}
+__device__ __forceinline__ float div1_exact(float x, float y) {
+#if D2D_FAST_DIV
+    const bool ok = div_in_range(y) && (x == 0.0f || div_in_range(x));
+    if (!wave_any(!ok)) return div_with_rcp(x, y, rcp_refined(y));
+#endif
+    return x / y;
+}
 
 // Reflection of a point (wave-uniform data, geometry.py:652-670).
 __device__ __forceinline__ void image_of(const float4& r0, float px, float py, float& ox, float& oy) {
@@ -135,10 +185,6 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                                                const float (&imgx)[D2D_MAX_ORDER], const float (&imgy)[D2D_MAX_ORDER],
                                                float rxx, float rxy, bool lane_bad, float& acc, WaveStats& st,
                                                GradCtx* g = nullptr) {
-    if (STATS) {
-        st.c[0] += 1;
-        st.c[6] += K;
-    }
     int on_i = 0, on_w = 0, hit_i = 0, hit_j = -1;  // GRAD: which activation carries the min / max
     bool znan = false;  // GRAD: the reference's autodiff yields NaN for this (cell, candidate), see below
     float px[K + 2], py[K + 2];
@@ -147,6 +193,36 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     px[K + 1] = rxx;
     py[K + 1] = rxy;
 
+    // ---- pre-filter on the LAST interaction point (the first one the backward scan produces) -----------
+    // With an approximate quotient (v_rcp, a few ulp) and an explicit error bound M, decide whether the point's
+    // parametric coordinate s on its wall is certainly outside the range where on_objects is not exactly 0.
+    // If that holds in every lane, valid == 0 for the whole wave whatever the other points are: skip the
+    // candidate before any exact division.  (Not in the GRAD build: the reference's autodiff NaN traps depend
+    // on all interaction points.)
+    if (!GRAD && K > 0) {
+        const float4 r0 = a.refl[2 * cand[K - 1]];
+        const float4 r1 = a.refl[2 * cand[K - 1] + 1];
+        const float4 fc = a.flt[cand[K - 1]];
+        float ux = rxx - imgx[K - 1], uy = rxy - imgy[K - 1];
+        float vx = r0.x - rxx, vy = r0.y - rxy;
+        float un = ux * r0.z + uy * r0.w;
+        float vn = vx * r0.z + vy * r0.w;
+        float gq = vn * __builtin_amdgcn_rcpf(un);
+        float dx = __builtin_fmaf(gq, ux, -vx), dy = __builtin_fmaf(gq, uy, -vy);  // p - origin
+        float sa = __builtin_fmaf(r1.y, dy, r1.x * dx) * fc.x;
+        // magnitudes that enter p - origin on the exact path (incl. the rounding of p = pt + inc at |origin| scale)
+        float ex = __builtin_fmaf(fabsf(gq), fabsf(ux), fabsf(vx)) + fabsf(r0.x);
+        float ey = __builtin_fmaf(fabsf(gq), fabsf(uy), fabsf(vy)) + fabsf(r0.y);
+        float M = __builtin_fmaf(__builtin_fmaf(fabsf(r1.y), ey, fabsf(r1.x) * ex), fc.y, 1e-30f);
+        bool cull = !lane_bad && (un != 0.0f) && (ex < 1e18f) && (ey < 1e18f) && ((sa + M < a.on_lo) || (sa - M > a.on_hi));
+        if (STATS) st.c[9] += 1;
+        if (!wave_any(!cull)) return;
+    }
+
+    if (STATS) {
+        st.c[0] += 1;
+        st.c[6] += K;
+    }
     // ---- backward scan of the image method, geometry.py:1093-1110 -------------------------
     {
         float ptx = rxx, pty = rxy;
@@ -159,8 +235,10 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             float vn = vx * r0.z + vy * r0.w;
             bool z = (un == 0.0f);
             float den = z ? 1.0f : un;
-            float incx = z ? 0.0f : (vn * ux) / den;
-            float incy = z ? 0.0f : (vn * uy) / den;
+            float incx, incy;
+            div2_exact(vn * ux, vn * uy, den, incx, incy);
+            incx = z ? 0.0f : incx;
+            incy = z ? 0.0f : incy;
             ptx = ptx + incx;
             pty = pty + incy;
             px[i + 1] = ptx;
@@ -210,7 +288,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         const float4 r0 = a.refl[2 * cand[i]];
         const float4 r1 = a.refl[2 * cand[i] + 1];
         float dx = px[i + 1] - r0.x, dy = py[i + 1] - r0.y;
-        float s = (r1.x * dx + r1.y * dy) / r1.z;
+        float s = div1_exact(r1.x * dx + r1.y * dy, r1.z);
         if (MODE == MODE_HARD) {
             on_b = on_b && (s >= 0.0f) && (s <= 1.0f);
         } else if (MODE == MODE_HSIG) {
@@ -672,7 +750,7 @@ __global__ void __launch_bounds__(64) power_fwd_kernel(SweepArgs a) {
     float acc = 0.0f;  // scene.py:1893
     WaveStats st;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) st.c[i] = 0;
+    for (int i = 0; i < 10; ++i) st.c[i] = 0;
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
     if (a.min_order <= 1 && a.max_order >= 1) sweep_order<1, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
     if (a.min_order <= 2 && a.max_order >= 2) sweep_order<2, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
@@ -684,8 +762,18 @@ __global__ void __launch_bounds__(64) power_fwd_kernel(SweepArgs a) {
     }
     if (STATS && lane == 0 && a.stats) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) atomicAdd(&a.stats[i], st.c[i]);
+        for (int i = 0; i < 10; ++i) atomicAdd(&a.stats[i], st.c[i]);
     }
+}
+
+// Self-test of the bare division chain against the compiler's generic expansion (bit equality expected).
+__global__ void selftest_div_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ q_fast,
+                                    float* __restrict__ q_ref, float* __restrict__ q_hostr, const float* __restrict__ ry, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    q_fast[i] = div_with_rcp(x[i], y[i], rcp_refined(y[i]));
+    q_ref[i] = x[i] / y[i];
+    q_hostr[i] = div_with_rcp(x[i], y[i], ry[i]);  // with a host-computed correctly rounded reciprocal
 }
 
 // Value + gradient sweep: same forward arithmetic as power_fwd_kernel (bit-identical values), plus the

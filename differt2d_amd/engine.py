@@ -197,6 +197,14 @@ class Context:
         L.check(self._lib.d2d_power_map_stats(self._ctx, C.byref(params), tx, stats))
         return stats
 
+    def selftest_div(self, x, y):
+        """(q_fast, q_ref, q_hostr) of the division self-test (include/d2d.h)."""
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        y = np.ascontiguousarray(y, dtype=np.float32).reshape(-1)
+        outs = [np.empty_like(x) for _ in range(3)]
+        L.check(self._lib.d2d_selftest_div(self._ctx, x, y, x.size, *outs))
+        return outs
+
     def get_map(self) -> np.ndarray:
         out = np.empty(self.shape, np.float32)
         L.check(self._lib.d2d_get_map(self._ctx, out))

@@ -161,9 +161,15 @@ int d2d_get_scene_vjp(d2d_ctx* ctx, float* tx_bar, float* xys_bar);
  *   [2] ... that reached the occlusion loop                      [3] ... that reached valid * fun
  *   [4] segment/wall tests evaluated                             [5] tests that took the exact-divide path
  *   [6] sum of k over [0]    [7] sum of k over [1]    [8] sum of (k+1) over [3]
+ *   [9] candidates that went through the approximate on_objects pre-filter (all candidates of order >= 1)
  * bench.py prices these with SURVEY.md section 8(d)'s per-unit FLOP figures. */
-#define D2D_NUM_STATS 9
+#define D2D_NUM_STATS 10
 int d2d_power_map_stats(d2d_ctx* ctx, const d2d_params* params, const float* tx, uint64_t* stats);
+
+/* Diagnostic: evaluates x[i] / y[i] on the GPU three ways -- q_fast: the kernels' bare fma chain on a refined
+ * v_rcp; q_ref: the compiler's generic correctly rounded expansion; q_hostr: the bare chain on a host-computed
+ * reciprocal. For operands in [2^-62, 2^62] (or x == 0) all three must be bit-identical. */
+int d2d_selftest_div(d2d_ctx* ctx, const float* x, const float* y, int64_t n, float* q_fast, float* q_ref, float* q_hostr);
 
 /* Synchronises and copies the resident value map to out[m*n]. */
 int d2d_get_map(d2d_ctx* ctx, float* out);
