@@ -66,7 +66,7 @@ def executed_flop(stats, approx):
     f_seg = 41 if approx else 17
     s = [int(v) for v in stats]
     per_wave = s[6] * 36 + s[7] * 29 + s[4] * f_seg + (s[8] - s[3]) * 9 + s[3] * 23
-    per_wave += s[9] * 30  # approximate on_objects pre-filter: ~30 FLOP per candidate of order >= 1
+    per_wave += s[9] * 120  # tile culling: per level 4 vertex evaluations of ~30 FLOP in each of the 64 lanes
     return per_wave * 64
 
 
@@ -246,7 +246,7 @@ def main():
                 "unpruned_flop_per_launch": flop_unpruned,
                 "unpruned_equiv_TFLOPs": flop_unpruned / (kernel_ms * 1e-3) / 1e12,
                 "executed_lane_units": {
-                    "prefiltered": int(stats[9]) * 64, "candidates_exact": int(stats[0]) * 64, "reached_loss": int(stats[1]) * 64,
+                    "cull_levels": int(stats[9]) * 64, "candidates_exact": int(stats[0]) * 64, "reached_loss": int(stats[1]) * 64,
                     "reached_occlusion": int(stats[2]) * 64, "reached_fun": int(stats[3]) * 64,
                     "segment_tests": int(stats[4]) * 64, "exact_divide_tests": int(stats[5]) * 64,
                 },

@@ -565,17 +565,19 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
         return D2D_OK;
     }
+    const size_t tab_lds = (size_t)(3 * c->N + 1) * sizeof(float4);
+    if (tab_lds > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~1300)", c->N);
     if (d_stats) {
         switch (mode) {
-            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HARD, true>), grid, block, 0, c->stream, a); break;
-            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HSIG, true>), grid, block, 0, c->stream, a); break;
-            default: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_SIG, true>), grid, block, 0, c->stream, a); break;
+            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HARD, true>), grid, block, tab_lds, c->stream, a); break;
+            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HSIG, true>), grid, block, tab_lds, c->stream, a); break;
+            default: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_SIG, true>), grid, block, tab_lds, c->stream, a); break;
         }
     } else {
         switch (mode) {
-            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HARD, false>), grid, block, 0, c->stream, a); break;
-            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HSIG, false>), grid, block, 0, c->stream, a); break;
-            default: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_SIG, false>), grid, block, 0, c->stream, a); break;
+            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HARD, false>), grid, block, tab_lds, c->stream, a); break;
+            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HSIG, false>), grid, block, tab_lds, c->stream, a); break;
+            default: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_SIG, false>), grid, block, tab_lds, c->stream, a); break;
         }
     }
     HIP_TRY(hipGetLastError());

@@ -180,7 +180,7 @@ __device__ __forceinline__ void normalize2_bwd(float vx, float vy, float obx, fl
     vby = (oby - d * oy) / len;
 }
 
-template <int K, int MODE, bool STATS, bool GRAD = false>
+template <int K, int MODE, bool STATS, bool GRAD = false, bool PREF = true>
 __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&cand)[D2D_MAX_ORDER],
                                                const float (&imgx)[D2D_MAX_ORDER], const float (&imgy)[D2D_MAX_ORDER],
                                                float rxx, float rxy, bool lane_bad, float& acc, WaveStats& st,
@@ -199,7 +199,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // If that holds in every lane, valid == 0 for the whole wave whatever the other points are: skip the
     // candidate before any exact division.  (Not in the GRAD build: the reference's autodiff NaN traps depend
     // on all interaction points.)
-    if (!GRAD && K > 0) {
+    if (PREF && !GRAD && K > 0) {
         const float4 r0 = a.refl[2 * cand[K - 1]];
         const float4 r1 = a.refl[2 * cand[K - 1] + 1];
         const float4 fc = a.flt[cand[K - 1]];
@@ -729,6 +729,183 @@ __device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float
     }
 }
 
+// =====================================================================================
+// Candidate-parallel tile culling.
+//
+// A wave owns an 8 x 8 patch of RX cells.  Before the cells (one per lane) walk the candidates of a
+// prefix (w_0 .. w_{K-2}) one by one, the wave turns its lanes around: lane l takes the candidate whose
+// LAST wall is the l-th allowed object, and decides -- conservatively, for the whole patch at once --
+// whether on_objects can be anything but exactly 0 for any cell of the patch.  Survivors come back as a
+// ballot mask and are then evaluated exactly, in the reference's order, by eval_candidate.
+//
+// The test: the parametric coordinate s of the point where the line (rx -> image) meets the wall's line
+// is a linear-fractional function of rx; over a convex region that does not meet its pole line
+// (un = (rx - image).n = 0) it is monotone along every segment, so its range over the region is spanned
+// by the region's vertices.  Level 1 evaluates the 4 corners of the patch's bounding box against the last
+// wall; level j > 1 takes the sub-segment of wall K-j+1 that level j-1 left possible (widened by the
+// rounding bound, as a thin quad around the wall) and evaluates its 4 vertices against wall K-j.
+// A candidate is dropped only if some level proves s outside the window where the activation is not
+// exactly saturated to 0 (hard: [0,1]; hard_sigmoid: widened by 3/alpha; sigmoid: by 89/alpha), with an
+// explicit bound M on |s_fp32(exact path) - s_real| -- so dropping it cannot change a bit of the output.
+// =====================================================================================
+struct WallC {  // what the culling needs of a wall
+    float ox, oy, nx, ny, tx, ty, rsq;
+};
+
+__device__ __forceinline__ WallC make_wallc(const float4& r0, const float4& r1, const float4& fc) {
+    return WallC{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, fc.x};
+}
+
+// Range of s over the convex hull of 4 points; returns false when the region may meet the pole line or
+// anything is not comfortably finite (then nothing may be concluded).
+__device__ __forceinline__ bool s_range(const float (&qx)[4], const float (&qy)[4], float Ix, float Iy, const WallC& w,
+                                        float& smin, float& smax, float& M, float& E) {
+    const float eps = 1.1920929e-07f;
+    bool pos = true, neg = true, fin = true;
+    smin = __builtin_inff();
+    smax = -__builtin_inff();
+    E = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float ux = qx[j] - Ix, uy = qy[j] - Iy;
+        float vx = w.ox - qx[j], vy = w.oy - qy[j];
+        float un = __builtin_fmaf(ux, w.nx, uy * w.ny);
+        float vn = __builtin_fmaf(vx, w.nx, vy * w.ny);
+        // bound on |un_fp32 - un_real| for any evaluation order of this expression
+        float du = 8.0f * eps * __builtin_fmaf(fabsf(w.nx), fabsf(qx[j]) + fabsf(Ix), fabsf(w.ny) * (fabsf(qy[j]) + fabsf(Iy)));
+        pos = pos && (un > du);
+        neg = neg && (un < -du);
+        float g = vn * __builtin_amdgcn_rcpf(un);
+        float dx = __builtin_fmaf(g, ux, -vx), dy = __builtin_fmaf(g, uy, -vy);
+        float s = __builtin_fmaf(w.ty, dy, w.tx * dx) * w.rsq;
+        float mag = __builtin_fmaf(fabsf(g), fabsf(ux) + fabsf(uy), fabsf(vx) + fabsf(vy));
+        fin = fin && (mag < 1e18f);
+        smin = fminf(smin, s);
+        smax = fmaxf(smax, s);
+        E = fmaxf(E, mag);
+    }
+    E = E + (fabsf(w.ox) + fabsf(w.oy)) + (fabsf(Ix) + fabsf(Iy));
+    M = __builtin_fmaf(64.0f * eps * w.rsq * (fabsf(w.tx) + fabsf(w.ty)), 2.0f * E, 1e-30f);
+    return (pos || neg) && fin;
+}
+
+// true = the candidate is certainly invalid for every cell of the patch.
+// walls[j], images[j] for j = K-1 (last wall) down to 0; level 1 uses the patch box.
+template <int K>
+__device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float (&by)[4], const WallC (&w)[K],
+                                               const float (&Ix)[K], const float (&Iy)[K], float on_lo, float on_hi) {
+    const float eps = 1.1920929e-07f;
+    float qx[4], qy[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        qx[j] = bx[j];
+        qy[j] = by[j];
+    }
+#pragma unroll
+    for (int lvl = K - 1; lvl >= 0; --lvl) {
+        float smin, smax, M, E;
+        bool ok = s_range(qx, qy, Ix[lvl], Iy[lvl], w[lvl], smin, smax, M, E);
+        if (!ok) return false;
+        if (smax + M < on_lo || smin - M > on_hi) return true;
+        if (lvl == 0) break;
+        // what is left of wall `lvl` for the next level: sigma in [sa, sb], as a thin quad around the wall
+        float sa = fmaxf(smin - M, on_lo), sb = fminf(smax + M, on_hi);
+        float d = 64.0f * eps * 2.0f * E;  // the fp32 point may sit this far off the wall's line
+        float eax = __builtin_fmaf(sa, w[lvl].tx, w[lvl].ox), eay = __builtin_fmaf(sa, w[lvl].ty, w[lvl].oy);
+        float ebx = __builtin_fmaf(sb, w[lvl].tx, w[lvl].ox), eby = __builtin_fmaf(sb, w[lvl].ty, w[lvl].oy);
+        float ddx = d * w[lvl].nx, ddy = d * w[lvl].ny;
+        // also pad along the wall: the end points above carry their own rounding
+        float px_ = d * w[lvl].tx * w[lvl].rsq * (fabsf(w[lvl].tx) + fabsf(w[lvl].ty)), py_ = d * w[lvl].ty * w[lvl].rsq * (fabsf(w[lvl].tx) + fabsf(w[lvl].ty));
+        qx[0] = eax - px_ + ddx; qy[0] = eay - py_ + ddy;
+        qx[1] = eax - px_ - ddx; qy[1] = eay - py_ - ddy;
+        qx[2] = ebx + px_ + ddx; qy[2] = eby + py_ + ddy;
+        qx[3] = ebx + px_ - ddx; qy[3] = eby + py_ - ddy;
+    }
+    return false;
+}
+
+// All candidates of order K >= 1 with tile culling; `tab` = LDS copy of {refl[2N], flt[N]}.
+template <int K, int MODE, bool STATS>
+__device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const float4* tab, const float (&bx)[4],
+                                                   const float (&by)[4], float rxx, float rxy, bool lane_bad, float& acc,
+                                                   WaveStats& st) {
+    const int lane = threadIdx.x & 63;
+    int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+    float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];
+    const int Nc = a.Nc;
+    // odometer over the K-1 prefix positions (wave-uniform)
+    int pos[D2D_MAX_ORDER] = {0, 0, 0, 0};
+    const int n_chunks = (Nc + 63) >> 6;
+    // iterate prefixes in lexicographic order
+    // first prefix
+#pragma unroll
+    for (int d = 0; d < K - 1; ++d) pos[d] = (d & 1) ? 1 : 0;  // 0,1,0,... has no equal neighbours
+    if (K - 1 > 0 && Nc < 2) return;
+    if (Nc < 1) return;
+    while (true) {
+        // images of the prefix
+#pragma unroll
+        for (int d = 0; d < K - 1; ++d) {
+            cand[d] = a.cw[pos[d]];
+            const float4 r0 = a.refl[2 * cand[d]];
+            image_of(r0, d == 0 ? a.txx : imgx[d > 0 ? d - 1 : 0], d == 0 ? a.txy : imgy[d > 0 ? d - 1 : 0], imgx[d], imgy[d]);
+        }
+        const float pIx = (K == 1) ? a.txx : imgx[K >= 2 ? K - 2 : 0];
+        const float pIy = (K == 1) ? a.txy : imgy[K >= 2 ? K - 2 : 0];
+        const int last_prefix_pos = (K == 1) ? -1 : pos[K >= 2 ? K - 2 : 0];
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            // ---- lanes = candidates: lane l <-> last wall = cw[chunk * 64 + l]
+            const int lp = chunk * 64 + lane;
+            bool alive = (lp < Nc) && (lp != last_prefix_pos);
+            {
+                const int wl = a.cw[lp < Nc ? lp : 0];
+                WallC w[K];
+                float Ix[K], Iy[K];
+                const float4 r0 = tab[2 * wl], r1 = tab[2 * wl + 1], fc = tab[2 * a.N + wl];
+                w[K - 1] = make_wallc(r0, r1, fc);
+                image_of(r0, pIx, pIy, Ix[K - 1], Iy[K - 1]);
+#pragma unroll
+                for (int d = 0; d < K - 1; ++d) {
+                    const int wd = cand[d];
+                    w[d] = make_wallc(a.refl[2 * wd], a.refl[2 * wd + 1], a.flt[wd]);
+                    Ix[d] = imgx[d];
+                    Iy[d] = imgy[d];
+                }
+                if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi)) alive = false;
+            }
+            unsigned long long mask = __ballot(alive);
+            if (STATS) st.c[9] += K;
+            // ---- lanes = RX cells: survivors in ascending order (= the reference's order)
+            while (mask) {
+                const int b = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                cand[K - 1] = a.cw[chunk * 64 + b];
+                image_of(a.refl[2 * cand[K - 1]], pIx, pIy, imgx[K - 1], imgy[K - 1]);
+                eval_candidate<K, MODE, STATS, false, false>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
+            }
+        }
+        // next prefix (lexicographic, no equal neighbours); static indexing keeps pos[] in registers
+        if (K == 1) break;
+        bool carry = true;
+        int stop = -1;
+#pragma unroll
+        for (int d = K - 2; d >= 0; --d) {
+            if (carry) {
+                pos[d] += 1;
+                if (d > 0 && pos[d] == pos[d - 1]) pos[d] += 1;
+                if (pos[d] < Nc) {
+                    carry = false;
+                    stop = d;
+                }
+            }
+        }
+        if (carry) break;  // the first position overflowed: all prefixes done
+#pragma unroll
+        for (int e = 1; e < K - 1; ++e)
+            if (e > stop) pos[e] = (pos[e - 1] == 0) ? 1 : 0;
+    }
+}
+
 constexpr int TILE_W = 8;  // a wave covers an 8 x 8 patch of RX cells: neighbouring cells share skips
 constexpr int TILE_H = 8;
 
@@ -751,11 +928,29 @@ __global__ void __launch_bounds__(64) power_fwd_kernel(SweepArgs a) {
     WaveStats st;
 #pragma unroll
     for (int i = 0; i < 10; ++i) st.c[i] = 0;
+    // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index)
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    __syncthreads();
+    // bounding box of the wave's cells (NaN / inf coordinates make every comparison fail: nothing is culled)
+    float x0 = rxx, x1 = rxx, y0 = rxy, y1 = rxy;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, off, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
+        y0 = fminf(y0, __shfl_xor(y0, off, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+    }
+    const bool box_ok = !wave_any(lane_bad);
+    const float qn = __builtin_nanf("");
+    const float bx[4] = {box_ok ? x0 : qn, x1, x1, x0};
+    const float by[4] = {y0, y0, y1, y1};
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
-    if (a.min_order <= 1 && a.max_order >= 1) sweep_order<1, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
-    if (a.min_order <= 2 && a.max_order >= 2) sweep_order<2, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
-    if (a.min_order <= 3 && a.max_order >= 3) sweep_order<3, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
-    if (a.min_order <= 4 && a.max_order >= 4) sweep_order<4, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
+    if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
+    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled<2, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
+    if (a.min_order <= 3 && a.max_order >= 3) sweep_order_culled<3, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
+    if (a.min_order <= 4 && a.max_order >= 4) sweep_order_culled<4, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
     if (in_range) {
         if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
         else a.out[idx] = acc;

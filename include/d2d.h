@@ -161,7 +161,7 @@ int d2d_get_scene_vjp(d2d_ctx* ctx, float* tx_bar, float* xys_bar);
  *   [2] ... that reached the occlusion loop                      [3] ... that reached valid * fun
  *   [4] segment/wall tests evaluated                             [5] tests that took the exact-divide path
  *   [6] sum of k over [0]    [7] sum of k over [1]    [8] sum of (k+1) over [3]
- *   [9] candidates that went through the approximate on_objects pre-filter (all candidates of order >= 1)
+ *   [9] tile-culling levels evaluated (one count = 64 candidates x 4 vertex evaluations)
  * bench.py prices these with SURVEY.md section 8(d)'s per-unit FLOP figures. */
 #define D2D_NUM_STATS 10
 int d2d_power_map_stats(d2d_ctx* ctx, const d2d_params* params, const float* tx, uint64_t* stats);
