@@ -525,6 +525,12 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     // on_objects is exactly 0 / False once s < -widen or s > 1 + widen (same saturation argument)
     a.on_lo = (float)(-widen * (1.0 + 1e-5) - 1e-30);
     a.on_hi = (float)((1.0 + widen) * (1.0 + 1e-5) + 1e-30);
+    // loss certificate threshold (d2d_kernels.hpp): hard -> loss < tol decides; approx -> tol - loss must round to tol
+    a.loss_skip = -1.0f;
+    if (p->tol > 1e-30f && std::isfinite(p->tol)) {
+        if (!p->approx) a.loss_skip = p->tol * 0.999f;
+        else a.loss_skip = 0.49f * (p->tol - std::nextafterf(p->tol, 0.0f));
+    }
     for (int k = 0; k <= D2D_MAX_ORDER; ++k) a.fnum[k] = integer_pow(p->r_coef, k);
     a.h2 = p->height * p->height;
     a.fun_id = p->fun_id;
@@ -567,17 +573,25 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     }
     const size_t tab_lds = (size_t)(3 * c->N + 1) * sizeof(float4);
     if (tab_lds > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~1300)", c->N);
+#define D2D_LAUNCH_FWD(MODE_, STATS_, MAXK_) \
+    hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, STATS_, MAXK_>), grid, block, tab_lds, c->stream, a)
+#define D2D_LAUNCH_FWD_K(MODE_, STATS_)                      \
+    do {                                                     \
+        if (p->max_order <= 2) D2D_LAUNCH_FWD(MODE_, STATS_, 2); \
+        else if (p->max_order == 3) D2D_LAUNCH_FWD(MODE_, STATS_, 3); \
+        else D2D_LAUNCH_FWD(MODE_, STATS_, 4);                \
+    } while (0)
     if (d_stats) {
         switch (mode) {
-            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HARD, true>), grid, block, tab_lds, c->stream, a); break;
-            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HSIG, true>), grid, block, tab_lds, c->stream, a); break;
-            default: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_SIG, true>), grid, block, tab_lds, c->stream, a); break;
+            case d2d::MODE_HARD: D2D_LAUNCH_FWD_K(d2d::MODE_HARD, true); break;
+            case d2d::MODE_HSIG: D2D_LAUNCH_FWD_K(d2d::MODE_HSIG, true); break;
+            default: D2D_LAUNCH_FWD_K(d2d::MODE_SIG, true); break;
         }
     } else {
         switch (mode) {
-            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HARD, false>), grid, block, tab_lds, c->stream, a); break;
-            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_HSIG, false>), grid, block, tab_lds, c->stream, a); break;
-            default: hipLaunchKernelGGL((d2d::power_fwd_kernel<d2d::MODE_SIG, false>), grid, block, tab_lds, c->stream, a); break;
+            case d2d::MODE_HARD: D2D_LAUNCH_FWD_K(d2d::MODE_HARD, false); break;
+            case d2d::MODE_HSIG: D2D_LAUNCH_FWD_K(d2d::MODE_HSIG, false); break;
+            default: D2D_LAUNCH_FWD_K(d2d::MODE_SIG, false); break;
         }
     }
     HIP_TRY(hipGetLastError());

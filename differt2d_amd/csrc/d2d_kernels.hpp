@@ -41,6 +41,7 @@ struct SweepArgs {
     float seg_lo, seg_hi;      // -seg_tol, 1 + seg_tol (fp32, as geometry.py:168-169)
     float flt_lo, flt_hi;      // conservative "certainly outside the window" thresholds for the divide-free filter
     float on_lo, on_hi;        // parametric coordinate certainly outside the wall: s < on_lo or s > on_hi => on_objects == 0
+    float loss_skip;           // a loss certainly below this cannot change less(loss, tol) (see eval_candidate); < 0: never
     float fnum[D2D_MAX_ORDER + 1];  // r_coef ** k (lax.integer_pow), k = 0..D2D_MAX_ORDER
     float h2;                  // height * height
     int fun_id;
@@ -315,23 +316,52 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     bool on_zero = (MODE == MODE_HARD) ? !on_b : (MODE == MODE_HSIG) ? (on_c == 0.0f) : (on_z <= -89.0f);
     if (K > 0 && !wave_any(!on_zero || bad)) return;  // valid == 0 in every lane: acc + 0.0
 
-    if (STATS) {
-        st.c[1] += 1;
-        st.c[7] += K;
-    }
+    if (STATS) st.c[1] += 1;
     // ---- path loss, geometry.py:1077-1084 / 641-650 ---------------------------------------
+    // The loss of an image-method path is rounding noise (~1e-13) unless the path is degenerate, and it only
+    // enters through less(loss, tol).  Certificate: evaluate the specular residuals e_i cheaply (v_rsq, fma);
+    // from the same fp32 points the exact chain's e_i differs by at most c = 8e-6 per residual (both chains
+    // carry < 35 unit roundoffs per component), so loss_exact <= sum (|e_i| + c)^2 =: bound.  If bound is below
+    // loss_skip (hard: tol; approx: half the fp32 spacing below tol, where tol - loss rounds to tol) for every
+    // lane that still matters, the exact loss cannot change any output bit and is not computed.
     float loss = 0.0f;
+    bool loss_known = (K == 0);
+    if (K > 0) {
+        const float c = 8e-6f;
+        float nvx[K + 1], nvy[K + 1];
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
-        const float4 r0 = a.refl[2 * cand[i]];
-        float ix, iy, rx_, ry_;
-        normalize2(px[i + 1] - px[i], py[i + 1] - py[i], ix, iy);
-        normalize2(px[i + 2] - px[i + 1], py[i + 2] - py[i + 1], rx_, ry_);
-        float din = ix * r0.z + iy * r0.w;
-        float s2 = 2.0f * din;
-        float ex = rx_ - (ix - s2 * r0.z);
-        float ey = ry_ - (iy - s2 * r0.w);
-        loss = loss + (ex * ex + ey * ey);
+        for (int i = 0; i <= K; ++i) {
+            float vx = px[i + 1] - px[i], vy = py[i + 1] - py[i];
+            float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(vx, vx, vy * vy));
+            nvx[i] = vx * inv;
+            nvy[i] = vy * inv;
+        }
+        float bound = 0.0f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const float4 r0 = a.refl[2 * cand[i]];
+            float s2 = 2.0f * __builtin_fmaf(nvx[i], r0.z, nvy[i] * r0.w);
+            float ex = __builtin_fmaf(s2, r0.z, nvx[i + 1] - nvx[i]);
+            float ey = __builtin_fmaf(s2, r0.w, nvy[i + 1] - nvy[i]);
+            bound += __builtin_fmaf(2.0f * c, fabsf(ex) + fabsf(ey), __builtin_fmaf(ex, ex, ey * ey)) + c * c;
+        }
+        const bool certain = (bound * 1.00001f < a.loss_skip) && !bad;
+        loss_known = !wave_any(!certain && !on_zero);
+    }
+    if (!loss_known) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const float4 r0 = a.refl[2 * cand[i]];
+            float ix, iy, rx_, ry_;
+            normalize2(px[i + 1] - px[i], py[i + 1] - py[i], ix, iy);
+            normalize2(px[i + 2] - px[i + 1], py[i + 2] - py[i + 1], rx_, ry_);
+            float din = ix * r0.z + iy * r0.w;
+            float s2 = 2.0f * din;
+            float ex = rx_ - (ix - s2 * r0.z);
+            float ey = ry_ - (iy - s2 * r0.w);
+            loss = loss + (ex * ex + ey * ey);
+        }
+        if (STATS) st.c[7] += K;
     }
     bool ok_b = loss < a.tol;                                    // hard: jnp.less
     float ok_x = a.tol - loss;                                   // approx: activation(tol - loss)
@@ -415,10 +445,6 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         if (!wave_any(active)) break;
     }
 
-    if (STATS) {
-        st.c[3] += 1;
-        st.c[8] += K + 1;
-    }
     // ---- is_valid, geometry.py:947-963 -----------------------------------------------------
     float valid;
     float on_v = 1.0f, nh_v = 1.0f, ok_v = 1.0f;
@@ -440,6 +466,9 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         valid = nanflag ? 0.0f : valid;
     }
 
+    // valid is exactly 0 in every lane (all occluded): acc + 0 * fun == acc, and every adjoint is 0
+    if (!wave_any(valid != 0.0f || bad)) return;
+    if (STATS) st.c[3] += 1, st.c[8] += K + 1;
     // ---- fun(path), geometry.py:176-203 and utils.py:17-54 ---------------------------------
     float r = 0.0f;
 #pragma unroll
@@ -909,8 +938,13 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
 constexpr int TILE_W = 8;  // a wave covers an 8 x 8 patch of RX cells: neighbouring cells share skips
 constexpr int TILE_H = 8;
 
-template <int MODE, bool STATS>
-__global__ void __launch_bounds__(64) power_fwd_kernel(SweepArgs a) {
+// MAXK = highest order compiled into this instantiation (the host picks the smallest that covers max_order:
+// register allocation is the maximum over all compiled paths, and orders 3 / 4 need many more VGPRs).
+#ifndef D2D_FWD_WAVES
+#define D2D_FWD_WAVES 1  // minimum waves per SIMD asked of the register allocator (1 = unconstrained)
+#endif
+template <int MODE, bool STATS, int MAXK>
+__global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
     const int tile = blockIdx.x;
@@ -949,8 +983,8 @@ __global__ void __launch_bounds__(64) power_fwd_kernel(SweepArgs a) {
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
     if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
     if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled<2, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
-    if (a.min_order <= 3 && a.max_order >= 3) sweep_order_culled<3, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
-    if (a.min_order <= 4 && a.max_order >= 4) sweep_order_culled<4, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled<3, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_culled<4, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
     if (in_range) {
         if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
         else a.out[idx] = acc;

@@ -158,9 +158,9 @@ int d2d_get_scene_vjp(d2d_ctx* ctx, float* tx_bar, float* xys_bar);
 /* Same sweep through the instrumented build of the kernel (same results, not for timing): fills
  * stats[D2D_NUM_STATS] with executed-work counters summed over waves (one count = one 64-lane wave):
  *   [0] candidates evaluated (interaction points + on_objects)   [1] ... that reached the loss stage
- *   [2] ... that reached the occlusion loop                      [3] ... that reached valid * fun
+ *   [2] ... that reached the occlusion loop                      [3] ... with a non-zero validity (valid * fun evaluated)
  *   [4] segment/wall tests evaluated                             [5] tests that took the exact-divide path
- *   [6] sum of k over [0]    [7] sum of k over [1]    [8] sum of (k+1) over [3]
+ *   [6] sum of k over [0]    [7] sum of k over the candidates whose loss was evaluated exactly    [8] sum of (k+1) over [3]
  *   [9] tile-culling levels evaluated (one count = 64 candidates x 4 vertex evaluations)
  * bench.py prices these with SURVEY.md section 8(d)'s per-unit FLOP figures. */
 #define D2D_NUM_STATS 10
