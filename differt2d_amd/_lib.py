@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(CSRC, "libd2d.so")
 D2D_MAX_ORDER = 4
 D2D_NUM_STATS = 10
 D2D_COMM_ID_BYTES = 128
-D2D_ABI_VERSION = 1
+D2D_ABI_VERSION = 2
 
 D2D_WALL, D2D_RIS, D2D_VERTEX = 0, 1, 2
 SOLVER_IMAGE, SOLVER_MINPATH, SOLVER_FERMAT = 0, 1, 2
@@ -101,7 +101,8 @@ SYMBOLS = [
     ("d2d_get_map", C.c_int, [_ctx, _f32p]),
     ("d2d_power_map", C.c_int, [_ctx, C.POINTER(Params), _f32p, _f32p, _f32p, C.c_int32, C.c_int32, _f32p]),
     ("d2d_trace_paths", C.c_int, [_ctx, C.POINTER(Params), _f32p, _f32p, C.c_int32, _i32p, _i32p, C.c_int32,
-                                  C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("d2d_set_theta0", C.c_int, [_ctx, C.c_void_p, C.c_int64]),
     ("d2d_comm_unique_id", C.c_int, [C.c_void_p]),
     ("d2d_comm_init", C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32]),
     ("d2d_comm_destroy", C.c_int, [_ctx]),

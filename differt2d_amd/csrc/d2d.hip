@@ -90,7 +90,12 @@ struct d2d_ctx {
     DevBuf<float4> d_occl, d_refl, d_flt;
     DevBuf<int> d_cw;
     DevBuf<unsigned char> d_kind;
-    DevBuf<float> d_phi;
+    DevBuf<float2> d_sincos;
+    // optimiser-based solvers
+    DevBuf<float> d_bc1, d_bc2, d_theta0;
+    int bc_steps = -1;
+    std::vector<float> theta0;  // [C][D2D_MAX_ORDER] as set by d2d_set_theta0
+    DevBuf<int> d_scand, d_sorder;
     // trace scratch
     DevBuf<int> d_tcand, d_torder;
     DevBuf<float> d_ttx, d_trx, d_txys_in, d_tloss_in, d_txys, d_tloss, d_tvalid, d_ton, d_thit, d_tlen;
@@ -146,11 +151,13 @@ int upload_refl(d2d_ctx* c) {
     if ((rc = c->d_flt.ensure(flt.size()))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_flt.p, flt.data(), flt.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     if ((rc = c->d_kind.ensure((size_t)c->N + 1))) return rc;
-    if ((rc = c->d_phi.ensure((size_t)c->N + 1))) return rc;
+    if ((rc = c->d_sincos.ensure((size_t)c->N + 1))) return rc;
+    std::vector<float2> sc((size_t)c->N + 1);
+    for (int j = 0; j < c->N; ++j) sc[(size_t)j] = make_float2(sinf(c->phi[j]), cosf(c->phi[j]));  // geometry.py:709-710
     HIP_TRY(hipMemcpyAsync(c->d_refl.p, refl.data(), refl.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     if (c->N > 0) {
         HIP_TRY(hipMemcpyAsync(c->d_kind.p, c->kind.data(), (size_t)c->N, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_phi.p, c->phi.data(), (size_t)c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_sincos.p, sc.data(), (size_t)c->N * sizeof(float2), hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return D2D_OK;
@@ -187,6 +194,47 @@ int upload_mask(d2d_ctx* c) {
         HIP_TRY(hipMemcpyAsync(c->d_cw.p, c->cw.data(), c->cw.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return D2D_OK;
+}
+
+d2d::ObjTables obj_tables(d2d_ctx* c) {
+    d2d::ObjTables T;
+    T.occl = c->d_occl.p;
+    T.refl = c->d_refl.p;
+    T.kind = c->d_kind.p;
+    T.sincos = c->d_sincos.p;
+    T.N = c->N;
+    return T;
+}
+
+// optax.adam(0.1) defaults (optimize.py:83): b1 = 0.9, b2 = 0.999, eps = 1e-8; bias corrections 1 - b^t tabulated
+// in double precision and rounded to fp32 (the oracle does the same).
+int adam_cfg(d2d_ctx* c, const d2d_params* p, d2d::AdamCfg* A) {
+    const int steps = p->steps;
+    if (steps < 0 || steps > 1000000) return fail(D2D_ERR_INVALID, "steps must lie in 0..1e6, got %d", steps);
+    if (c->bc_steps != steps) {
+        std::vector<float> b1((size_t)steps + 1), b2((size_t)steps + 1);
+        for (int t = 1; t <= steps; ++t) {
+            b1[(size_t)t - 1] = (float)(1.0 - std::pow(0.9, (double)t));
+            b2[(size_t)t - 1] = (float)(1.0 - std::pow(0.999, (double)t));
+        }
+        int rc;
+        if ((rc = c->d_bc1.ensure((size_t)steps + 1)) || (rc = c->d_bc2.ensure((size_t)steps + 1))) return rc;
+        if (steps > 0) {
+            HIP_TRY(hipMemcpyAsync(c->d_bc1.p, b1.data(), (size_t)steps * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_bc2.p, b2.data(), (size_t)steps * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        c->bc_steps = steps;
+    }
+    A->solver = p->solver;
+    A->steps = steps;
+    A->bc1 = c->d_bc1.p;
+    A->bc2 = c->d_bc2.p;
+    A->lr = 0.1f;
+    A->b1 = 0.9f;
+    A->b2 = 0.999f;
+    A->eps = 1e-8f;
     return D2D_OK;
 }
 
@@ -322,7 +370,8 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_flt.release();
     c->d_cw.release();
     c->d_kind.release();
-    c->d_phi.release();
+    c->d_sincos.release();
+    c->d_bc1.release(); c->d_bc2.release(); c->d_theta0.release(); c->d_scand.release(); c->d_sorder.release();
     c->d_tcand.release(); c->d_torder.release(); c->d_ttx.release(); c->d_trx.release();
     c->d_txys_in.release(); c->d_tloss_in.release(); c->d_txys.release(); c->d_tloss.release();
     c->d_tvalid.release(); c->d_ton.release(); c->d_thit.release(); c->d_tlen.release();
@@ -469,13 +518,70 @@ int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t 
     return D2D_OK;
 }
 
+// MinPath / FermatPath sweep: explicit candidate list (these sweeps have few candidates), theta0 per candidate.
+static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx) {
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = upload_occl(c, p->patch))) return rc;
+    int64_t C = 0;
+    if ((rc = d2d_count_candidates(c->N, c->allowed.data(), p->min_order, p->max_order, &C))) return rc;
+    if (C > (1 << 22)) return fail(D2D_ERR_UNSUPPORTED, "%lld candidates are too many for an optimiser-based sweep", (long long)C);
+    std::vector<int32_t> cand((size_t)C * D2D_MAX_ORDER + 1), order((size_t)C + 1);
+    if ((rc = d2d_enumerate_candidates(c->N, c->allowed.data(), p->min_order, p->max_order, cand.data(), order.data(), C))) return rc;
+    bool need_theta = false;
+    for (int64_t i = 0; i < C; ++i)
+        for (int q = 0; q < order[(size_t)i]; ++q)
+            if (c->kind[cand[(size_t)i * D2D_MAX_ORDER + q]] != D2D_VERTEX) need_theta = true;
+    if (need_theta && (int64_t)c->theta0.size() != C * D2D_MAX_ORDER)
+        return fail(D2D_ERR_STATE, "d2d_set_theta0 must provide %lld x %d initial guesses for this sweep (got %zu values)",
+                    (long long)C, D2D_MAX_ORDER, c->theta0.size());
+    std::vector<float> th((size_t)C * D2D_MAX_ORDER + 1, 0.0f);
+    if ((int64_t)c->theta0.size() == C * D2D_MAX_ORDER) std::copy(c->theta0.begin(), c->theta0.end(), th.begin());
+    if ((rc = c->d_scand.ensure(cand.size())) || (rc = c->d_sorder.ensure(order.size())) || (rc = c->d_theta0.ensure(th.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_scand.p, cand.data(), cand.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_sorder.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_theta0.p, th.data(), th.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
+    d2d::OptSweepArgs a;
+    memset(&a, 0, sizeof a);
+    a.T = obj_tables(c);
+    if ((rc = adam_cfg(c, p, &a.A))) return rc;
+    a.cand = c->d_scand.p;
+    a.order = c->d_sorder.p;
+    a.theta0 = c->d_theta0.p;
+    a.C = (int)C;
+    a.X = c->d_X.p;
+    a.Y = c->d_Y.p;
+    a.out = c->d_out.p;
+    a.cells = (long)c->m * c->n;
+    a.txx = tx[0];
+    a.txy = tx[1];
+    a.mode = p->approx ? (p->act == D2D_ACT_HARD_SIGMOID ? d2d::MODE_HSIG : d2d::MODE_SIG) : d2d::MODE_HARD;
+    a.alpha = p->alpha;
+    a.tol = p->tol;
+    a.seg_lo = -p->seg_tol;
+    a.seg_hi = 1.0f + p->seg_tol;
+    for (int k = 0; k <= D2D_MAX_ORDER; ++k) a.fnum[k] = integer_pow(p->r_coef, k);
+    a.h2 = p->height * p->height;
+    a.fun_id = p->fun_id;
+    a.out_mode = p->out_mode;
+    const unsigned blocks = (unsigned)((a.cells + 63) / 64);
+    hipLaunchKernelGGL(d2d::power_opt_kernel, dim3(blocks), dim3(64), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    return D2D_OK;
+}
+
 static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsigned long long* d_stats, int grad_mode = 0) {
     if (!c || !tx) return fail(D2D_ERR_INVALID, "NULL argument");
     int rc = check_params(p);
     if (rc) return rc;
     if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come before a sweep");
     if (!c->have_grid) return fail(D2D_ERR_STATE, "d2d_set_grid must come before a sweep");
-    if (p->solver != D2D_SOLVER_IMAGE) return fail(D2D_ERR_UNSUPPORTED, "solver %d is not available in this build", p->solver);
+    if (p->solver == D2D_SOLVER_MINPATH || p->solver == D2D_SOLVER_FERMAT) {
+        if (d_stats || grad_mode) return fail(D2D_ERR_UNSUPPORTED, "the optimiser-based solvers have no stats / gradient kernels");
+        return opt_sweep_launch(c, p, tx);
+    }
+    if (p->solver != D2D_SOLVER_IMAGE) return fail(D2D_ERR_INVALID, "unknown solver %d", p->solver);
     if (p->max_order >= 1)
         for (int j = 0; j < c->N; ++j)
             if (c->allowed[j] && c->kind[j] != D2D_WALL)
@@ -682,22 +788,32 @@ int d2d_power_map_stats(d2d_ctx* c, const d2d_params* p, const float* tx, uint64
     return D2D_OK;
 }
 
+int d2d_set_theta0(d2d_ctx* c, const float* theta0, int64_t n_candidates) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (n_candidates < 0 || (n_candidates > 0 && !theta0)) return fail(D2D_ERR_INVALID, "bad theta0 arguments");
+    c->theta0.assign(theta0, theta0 + n_candidates * D2D_MAX_ORDER);
+    return D2D_OK;
+}
+
 int d2d_trace_paths(d2d_ctx* c, const d2d_params* p, const float* tx, const float* rx, int32_t P, const int32_t* cand,
-                    const int32_t* order, int32_t C, const float* xys_in, const float* loss_in, float* xys, float* loss,
-                    float* valid, float* on, float* hit, float* length) {
+                    const int32_t* order, int32_t C, const float* theta0, const float* xys_in, const float* loss_in, float* xys,
+                    float* loss, float* valid, float* on, float* hit, float* length) {
     if (!c || !tx || !rx || !cand || !order || !xys || !loss || !valid) return fail(D2D_ERR_INVALID, "NULL argument");
     int rc = check_params(p);
     if (rc) return rc;
     if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
     if (P < 0 || C < 0) return fail(D2D_ERR_INVALID, "negative sizes");
-    if (p->solver != D2D_SOLVER_IMAGE && !xys_in) return fail(D2D_ERR_UNSUPPORTED, "solver %d is not available in this build", p->solver);
+    const bool opt = (p->solver == D2D_SOLVER_MINPATH || p->solver == D2D_SOLVER_FERMAT) && !xys_in;
+    if (p->solver < D2D_SOLVER_IMAGE || p->solver > D2D_SOLVER_FERMAT) return fail(D2D_ERR_INVALID, "unknown solver %d", p->solver);
     for (int i = 0; i < C; ++i) {
         if (order[i] < 0 || order[i] > D2D_MAX_ORDER) return fail(D2D_ERR_INVALID, "candidate %d has order %d", i, order[i]);
         for (int q = 0; q < order[i]; ++q) {
             int w = cand[(size_t)i * D2D_MAX_ORDER + q];
             if (w < 0 || w >= c->N) return fail(D2D_ERR_INVALID, "candidate %d references object %d of %d", i, w, c->N);
-            if (!xys_in && c->kind[w] != D2D_WALL)
+            if (!xys_in && !opt && c->kind[w] != D2D_WALL)
                 return fail(D2D_ERR_UNSUPPORTED, "ImagePath needs Wall objects; object %d has kind %d", w, (int)c->kind[w]);
+            if (opt && !theta0 && c->kind[w] != D2D_VERTEX)
+                return fail(D2D_ERR_INVALID, "theta0 is required by the optimiser-based solvers");
         }
     }
     const size_t n = (size_t)P * (size_t)C;
@@ -729,11 +845,15 @@ int d2d_trace_paths(d2d_ctx* c, const d2d_params* p, const float* tx, const floa
     }
     d2d::TraceArgs a;
     memset(&a, 0, sizeof a);
-    a.occl = c->d_occl.p;
-    a.refl = c->d_refl.p;
-    a.kind = c->d_kind.p;
-    a.phi = c->d_phi.p;
-    a.N = c->N;
+    a.T = obj_tables(c);
+    a.solver = p->solver;
+    if (opt) {
+        if ((rc = adam_cfg(c, p, &a.A))) return rc;
+        if ((rc = c->d_theta0.ensure((size_t)C * D2D_MAX_ORDER + 1))) return rc;
+        if (theta0) HIP_TRY(hipMemcpyAsync(c->d_theta0.p, theta0, (size_t)C * D2D_MAX_ORDER * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        else HIP_TRY(hipMemsetAsync(c->d_theta0.p, 0, (size_t)C * D2D_MAX_ORDER * sizeof(float), c->stream));
+        a.theta0 = c->d_theta0.p;
+    }
     a.cand = c->d_tcand.p;
     a.order = c->d_torder.p;
     a.C = C;

@@ -1084,42 +1084,23 @@ __global__ void __launch_bounds__(256) vjp_reduce_kernel(const float* __restrict
 }  // namespace d2d
 
 // =====================================================================================
-// Path tracing kernel ("emit paths"): one thread per (tx/rx pair, candidate); writes the
-// interaction points, the loss and the validity of every candidate.  Serves
-// Scene.all_paths / all_valid_paths / accumulate_over_paths (scene.py:1156-1334),
-// ImagePath.from_tx_objects_rx (geometry.py:1013-1114) and Path.is_valid / on_objects /
-// intersects_with_objects (geometry.py:821-963) of the host mirror.  Small problem sizes:
+// Generic (any object kind, any solver) literal evaluation: used by the path tracing kernel
+// ("emit paths") and by the optimiser-based sweeps (MinPath / FermatPath).  Small problem sizes:
 // written literally (every activation evaluated, NaN-propagating min/max), no skipping.
 // =====================================================================================
 namespace d2d {
 
-struct TraceArgs {
-    const float4* __restrict__ occl;
-    const float4* __restrict__ refl;
-    const unsigned char* __restrict__ kind;  // [N] D2D_WALL / D2D_RIS / D2D_VERTEX
-    const float* __restrict__ phi;           // [N]
-    int N;
-    const int* __restrict__ cand;   // [C][D2D_MAX_ORDER]
-    const int* __restrict__ order;  // [C]
-    int C;
-    const float* __restrict__ tx;  // [P][2]
-    const float* __restrict__ rx;  // [P][2]
-    int P;
-    const float* __restrict__ xys_in;   // [P][C][D2D_MAX_ORDER+2][2] or null: validate these paths instead of solving
-    const float* __restrict__ loss_in;  // [P][C] or null
-    float* __restrict__ xys;    // [P][C][D2D_MAX_ORDER+2][2]
-    float* __restrict__ loss;   // [P][C]
-    float* __restrict__ valid;  // [P][C]   final is_valid
-    float* __restrict__ on;     // [P][C]   on_objects            (may be null)
-    float* __restrict__ hit;    // [P][C]   intersects_with_objects (may be null)
-    float* __restrict__ length; // [P][C]   path_length           (may be null)
-    int mode;  // MODE_*
-    float alpha, tol, seg_lo, seg_hi;
-};
-
 // NaN-propagating min / max (jnp.minimum / jnp.maximum)
 __device__ __forceinline__ float minp(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : (a < b ? a : b); }
 __device__ __forceinline__ float maxp(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : (a > b ? a : b); }
+
+struct ObjTables {
+    const float4* __restrict__ occl;         // [N] {P1x, P1y, Ax, Ay}
+    const float4* __restrict__ refl;         // [2N] {ox, oy, nx, ny}, {tx, ty, sq, |t|}
+    const unsigned char* __restrict__ kind;  // [N] D2D_WALL / D2D_RIS / D2D_VERTEX
+    const float2* __restrict__ sincos;       // [N] {sin(phi), cos(phi)} (RIS)
+    int N;
+};
 
 struct Truth {
     int mode;
@@ -1137,81 +1118,19 @@ struct Truth {
     __device__ float lt(float x, float y) const { return mode ? act(y - x) : (x < y ? 1.0f : 0.0f); }
 };
 
-__global__ void __launch_bounds__(64) trace_kernel(TraceArgs a) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (long)a.P * a.C) return;
-    const int p = (int)(tid / a.C), c = (int)(tid % a.C);
-    const int k = a.order[c];
-    int cd[D2D_MAX_ORDER];
-#pragma unroll
-    for (int i = 0; i < D2D_MAX_ORDER; ++i) cd[i] = a.cand[c * D2D_MAX_ORDER + i];
-    constexpr int NP = D2D_MAX_ORDER + 2;
-    float px[NP], py[NP];
-    const float txx = a.tx[2 * p], txy = a.tx[2 * p + 1], rxx = a.rx[2 * p], rxy = a.rx[2 * p + 1];
-    const Truth T{a.mode, a.alpha};
-    float loss = 0.0f;
+constexpr int NP = D2D_MAX_ORDER + 2;
 
-    if (a.xys_in) {
+// sum_k obj_k.evaluate_cartesian(P[k:k+3]): Wall geometry.py:641-650, RIS :698-711, Vertex :416-419
+__device__ __forceinline__ float interaction_loss(const ObjTables& T, int k, const int (&cd)[D2D_MAX_ORDER], const float (&px)[NP],
+                                                  const float (&py)[NP]) {
+    float loss = 0.0f;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            px[i] = a.xys_in[(tid * NP + i) * 2];
-            py[i] = a.xys_in[(tid * NP + i) * 2 + 1];
-        }
-        loss = a.loss_in ? a.loss_in[tid] : 0.0f;
-    } else {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) px[i] = py[i] = __builtin_nanf("");
-        px[0] = txx;
-        py[0] = txy;
-        // forward images, geometry.py:1086-1091
-        float imx[D2D_MAX_ORDER], imy[D2D_MAX_ORDER];
-        float ix = txx, iy = txy;
-#pragma unroll
-        for (int i = 0; i < D2D_MAX_ORDER; ++i) {
-            if (i < k) {
-                float ox, oy;
-                image_of(a.refl[2 * cd[i]], ix, iy, ox, oy);
-                ix = ox;
-                iy = oy;
-                imx[i] = ix;
-                imy[i] = iy;
-            }
-        }
-        // backward scan, geometry.py:1093-1110
-        float ptx = rxx, pty = rxy;
-#pragma unroll
-        for (int i = D2D_MAX_ORDER - 1; i >= 0; --i) {
-            if (i < k) {
-                const float4 r0 = a.refl[2 * cd[i]];
-                float ux = ptx - imx[i], uy = pty - imy[i];
-                float vx = r0.x - ptx, vy = r0.y - pty;
-                float un = ux * r0.z + uy * r0.w;
-                float vn = vx * r0.z + vy * r0.w;
-                bool z = (un == 0.0f);
-                float den = z ? 1.0f : un;
-                float incx = z ? 0.0f : (vn * ux) / den;
-                float incy = z ? 0.0f : (vn * uy) / den;
-                ptx = ptx + incx;
-                pty = pty + incy;
-#pragma unroll
-                for (int q = 0; q < NP; ++q)
-                    if (q == i + 1) {
-                        px[q] = ptx;
-                        py[q] = pty;
-                    }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NP; ++q)
-            if (q == k + 1) {
-                px[q] = rxx;
-                py[q] = rxy;
-            }
-        // path loss, geometry.py:1077-1084
-#pragma unroll
-        for (int i = 0; i < D2D_MAX_ORDER; ++i) {
-            if (i < k) {
-                const float4 r0 = a.refl[2 * cd[i]];
+    for (int i = 0; i < D2D_MAX_ORDER; ++i) {
+        if (i < k) {
+            const int kd = T.kind[cd[i]];
+            const float4 r0 = T.refl[2 * cd[i]];
+            float ev = 0.0f;
+            if (kd == D2D_WALL) {
                 float ix_, iy_, rx_, ry_;
                 normalize2(px[i + 1] - px[i], py[i + 1] - py[i], ix_, iy_);
                 normalize2(px[i + 2] - px[i + 1], py[i + 2] - py[i + 1], rx_, ry_);
@@ -1219,58 +1138,25 @@ __global__ void __launch_bounds__(64) trace_kernel(TraceArgs a) {
                 float s2 = 2.0f * din;
                 float ex = rx_ - (ix_ - s2 * r0.z);
                 float ey = ry_ - (iy_ - s2 * r0.w);
-                loss = loss + (ex * ex + ey * ey);
+                ev = ex * ex + ey * ey;
+            } else if (kd == D2D_RIS) {
+                float rx_, ry_;
+                normalize2(px[i + 2] - px[i + 1], py[i + 2] - py[i + 1], rx_, ry_);
+                float mx = -rx_, my = -ry_;
+                float sin_a = mx * r0.w - my * r0.z;
+                float cos_a = mx * r0.z + my * r0.w;
+                const float2 sc = T.sincos[cd[i]];
+                float ds = sin_a - sc.x, dc = cos_a - sc.y;
+                ev = ds * ds + dc * dc;
             }
+            loss = loss + ev;
         }
     }
+    return loss;
+}
 
-    // on_objects, geometry.py:821-854
-    float on = 1.0f;
-#pragma unroll
-    for (int i = 0; i < D2D_MAX_ORDER; ++i) {
-        if (i < k) {
-            float cval;
-            if (a.kind[cd[i]] == D2D_VERTEX) {
-                cval = 1.0f;  // geometry.py:397-403
-            } else {
-                const float4 r0 = a.refl[2 * cd[i]];
-                const float4 r1 = a.refl[2 * cd[i] + 1];
-                float dx = px[i + 1] - r0.x, dy = py[i + 1] - r0.y;
-                float s = (r1.x * dx + r1.y * dy) / r1.z;
-                cval = T.t_and(T.ge(s, 0.0f), T.le(s, 1.0f));
-            }
-            on = T.t_and(on, cval);
-        }
-    }
-    // intersects_with_objects, geometry.py:856-906
-    float hit = 0.0f;
-#pragma unroll
-    for (int i = 0; i <= D2D_MAX_ORDER; ++i) {
-        if (i <= k) {
-            const int ig0 = (i == 0) ? -1 : cd[i - 1];
-            const int ig1 = (i == k) ? -1 : cd[i < D2D_MAX_ORDER ? i : 0];
-            const float bx = px[i] - px[i + 1], by = py[i] - py[i + 1];
-            for (int j = 0; j < a.N; ++j) {
-                if (j == ig0 || j == ig1) continue;
-                if (a.kind[j] == D2D_VERTEX) continue;  // geometry.py:407-414: false_value, or() leaves hit unchanged
-                const float4 w = a.occl[j];
-                float Cx = w.x - px[i], Cy = w.y - py[i];
-                float fa = by * Cx - bx * Cy;
-                float fb = w.z * Cy - w.w * Cx;
-                float fd = w.w * bx - w.z * by;
-                bool dz = (fd == 0.0f);
-                float dd = dz ? 1.0f : fd;
-                float ta = dz ? __builtin_inff() : fa / dd;
-                float tb = dz ? __builtin_inff() : fb / dd;
-                float h = T.t_and(T.t_and(T.ge(ta, a.seg_lo), T.le(ta, a.seg_hi)), T.t_and(T.ge(tb, a.seg_lo), T.le(tb, a.seg_hi)));
-                hit = T.t_or(hit, h);
-            }
-        }
-    }
-    float ok = T.lt(loss, a.tol);
-    float valid = T.t_and(T.t_and(on, T.t_not(hit)), ok);
-    if (valid != valid) valid = 0.0f;  // jnp.nan_to_num
-    // path length, geometry.py:176-203
+// path_length, geometry.py:176-203
+__device__ __forceinline__ float literal_length(int k, const float (&px)[NP], const float (&py)[NP]) {
     float r = 0.0f;
 #pragma unroll
     for (int i = 0; i <= D2D_MAX_ORDER; ++i) {
@@ -1280,6 +1166,338 @@ __global__ void __launch_bounds__(64) trace_kernel(TraceArgs a) {
             r = r + sqrtf(vx * vx + vy * vy);
         }
     }
+    return r;
+}
+
+// on_objects / intersects_with_objects / is_valid, geometry.py:821-963, for any mix of object kinds
+__device__ __forceinline__ void literal_validity(const ObjTables& T, const Truth& L, int k, const int (&cd)[D2D_MAX_ORDER],
+                                                 const float (&px)[NP], const float (&py)[NP], float loss, float tol,
+                                                 float seg_lo, float seg_hi, float& on, float& hit, float& valid) {
+    on = 1.0f;
+#pragma unroll
+    for (int i = 0; i < D2D_MAX_ORDER; ++i) {
+        if (i < k) {
+            float cval;
+            if (T.kind[cd[i]] == D2D_VERTEX) {
+                cval = 1.0f;  // geometry.py:397-403
+            } else {
+                const float4 r0 = T.refl[2 * cd[i]];
+                const float4 r1 = T.refl[2 * cd[i] + 1];
+                float dx = px[i + 1] - r0.x, dy = py[i + 1] - r0.y;
+                float s = (r1.x * dx + r1.y * dy) / r1.z;
+                cval = L.t_and(L.ge(s, 0.0f), L.le(s, 1.0f));
+            }
+            on = L.t_and(on, cval);
+        }
+    }
+    hit = 0.0f;
+#pragma unroll
+    for (int i = 0; i <= D2D_MAX_ORDER; ++i) {
+        if (i <= k) {
+            const int ig0 = (i == 0) ? -1 : cd[i - 1];
+            const int ig1 = (i == k) ? -1 : cd[i < D2D_MAX_ORDER ? i : 0];
+            const float bx = px[i] - px[i + 1], by = py[i] - py[i + 1];
+            for (int j = 0; j < T.N; ++j) {
+                if (j == ig0 || j == ig1) continue;
+                if (T.kind[j] == D2D_VERTEX) continue;  // geometry.py:407-414: false_value; or() leaves hit unchanged
+                const float4 w = T.occl[j];
+                float Cx = w.x - px[i], Cy = w.y - py[i];
+                float fa = by * Cx - bx * Cy;
+                float fb = w.z * Cy - w.w * Cx;
+                float fd = w.w * bx - w.z * by;
+                bool dz = (fd == 0.0f);
+                float dd = dz ? 1.0f : fd;
+                float ta = dz ? __builtin_inff() : fa / dd;
+                float tb = dz ? __builtin_inff() : fb / dd;
+                float h = L.t_and(L.t_and(L.ge(ta, seg_lo), L.le(ta, seg_hi)), L.t_and(L.ge(tb, seg_lo), L.le(tb, seg_hi)));
+                hit = L.t_or(hit, h);
+            }
+        }
+    }
+    float ok = L.lt(loss, tol);
+    valid = L.t_and(L.t_and(on, L.t_not(hit)), ok);
+    if (valid != valid) valid = 0.0f;  // jnp.nan_to_num
+}
+
+// ---- image method with runtime order (geometry.py:1013-1114) ----------------------------------------
+__device__ __forceinline__ void image_solve(const ObjTables& T, int k, const int (&cd)[D2D_MAX_ORDER], float txx, float txy,
+                                            float rxx, float rxy, float (&px)[NP], float (&py)[NP]) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) px[i] = py[i] = __builtin_nanf("");
+    px[0] = txx;
+    py[0] = txy;
+    float imx[D2D_MAX_ORDER], imy[D2D_MAX_ORDER];
+    float ix = txx, iy = txy;
+#pragma unroll
+    for (int i = 0; i < D2D_MAX_ORDER; ++i) {
+        if (i < k) {
+            float ox, oy;
+            image_of(T.refl[2 * cd[i]], ix, iy, ox, oy);
+            ix = ox;
+            iy = oy;
+            imx[i] = ix;
+            imy[i] = iy;
+        }
+    }
+    float ptx = rxx, pty = rxy;
+#pragma unroll
+    for (int i = D2D_MAX_ORDER - 1; i >= 0; --i) {
+        if (i < k) {
+            const float4 r0 = T.refl[2 * cd[i]];
+            float ux = ptx - imx[i], uy = pty - imy[i];
+            float vx = r0.x - ptx, vy = r0.y - pty;
+            float un = ux * r0.z + uy * r0.w;
+            float vn = vx * r0.z + vy * r0.w;
+            bool z = (un == 0.0f);
+            float den = z ? 1.0f : un;
+            float incx = z ? 0.0f : (vn * ux) / den;
+            float incy = z ? 0.0f : (vn * uy) / den;
+            ptx = ptx + incx;
+            pty = pty + incy;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                if (q == i + 1) {
+                    px[q] = ptx;
+                    py[q] = pty;
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+        if (q == k + 1) {
+            px[q] = rxx;
+            py[q] = rxy;
+        }
+}
+
+// ---- MinPath / FermatPath: Adam on the parametric coordinates ------------------------------------------
+// geometry.py:1117-1288, optimize.py:44-97 with optax.adam(0.1): mu = b1 mu + (1-b1) g; nu = b2 nu + (1-b2) g^2;
+// x += -lr * (mu / (1 - b1^t)) / (sqrt(nu / (1 - b2^t)) + eps).  The gradient of the objective w.r.t. theta is
+// derived by hand (reverse mode through parametric_to_cartesian and evaluate_cartesian / path_length).
+struct AdamCfg {
+    int solver;  // D2D_SOLVER_MINPATH or D2D_SOLVER_FERMAT
+    int steps;
+    const float* __restrict__ bc1;  // [steps] 1 - b1^t
+    const float* __restrict__ bc2;  // [steps] 1 - b2^t
+    float lr, b1, b2, eps;
+};
+
+__device__ __forceinline__ void theta_to_points(const ObjTables& T, int k, const int (&cd)[D2D_MAX_ORDER],
+                                                const float (&theta)[D2D_MAX_ORDER], float txx, float txy, float rxx, float rxy,
+                                                float (&px)[NP], float (&py)[NP]) {
+    // parametric_to_cartesian, geometry.py:988-1010 / 581-587 / 381-385
+#pragma unroll
+    for (int i = 0; i < NP; ++i) px[i] = py[i] = __builtin_nanf("");
+    px[0] = txx;
+    py[0] = txy;
+    int j = 0;
+#pragma unroll
+    for (int i = 0; i < D2D_MAX_ORDER; ++i) {
+        if (i < k) {
+            const float4 r0 = T.refl[2 * cd[i]];
+            const float4 r1 = T.refl[2 * cd[i] + 1];
+            float x = r0.x, y = r0.y;  // Vertex: both rows hold the point, t = 0
+            if (T.kind[cd[i]] != D2D_VERTEX) {
+                float th = 0.0f;
+#pragma unroll
+                for (int q = 0; q < D2D_MAX_ORDER; ++q)
+                    if (q == j) th = theta[q];
+                x = r0.x + th * r1.x;
+                y = r0.y + th * r1.y;
+                ++j;
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                if (q == i + 1) {
+                    px[q] = x;
+                    py[q] = y;
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+        if (q == k + 1) {
+            px[q] = rxx;
+            py[q] = rxy;
+        }
+}
+
+// objective and its gradient w.r.t. the interaction points (pbx, pby), then w.r.t. theta
+__device__ __forceinline__ float objective_grad(const ObjTables& T, int solver, int k, const int (&cd)[D2D_MAX_ORDER],
+                                                const float (&px)[NP], const float (&py)[NP], float (&gth)[D2D_MAX_ORDER]) {
+    float pbx[NP], pby[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pbx[i] = pby[i] = 0.0f;
+    float loss = 0.0f;
+    if (solver == D2D_SOLVER_FERMAT) {
+#pragma unroll
+        for (int i = 0; i <= D2D_MAX_ORDER; ++i) {
+            if (i <= k) {
+                float wx = (px[i + 1] - px[i]) + D2D_EPS, wy = (py[i + 1] - py[i]) + D2D_EPS;
+                float len = sqrtf(wx * wx + wy * wy);
+                loss = loss + len;
+                float gx = wx / len, gy = wy / len;
+                pbx[i + 1] += gx; pby[i + 1] += gy;
+                pbx[i] -= gx; pby[i] -= gy;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < D2D_MAX_ORDER; ++i) {
+            if (i < k) {
+                const int kd = T.kind[cd[i]];
+                const float4 r0 = T.refl[2 * cd[i]];
+                float ev = 0.0f;
+                if (kd == D2D_WALL) {
+                    float v1x = px[i + 1] - px[i], v1y = py[i + 1] - py[i];
+                    float v2x = px[i + 2] - px[i + 1], v2y = py[i + 2] - py[i + 1];
+                    float ix_, iy_, rx_, ry_;
+                    normalize2(v1x, v1y, ix_, iy_);
+                    normalize2(v2x, v2y, rx_, ry_);
+                    float din = ix_ * r0.z + iy_ * r0.w;
+                    float s2 = 2.0f * din;
+                    float ex = rx_ - (ix_ - s2 * r0.z);
+                    float ey = ry_ - (iy_ - s2 * r0.w);
+                    ev = ex * ex + ey * ey;
+                    float ebx = 2.0f * ex, eby = 2.0f * ey;
+                    float dinb = 2.0f * (ebx * r0.z + eby * r0.w);
+                    float ibx = -ebx + dinb * r0.z, iby = -eby + dinb * r0.w;
+                    float a1x, a1y, a2x, a2y;
+                    normalize2_bwd(v1x, v1y, ibx, iby, a1x, a1y);
+                    normalize2_bwd(v2x, v2y, ebx, eby, a2x, a2y);
+                    pbx[i + 1] += a1x - a2x; pby[i + 1] += a1y - a2y;
+                    pbx[i] -= a1x; pby[i] -= a1y;
+                    pbx[i + 2] += a2x; pby[i + 2] += a2y;
+                } else if (kd == D2D_RIS) {
+                    float v2x = px[i + 2] - px[i + 1], v2y = py[i + 2] - py[i + 1];
+                    float rx_, ry_;
+                    normalize2(v2x, v2y, rx_, ry_);
+                    float mx = -rx_, my = -ry_;
+                    float sin_a = mx * r0.w - my * r0.z;
+                    float cos_a = mx * r0.z + my * r0.w;
+                    const float2 sc = T.sincos[cd[i]];
+                    float ds = sin_a - sc.x, dc = cos_a - sc.y;
+                    ev = ds * ds + dc * dc;
+                    float sb = 2.0f * ds, cb = 2.0f * dc;
+                    float mbx = sb * r0.w + cb * r0.z, mby = -sb * r0.z + cb * r0.w;
+                    float a2x, a2y;
+                    normalize2_bwd(v2x, v2y, -mbx, -mby, a2x, a2y);
+                    pbx[i + 2] += a2x; pby[i + 2] += a2y;
+                    pbx[i + 1] -= a2x; pby[i + 1] -= a2y;
+                }
+                loss = loss + ev;
+            }
+        }
+    }
+    // d/d theta_j = t_j . pbar_j
+    int j = 0;
+#pragma unroll
+    for (int q = 0; q < D2D_MAX_ORDER; ++q) gth[q] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D2D_MAX_ORDER; ++i) {
+        if (i < k && T.kind[cd[i]] != D2D_VERTEX) {
+            const float4 r1 = T.refl[2 * cd[i] + 1];
+            float gval = r1.x * pbx[i + 1] + r1.y * pby[i + 1];
+#pragma unroll
+            for (int q = 0; q < D2D_MAX_ORDER; ++q)
+                if (q == j) gth[q] = gval;
+            ++j;
+        }
+    }
+    return loss;
+}
+
+// Returns the path points and the loss the reference attaches to the path.
+__device__ __forceinline__ float opt_solve(const ObjTables& T, const AdamCfg& A, int k, const int (&cd)[D2D_MAX_ORDER],
+                                           const float (&theta0)[D2D_MAX_ORDER], float txx, float txy, float rxx, float rxy,
+                                           float (&px)[NP], float (&py)[NP]) {
+    float th[D2D_MAX_ORDER], mu[D2D_MAX_ORDER], nu[D2D_MAX_ORDER], g[D2D_MAX_ORDER];
+    int nu_ = 0;
+#pragma unroll
+    for (int i = 0; i < D2D_MAX_ORDER; ++i) {
+        th[i] = theta0[i];
+        mu[i] = nu[i] = 0.0f;
+        if (i < k && T.kind[cd[i]] != D2D_VERTEX) ++nu_;
+    }
+    float last = 0.0f;
+    for (int t = 0; t < A.steps; ++t) {
+        theta_to_points(T, k, cd, th, txx, txy, rxx, rxy, px, py);
+        last = objective_grad(T, A.solver, k, cd, px, py, g);
+        const float c1 = A.bc1[t], c2 = A.bc2[t];
+#pragma unroll
+        for (int q = 0; q < D2D_MAX_ORDER; ++q) {
+            if (q < nu_) {
+                mu[q] = A.b1 * mu[q] + (1.0f - A.b1) * g[q];
+                nu[q] = A.b2 * nu[q] + (1.0f - A.b2) * (g[q] * g[q]);
+                float mh = mu[q] / c1, nh = nu[q] / c2;
+                th[q] = th[q] + (-A.lr) * (mh / (sqrtf(nh) + A.eps));
+            }
+        }
+    }
+    theta_to_points(T, k, cd, th, txx, txy, rxx, rxy, px, py);
+    if (A.solver == D2D_SOLVER_FERMAT) return interaction_loss(T, k, cd, px, py);  // geometry.py:1204
+    return last;                                                                    // geometry.py:1284-1288
+}
+
+struct TraceArgs {
+    ObjTables T;
+    AdamCfg A;
+    int solver;
+    const int* __restrict__ cand;   // [C][D2D_MAX_ORDER]
+    const int* __restrict__ order;  // [C]
+    const float* __restrict__ theta0;  // [C][D2D_MAX_ORDER] initial guesses of the optimiser solvers, or null
+    int C;
+    const float* __restrict__ tx;  // [P][2]
+    const float* __restrict__ rx;  // [P][2]
+    int P;
+    const float* __restrict__ xys_in;   // [P][C][NP][2] or null: validate these paths instead of solving
+    const float* __restrict__ loss_in;  // [P][C] or null
+    float* __restrict__ xys;    // [P][C][NP][2]
+    float* __restrict__ loss;   // [P][C]
+    float* __restrict__ valid;  // [P][C]   final is_valid
+    float* __restrict__ on;     // [P][C]   on_objects            (may be null)
+    float* __restrict__ hit;    // [P][C]   intersects_with_objects (may be null)
+    float* __restrict__ length; // [P][C]   path_length           (may be null)
+    int mode;  // MODE_*
+    float alpha, tol, seg_lo, seg_hi;
+};
+
+// One thread per (tx/rx pair, candidate).  Serves Scene.all_paths / all_valid_paths / accumulate_over_paths
+// (scene.py:1156-1334), {Image,Min,Fermat}Path.from_tx_objects_rx and Path.is_valid / on_objects /
+// intersects_with_objects (geometry.py:821-963) of the host mirror.
+__global__ void __launch_bounds__(64) trace_kernel(TraceArgs a) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (long)a.P * a.C) return;
+    const int p = (int)(tid / a.C), c = (int)(tid % a.C);
+    const int k = a.order[c];
+    int cd[D2D_MAX_ORDER];
+#pragma unroll
+    for (int i = 0; i < D2D_MAX_ORDER; ++i) cd[i] = a.cand[c * D2D_MAX_ORDER + i];
+    float px[NP], py[NP];
+    const float txx = a.tx[2 * p], txy = a.tx[2 * p + 1], rxx = a.rx[2 * p], rxy = a.rx[2 * p + 1];
+    const Truth L{a.mode, a.alpha};
+    float loss = 0.0f;
+    if (a.xys_in) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            px[i] = a.xys_in[(tid * NP + i) * 2];
+            py[i] = a.xys_in[(tid * NP + i) * 2 + 1];
+        }
+        loss = a.loss_in ? a.loss_in[tid] : 0.0f;
+    } else if (a.solver == D2D_SOLVER_IMAGE) {
+        image_solve(a.T, k, cd, txx, txy, rxx, rxy, px, py);
+        loss = interaction_loss(a.T, k, cd, px, py);
+    } else if (k == 0) {
+        image_solve(a.T, 0, cd, txx, txy, rxx, rxy, px, py);  // geometry.py:1178-1180 / 1268-1270
+    } else {
+        float th0[D2D_MAX_ORDER];
+#pragma unroll
+        for (int i = 0; i < D2D_MAX_ORDER; ++i) th0[i] = a.theta0[c * D2D_MAX_ORDER + i];
+        loss = opt_solve(a.T, a.A, k, cd, th0, txx, txy, rxx, rxy, px, py);
+    }
+    float on, hit, valid;
+    literal_validity(a.T, L, k, cd, px, py, loss, a.tol, a.seg_lo, a.seg_hi, on, hit, valid);
+    const float r = literal_length(k, px, py);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         a.xys[(tid * NP + i) * 2] = px[i];
@@ -1290,6 +1508,66 @@ __global__ void __launch_bounds__(64) trace_kernel(TraceArgs a) {
     if (a.on) a.on[tid] = on;
     if (a.hit) a.hit[tid] = hit;
     if (a.length) a.length[tid] = r;
+}
+
+// Grid sweep for the optimiser-based solvers: one RX cell per lane, candidates walked in the reference's order
+// (scene.py:1892-1918); theta0 is per candidate and shared by every cell, as in the reference (scene.py:1887-1890).
+struct OptSweepArgs {
+    ObjTables T;
+    AdamCfg A;
+    const int* __restrict__ cand;      // [C][D2D_MAX_ORDER]   (explicit list: these sweeps have few candidates)
+    const int* __restrict__ order;     // [C]
+    const float* __restrict__ theta0;  // [C][D2D_MAX_ORDER]
+    int C;
+    const float* __restrict__ X;
+    const float* __restrict__ Y;
+    float* __restrict__ out;
+    long cells;
+    float txx, txy;
+    int mode;
+    float alpha, tol, seg_lo, seg_hi;
+    float fnum[D2D_MAX_ORDER + 1];
+    float h2;
+    int fun_id;
+    int out_mode;
+};
+
+__global__ void __launch_bounds__(64) power_opt_kernel(OptSweepArgs a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.cells) return;
+    const float rxx = a.X[idx], rxy = a.Y[idx];
+    const Truth L{a.mode, a.alpha};
+    float acc = 0.0f;
+    for (int c = 0; c < a.C; ++c) {
+        const int k = a.order[c];
+        int cd[D2D_MAX_ORDER];
+        float th0[D2D_MAX_ORDER];
+#pragma unroll
+        for (int i = 0; i < D2D_MAX_ORDER; ++i) {
+            cd[i] = a.cand[c * D2D_MAX_ORDER + i];
+            th0[i] = a.theta0[c * D2D_MAX_ORDER + i];
+        }
+        float px[NP], py[NP];
+        float loss = 0.0f;
+        if (k == 0) image_solve(a.T, 0, cd, a.txx, a.txy, rxx, rxy, px, py);
+        else loss = opt_solve(a.T, a.A, k, cd, th0, a.txx, a.txy, rxx, rxy, px, py);
+        float on, hit, valid;
+        literal_validity(a.T, L, k, cd, px, py, loss, a.tol, a.seg_lo, a.seg_hi, on, hit, valid);
+        const float r = literal_length(k, px, py);
+        float f;
+        if (a.fun_id == D2D_FUN_RECEIVED_POWER) {
+            float num = a.fnum[0];
+#pragma unroll
+            for (int q = 1; q <= D2D_MAX_ORDER; ++q)
+                if (q == k) num = a.fnum[q];
+            f = num / (a.h2 + r * r);
+        } else if (a.fun_id == D2D_FUN_LENGTH_SQUARED) f = r * r;
+        else if (a.fun_id == D2D_FUN_LENGTH) f = r;
+        else f = 1.0f;
+        acc = acc + valid * f;
+    }
+    if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
+    else a.out[idx] = acc;
 }
 
 }  // namespace d2d

@@ -220,7 +220,15 @@ class Context:
         return self.get_map()
 
     # -- individual paths -------------------------------------------------------------
-    def trace_paths(self, params: L.Params, tx, rx, candidates, xys_in=None, loss_in=None):
+    def set_theta0(self, theta0):
+        """Initial guesses ``[C, <=D2D_MAX_ORDER]`` of the MinPath / FermatPath solvers for the next sweeps."""
+        t = np.zeros((len(theta0), L.D2D_MAX_ORDER), np.float32)
+        for i, row in enumerate(theta0):
+            row = np.asarray(row, np.float32).reshape(-1)
+            t[i, : row.size] = row
+        L.check(self._lib.d2d_set_theta0(self._ctx, t.ctypes.data_as(C.c_void_p) if t.size else None, t.shape[0]))
+
+    def trace_paths(self, params: L.Params, tx, rx, candidates, xys_in=None, loss_in=None, theta0=None):
         """Solves (or validates ``xys_in``) every candidate for every (tx, rx) pair on the GPU.
 
         ``tx``/``rx``: (P, 2); ``candidates``: list of int arrays. Returns a dict of arrays with leading
@@ -252,9 +260,15 @@ class Context:
             xys_in = np.ascontiguousarray(xys_in, dtype=np.float32).reshape(P, Cn, NP, 2)
         if loss_in is not None:
             loss_in = np.ascontiguousarray(loss_in, dtype=np.float32).reshape(P, Cn)
+        th = None
+        if theta0 is not None:
+            th = np.zeros((max(Cn, 1), L.D2D_MAX_ORDER), np.float32)
+            for i, row in enumerate(theta0):
+                row = np.asarray(row, np.float32).reshape(-1)
+                th[i, : row.size] = row
         L.check(
             self._lib.d2d_trace_paths(
-                self._ctx, C.byref(params), tx, rx, P, cand, order, Cn, vp(xys_in), vp(loss_in),
+                self._ctx, C.byref(params), tx, rx, P, cand, order, Cn, vp(th), vp(xys_in), vp(loss_in),
                 out["xys"].reshape(-1), out["loss"].reshape(-1), out["valid"].reshape(-1),
                 vp(out["on"]), vp(out["hit"]), vp(out["length"]),
             )

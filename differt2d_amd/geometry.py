@@ -422,21 +422,65 @@ class ImagePath(Path):
         return cls(xys=out["xys"][0, 0, : k + 2], loss=out["loss"][0, 0])
 
 
-class FermatPath(Path):
-    """Path minimising its length (reference geometry.py:1117-1204)."""
+def draw_theta0(objects_per_candidate, key, theta0=None):
+    """Initial parametric guesses, one row per candidate: ``U[0, 1)`` per unknown (reference optimize.py:132).
+
+    The reference splits ``key`` into one Threefry key per candidate (scene.py:1887-1888); JAX's PRNG is not
+    available here, so a NumPy generator seeded by ``key`` draws the rows in candidate order instead -- same
+    distribution, different numbers.  Pass ``theta0`` explicitly for reproducible comparisons."""
+    from .abc import key_to_generator
+
+    counts = [sum(o.parameters_count() for o in objs) for objs in objects_per_candidate]
+    if theta0 is not None:
+        rows = [np.asarray(r, F).reshape(-1) for r in theta0]
+        if len(rows) != len(counts) or any(r.size < c for r, c in zip(rows, counts)):
+            raise ValueError("theta0 must hold one row per candidate with at least as many values as unknowns")
+        return rows
+    if key is None:
+        raise TypeError("this path class needs a `key` (or explicit `theta0`) to draw its initial guess")
+    rng = key_to_generator(key)
+    return [rng.random(c, dtype=F) for c in counts]
+
+
+def _opt_kwargs(kwargs):
+    kw = dict(kwargs)
+    steps = int(kw.pop("steps", 100))
+    many = int(kw.pop("many", 1))
+    theta0 = kw.pop("theta0", None)
+    if many != 1:
+        raise L.D2DUnsupported(-4, "many != 1 (best of several random starts) is not implemented natively")
+    if kw.pop("optimizer", None) is not None:
+        raise L.D2DUnsupported(-4, "only the default optimiser (optax.adam(0.1)) is implemented natively")
+    if kw:
+        raise TypeError(f"unexpected keyword arguments: {sorted(kw)}")
+    return steps, theta0
+
+
+class _OptPath(Path):
+    """Shared driver of the optimiser-based solvers (GPU: d2d_trace_paths with solver != image)."""
+
+    @classmethod
+    def from_tx_objects_rx(cls, tx, objects, rx, *, key=None, **kwargs):
+        from .engine import default_context, make_params
+
+        objects = list(objects)
+        k = len(objects)
+        steps, theta0 = _opt_kwargs(kwargs)
+        th = draw_theta0([objects], key, None if theta0 is None else [theta0]) if k else [np.zeros(0, F)]
+        ctx = default_context()
+        ctx.set_scene(*objects_to_tables(objects))
+        p = make_params(max_order=L.D2D_MAX_ORDER, solver=cls.solver, steps=steps)
+        out = ctx.trace_paths(p, _xy(tx), _xy(rx), [np.arange(k, dtype=np.int32)], theta0=th)
+        return cls(xys=out["xys"][0, 0, : k + 2], loss=out["loss"][0, 0])
+
+
+class FermatPath(_OptPath):
+    """Path minimising its length (reference geometry.py:1117-1204): Adam on the parametric coordinates, on the GPU."""
 
     solver = "fermat"
 
-    @classmethod
-    def from_tx_objects_rx(cls, tx, objects, rx, *, key, **kwargs):
-        raise L.D2DUnsupported(-4, "FermatPath has no native solver yet (SURVEY.md section 8f, row 2)")
 
-
-class MinPath(Path):
-    """Path minimising the sum of interaction losses (reference geometry.py:1207-1288)."""
+class MinPath(_OptPath):
+    """Path minimising the sum of interaction losses, Min-Path-Tracing (reference geometry.py:1207-1288)."""
 
     solver = "min"
-
-    @classmethod
-    def from_tx_objects_rx(cls, tx, objects, rx, *, key, **kwargs):
-        raise L.D2DUnsupported(-4, "MinPath has no native solver in this build")

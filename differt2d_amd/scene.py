@@ -30,8 +30,8 @@ from . import logic
 from .abc import Object, Plottable, key_to_generator
 from .engine import Context, default_context, make_params
 from .geometry import (
-    FermatPath, ImagePath, MinPath, Path, Point, RIS, Vertex, Wall, _validity_kwargs, closest_point,
-    objects_to_tables, stack_leaves, unstack_leaves,
+    FermatPath, ImagePath, MinPath, Path, Point, RIS, Vertex, Wall, _opt_kwargs, _validity_kwargs, closest_point,
+    draw_theta0, objects_to_tables, stack_leaves, unstack_leaves,
 )
 
 __all__ = ("Scene", "SceneName", "PyTreeDict", "all_path_candidates")
@@ -290,16 +290,29 @@ class Scene(Plottable):
     @staticmethod
     def _solver_of(path_cls) -> str:
         solver = getattr(path_cls, "solver", None)
-        if solver != "image":
-            raise L.D2DUnsupported(-4, f"path_cls={path_cls.__name__} has no native solver in this build (ImagePath has)")
+        if solver not in ("image", "min", "fermat"):
+            raise L.D2DUnsupported(-4, f"path_cls={getattr(path_cls, '__name__', path_cls)} has no native solver "
+                                       "(ImagePath, MinPath and FermatPath have)")
         return solver
+
+    def _solver_setup(self, path_cls, path_cls_kwargs, candidates, key):
+        """(extra make_params kwargs, theta0 rows or None) for a path class."""
+        solver = self._solver_of(path_cls)
+        if solver == "image":
+            if path_cls_kwargs:
+                raise TypeError(f"ImagePath takes no path_cls_kwargs, got {sorted(path_cls_kwargs)}")
+            return dict(solver=solver), None
+        steps, theta0 = _opt_kwargs(path_cls_kwargs or {})
+        rows = draw_theta0([self.get_interacting_objects(c) for c in candidates], key, theta0)
+        return dict(solver=solver, steps=steps), rows
 
     def _trace(self, pairs_tx, pairs_rx, candidates, path_cls, path_cls_kwargs, key, validity):
         """GPU trace of every candidate for every (tx, rx) pair -> dict of arrays, leading shape (P, C)."""
         ctx = self._ctx()
         self._upload(ctx)
-        params = make_params(max_order=L.D2D_MAX_ORDER, solver=self._solver_of(path_cls), **validity)
-        return ctx.trace_paths(params, pairs_tx, pairs_rx, candidates)
+        extra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, candidates, key)
+        params = make_params(max_order=L.D2D_MAX_ORDER, **extra, **validity)
+        return ctx.trace_paths(params, pairs_tx, pairs_rx, candidates, theta0=theta0)
 
     # ------------------------------------------------------------------- individual paths
     def all_paths(self, path_cls: type = ImagePath, path_cls_kwargs: Optional[Mapping] = None, min_order: int = 0,
@@ -353,11 +366,12 @@ class Scene(Plottable):
     def _sweep_params(self, fun, fun_args, fun_kwargs, path_cls, path_cls_kwargs, min_order, max_order, order, kwargs):
         validity = _validity_kwargs(**kwargs)
         native = _native_fun(fun, fun_args, fun_kwargs)
-        common = dict(min_order=min_order, max_order=max_order, order=order, solver=self._solver_of(path_cls), **validity)
+        self._solver_of(path_cls)
+        common = dict(min_order=min_order, max_order=max_order, order=order, **validity)
         return native, common
 
     def _emit_grid(self, X, Y, fixed: Point, grid_is_rx: bool, point_cls, fun, fun_args, fun_kwargs, common,
-                   filter_objects, path_cls):
+                   filter_objects, path_cls, path_cls_kwargs=None, key=None):
         """Arbitrary Python ``fun`` on a grid: trace all (cell, candidate) on the GPU, call ``fun`` once per
         candidate on the batched paths, accumulate in candidate order (fp32)."""
         candidates = self.all_path_candidates(common["min_order"], common["max_order"], order=common.get("order"),
@@ -374,7 +388,8 @@ class Scene(Plottable):
         p = dict(common)
         p.pop("order", None)
         p["min_order"], p["max_order"] = 0, L.D2D_MAX_ORDER
-        out = ctx.trace_paths(make_params(**p), txs, rxs, candidates)
+        extra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, candidates, key)
+        out = ctx.trace_paths(make_params(**extra, **p), txs, rxs, candidates, theta0=theta0)
         acc = np.zeros(X.shape, F)
         for c, cand in enumerate(candidates):
             k = len(cand)
@@ -407,7 +422,7 @@ class Scene(Plottable):
                 raise L.D2DUnsupported(-4, "grad / value_and_grad need a natively fused fun (differt2d_amd.utils): an "
                                            "arbitrary Python callable cannot be differentiated by the hand-derived kernels")
             gen = ((name, self._emit_grid(X, Y, tx, True, receiver_cls, fun, fun_args, fun_kwargs, common, filter_objects,
-                                          path_cls)) for name, tx in txs)
+                                          path_cls, path_cls_kwargs, key)) for name, tx in txs)
             if reduce_all:
                 Z = F(0.0)
                 for _, p in gen:
@@ -417,6 +432,13 @@ class Scene(Plottable):
 
         name, extra = native
         ctx = self._ctx()
+        cands = None
+        if self._solver_of(path_cls) != "image":
+            if want_grad:
+                raise L.D2DUnsupported(-4, "grad / value_and_grad are implemented for ImagePath only")
+            cands = self.all_path_candidates(min_order, max_order, order=order, filter_objects=filter_objects)
+        sextra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, cands or [], key)
+        extra = {**extra, **sextra}
 
         def fetch():
             if value_and_grad:  # takes precedence over grad (reference scene.py:1920-1923)
@@ -427,6 +449,8 @@ class Scene(Plottable):
 
         def launch(tx, out_mode):
             params = make_params(fun=name, out_mode=out_mode, **extra, **common)
+            if theta0 is not None:
+                ctx.set_theta0(theta0)
             if want_grad:
                 ctx.launch_vg(params, tx.xy, scene_vjp=False)
             else:
@@ -464,6 +488,9 @@ class Scene(Plottable):
         native, common = self._sweep_params(fun, (), fun_kwargs, path_cls, None, min_order, max_order, order, kwargs)
         if native is None:
             raise L.D2DUnsupported(-4, "the scene VJP needs a natively fused fun (differt2d_amd.utils)")
+        if self._solver_of(path_cls) != "image":
+            raise L.D2DUnsupported(-4, "the scene VJP is implemented for ImagePath only")
+        common["solver"] = "image"
         name, extra = native
         ctx = self._ctx()
         for tx_name, tx in self.transmitters.items():
@@ -488,7 +515,7 @@ class Scene(Plottable):
             raise L.D2DUnsupported(-4, "grad / value_and_grad need the gradient kernels (not in this build)")
         _, common = self._sweep_params(fun, fun_args, fun_kwargs, path_cls, path_cls_kwargs, min_order, max_order, order, kwargs)
         gen = ((name, self._emit_grid(X, Y, rx, False, transmitter_cls, fun, fun_args, fun_kwargs, common, filter_objects,
-                                      path_cls)) for name, rx in self.receivers.items())
+                                      path_cls, path_cls_kwargs, key)) for name, rx in self.receivers.items())
         if reduce_all:
             Z = F(0.0)
             for _, p in gen:

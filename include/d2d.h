@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define D2D_MAX_ORDER 4 /* highest interaction order a sweep accepts */
-#define D2D_ABI_VERSION 1
+#define D2D_ABI_VERSION 2
 
 typedef enum d2d_status {
     D2D_OK = 0,
@@ -132,8 +132,14 @@ int d2d_list_candidates(d2d_ctx* ctx, int32_t min_order, int32_t max_order, int3
  * output maps; the value map is zeroed. */
 int d2d_set_grid(d2d_ctx* ctx, const float* X, const float* Y, int32_t m, int32_t n);
 
+/* Initial guesses of the optimiser-based solvers for the NEXT sweeps: theta0[n_candidates][D2D_MAX_ORDER], one row per
+ * candidate in enumeration order (unused entries ignored); every RX cell starts from the same guess, as in the
+ * reference (differt2d/scene.py:1887-1890, optimize.py:132). */
+int d2d_set_theta0(d2d_ctx* ctx, const float* theta0, int64_t n_candidates);
+
 /* Launches the fused forward sweep for transmitter tx[2] on the ctx stream (asynchronous).
- * Inputs and outputs stay resident in HBM. */
+ * Inputs and outputs stay resident in HBM. params->solver selects ImagePath (fused image-method kernel) or
+ * MinPath / FermatPath (per-cell Adam loop of params->steps iterations, hand-derived gradient). */
 int d2d_power_map_launch(d2d_ctx* ctx, const d2d_params* params, const float* tx);
 
 /* ---- value + gradient (replaces grad=True / value_and_grad=True of the sweep, differt2d/scene.py:1920-1923,
@@ -187,10 +193,12 @@ int d2d_power_map(d2d_ctx* ctx, const d2d_params* params, const float* tx, const
  * xys_in[P][C][D2D_MAX_ORDER+2][2] and losses loss_in[P][C] (NULL = 0)) and evaluates it against the
  * current scene. Outputs (row-major, [P][C] leading): xys[..][D2D_MAX_ORDER+2][2] (unused rows NaN),
  * loss, valid (is_valid after nan_to_num; 0/1 in hard mode), and optionally on (on_objects),
- * hit (intersects_with_objects) and length (path_length). Synchronous. */
+ * hit (intersects_with_objects) and length (path_length). theta0[C][D2D_MAX_ORDER] = initial parametric
+ * coordinates of the optimiser-based solvers (MinPath geometry.py:1207-1288, FermatPath :1117-1204; the reference
+ * draws them from a per-candidate PRNG key shared by all pairs, scene.py:1887-1890); NULL for ImagePath. Synchronous. */
 int d2d_trace_paths(d2d_ctx* ctx, const d2d_params* params, const float* tx, const float* rx, int32_t P,
-                    const int32_t* cand, const int32_t* order, int32_t C, const float* xys_in, const float* loss_in,
-                    float* xys, float* loss, float* valid, float* on, float* hit, float* length);
+                    const int32_t* cand, const int32_t* order, int32_t C, const float* theta0, const float* xys_in,
+                    const float* loss_in, float* xys, float* loss, float* valid, float* on, float* hit, float* length);
 
 /* ---- multi-GPU (one process per GPU; the reference has no multi-device code: its only batching is jax.vmap
  *      over the grid, differt2d/scene.py:1927-1932; RX rows are sharded over ranks and maps are assembled with one

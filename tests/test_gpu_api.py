@@ -228,14 +228,22 @@ def test_sweep_kwargs_and_filter_objects():
 
 def test_unsupported_is_loud():
     from differt2d_amd import _lib as L
-    from differt2d_amd.geometry import MinPath
+    from differt2d_amd.geometry import MinPath, Path
     from differt2d_amd.scene import Scene
     from differt2d_amd.utils import received_power
+
+    class MyPath(Path):  # a user-defined solver cannot run on the GPU
+        pass
 
     scene = Scene.square_scene()
     X, Y = scene.grid(n=4)
     with pytest.raises(L.D2DUnsupported):
-        scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, key=1)
+        scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MyPath, key=1)
+    with pytest.raises(L.D2DUnsupported):
+        scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, key=1, grad=True)
+    with pytest.raises(L.D2DUnsupported):
+        scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, key=1,
+                                                      path_cls_kwargs={"many": 10})
     with pytest.raises(L.D2DUnsupported):
         scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, function=lambda x, a: x, approx=True)
 
