@@ -26,6 +26,7 @@ SOLVER_IMAGE, SOLVER_MINPATH, SOLVER_FERMAT = 0, 1, 2
 ACT_HARD_SIGMOID, ACT_SIGMOID = 0, 1
 FUN_RECEIVED_POWER, FUN_LENGTH_SQUARED, FUN_LENGTH, FUN_ONE = 0, 1, 2, 3
 OUT_OVERWRITE, OUT_ADD = 0, 1
+GRID_RX, GRID_TX = 0, 1
 
 STATUS_NAMES = {
     0: "D2D_OK",
@@ -68,7 +69,8 @@ class Params(C.Structure):
         ("solver", C.c_int32),
         ("steps", C.c_int32),
         ("out_mode", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("grid_role", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 

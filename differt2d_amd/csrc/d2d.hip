@@ -255,6 +255,7 @@ int check_params(const d2d_params* p) {
         return fail(D2D_ERR_UNSUPPORTED, "activation %d is not one of the native activations", p->act);
     if (p->fun_id < 0 || p->fun_id > D2D_FUN_ONE) return fail(D2D_ERR_UNSUPPORTED, "fun_id %d is not a native path function", p->fun_id);
     if (p->out_mode != D2D_OUT_OVERWRITE && p->out_mode != D2D_OUT_ADD) return fail(D2D_ERR_INVALID, "bad out_mode %d", p->out_mode);
+    if (p->grid_role != D2D_GRID_RX && p->grid_role != D2D_GRID_TX) return fail(D2D_ERR_INVALID, "bad grid_role %d", p->grid_role);
     if (!(p->seg_tol >= 0.0f)) return fail(D2D_ERR_INVALID, "seg_tol must be >= 0");
     return D2D_OK;
 }
@@ -556,6 +557,7 @@ static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx) {
     a.cells = (long)c->m * c->n;
     a.txx = tx[0];
     a.txy = tx[1];
+    a.grid_is_tx = (p->grid_role == D2D_GRID_TX) ? 1 : 0;
     a.mode = p->approx ? (p->act == D2D_ACT_HARD_SIGMOID ? d2d::MODE_HSIG : d2d::MODE_SIG) : d2d::MODE_HARD;
     a.alpha = p->alpha;
     a.tol = p->tol;
@@ -649,6 +651,20 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     const long long tiles = (long long)tiles_x * tiles_y;
     if (tiles > 0x7fffffffLL) return fail(D2D_ERR_INVALID, "grid too large: %lld tiles", tiles);
     dim3 grid((unsigned)tiles), block(64);
+    const bool txg = p->grid_role == D2D_GRID_TX;
+    if (txg && d_stats) return fail(D2D_ERR_UNSUPPORTED, "the instrumented build covers the RX-grid kernel only");
+    if (txg && !grad_mode) {
+        // TX grid, values only: the per-lane-image code path without the adjoint
+        const size_t lds0 = (size_t)(4 * c->N + 4) * sizeof(float);
+        a.grad = nullptr; a.cot = nullptr; a.partial = nullptr;
+        switch (mode) {
+            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_HARD, true, false>), grid, block, lds0, c->stream, a); break;
+            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_HSIG, true, false>), grid, block, lds0, c->stream, a); break;
+            default: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_SIG, true, false>), grid, block, lds0, c->stream, a); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return D2D_OK;
+    }
     if (grad_mode) {
         const size_t cells = (size_t)c->m * c->n;
         if ((rc = c->d_grad.ensure(2 * cells))) return rc;
@@ -663,10 +679,15 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
         if (p->out_mode == D2D_OUT_OVERWRITE) c->have_vjp = false;
         const size_t lds = (size_t)(4 * c->N + 4) * sizeof(float);
+#define D2D_LAUNCH_VG(MODE_)                                                                                             \
+    do {                                                                                                                \
+        if (txg) hipLaunchKernelGGL((d2d::power_vg_kernel<MODE_, true, true>), grid, block, lds, c->stream, a);         \
+        else hipLaunchKernelGGL((d2d::power_vg_kernel<MODE_, false, true>), grid, block, lds, c->stream, a);            \
+    } while (0)
         switch (mode) {
-            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_HARD>), grid, block, lds, c->stream, a); break;
-            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_HSIG>), grid, block, lds, c->stream, a); break;
-            default: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_SIG>), grid, block, lds, c->stream, a); break;
+            case d2d::MODE_HARD: D2D_LAUNCH_VG(d2d::MODE_HARD); break;
+            case d2d::MODE_HSIG: D2D_LAUNCH_VG(d2d::MODE_HSIG); break;
+            default: D2D_LAUNCH_VG(d2d::MODE_SIG); break;
         }
         HIP_TRY(hipGetLastError());
         if (grad_mode == 2) {

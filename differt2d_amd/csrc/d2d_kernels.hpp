@@ -181,16 +181,19 @@ __device__ __forceinline__ void normalize2_bwd(float vx, float vy, float obx, fl
     vby = (oby - d * oy) / len;
 }
 
-template <int K, int MODE, bool STATS, bool GRAD = false, bool PREF = true>
+// (txx, txy) / (rxx, rxy): the path's end points; exactly one of the two is the lane's grid cell, the other is
+// wave-uniform (RX grid: scene.py:1803-1953; TX grid, TXG = true: scene.py:1489-1648, where the per-cell gradient is
+// taken w.r.t. the transmitter, scene.py:1617-1620).
+template <int K, int MODE, bool STATS, bool GRAD = false, bool PREF = true, bool TXG = false>
 __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&cand)[D2D_MAX_ORDER],
                                                const float (&imgx)[D2D_MAX_ORDER], const float (&imgy)[D2D_MAX_ORDER],
-                                               float rxx, float rxy, bool lane_bad, float& acc, WaveStats& st,
-                                               GradCtx* g = nullptr) {
+                                               float txx, float txy, float rxx, float rxy, bool lane_bad, float& acc,
+                                               WaveStats& st, GradCtx* g = nullptr) {
     int on_i = 0, on_w = 0, hit_i = 0, hit_j = -1;  // GRAD: which activation carries the min / max
     bool znan = false;  // GRAD: the reference's autodiff yields NaN for this (cell, candidate), see below
     float px[K + 2], py[K + 2];
-    px[0] = a.txx;
-    py[0] = a.txy;
+    px[0] = txx;
+    py[0] = txy;
     px[K + 1] = rxx;
     py[K + 1] = rxy;
 
@@ -653,8 +656,8 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
 #pragma unroll
         for (int i = K - 1; i >= 0; --i) {
             const float4 r0 = a.refl[2 * cand[i]];
-            const float prx = (i == 0) ? a.txx : imgx[i > 0 ? i - 1 : 0];
-            const float pry = (i == 0) ? a.txy : imgy[i > 0 ? i - 1 : 0];
+            const float prx = (i == 0) ? txx : imgx[i > 0 ? i - 1 : 0];
+            const float pry = (i == 0) ? txy : imgy[i > 0 ? i - 1 : 0];
             float wx = prx - r0.x, wy = pry - r0.y;
             float dn = wx * r0.z + wy * r0.w;
             float s2 = 2.0f * dn;
@@ -669,12 +672,12 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             if (i == 0) { txbx += prbx; txby += prby; }
             else { ibx_[i > 0 ? i - 1 : 0] += prbx; iby_[i > 0 ? i - 1 : 0] += prby; }
         }
-        g->grx += pbx[K + 1];
-        g->gry += pby[K + 1];
+        g->grx += TXG ? txbx : pbx[K + 1];
+        g->gry += TXG ? txby : pby[K + 1];
 
         if (g->scene) {
-            g->tbx += g->cot * txbx;
-            g->tby += g->cot * txby;
+            g->tbx += g->cot * (TXG ? pbx[K + 1] : txbx);  // adjoint of the fixed (wave-uniform) end point
+            g->tby += g->cot * (TXG ? pby[K + 1] : txby);
             // normals -> wall end points: n = m / len, m = (t_y, -t_x); t = dest - origin
 #pragma unroll
             for (int i = 0; i < K; ++i) {
@@ -715,20 +718,20 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
 
 // All candidates of order K in lexicographic order (scene.py:122-175), images built incrementally
 // (geometry.py:1086-1091, 1109).
-template <int K, int MODE, bool STATS, bool GRAD = false>
-__device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float rxy, bool lane_bad, float& acc,
-                                            WaveStats& st, GradCtx* g = nullptr) {
+template <int K, int MODE, bool STATS, bool GRAD = false, bool TXG = false>
+__device__ __forceinline__ void sweep_order(const SweepArgs& a, float txx, float txy, float rxx, float rxy, bool lane_bad,
+                                            float& acc, WaveStats& st, GradCtx* g = nullptr) {
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
     float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];
     if (K == 0) {
-        eval_candidate<0, MODE, STATS, GRAD>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st, g);
+        eval_candidate<0, MODE, STATS, GRAD, true, TXG>(a, cand, imgx, imgy, txx, txy, rxx, rxy, lane_bad, acc, st, g);
         return;
     }
     for (int i0 = 0; i0 < a.Nc; ++i0) {
         cand[0] = a.cw[i0];
-        image_of(a.refl[2 * cand[0]], a.txx, a.txy, imgx[0], imgy[0]);
+        image_of(a.refl[2 * cand[0]], txx, txy, imgx[0], imgy[0]);
         if (K == 1) {
-            eval_candidate<K, MODE, STATS, GRAD>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st, g);
+            eval_candidate<K, MODE, STATS, GRAD, true, TXG>(a, cand, imgx, imgy, txx, txy, rxx, rxy, lane_bad, acc, st, g);
             continue;
         }
         for (int i1 = 0; i1 < a.Nc; ++i1) {
@@ -736,7 +739,7 @@ __device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float
             if (cand[1] == cand[0]) continue;
             image_of(a.refl[2 * cand[1]], imgx[0], imgy[0], imgx[1], imgy[1]);
             if (K == 2) {
-                eval_candidate<K, MODE, STATS, GRAD>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st, g);
+                eval_candidate<K, MODE, STATS, GRAD, true, TXG>(a, cand, imgx, imgy, txx, txy, rxx, rxy, lane_bad, acc, st, g);
                 continue;
             }
             for (int i2 = 0; i2 < a.Nc; ++i2) {
@@ -744,14 +747,14 @@ __device__ __forceinline__ void sweep_order(const SweepArgs& a, float rxx, float
                 if (cand[2] == cand[1]) continue;
                 image_of(a.refl[2 * cand[2]], imgx[1], imgy[1], imgx[2], imgy[2]);
                 if (K == 3) {
-                    eval_candidate<K, MODE, STATS, GRAD>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st, g);
+                    eval_candidate<K, MODE, STATS, GRAD, true, TXG>(a, cand, imgx, imgy, txx, txy, rxx, rxy, lane_bad, acc, st, g);
                     continue;
                 }
                 for (int i3 = 0; i3 < a.Nc; ++i3) {
                     cand[3] = a.cw[i3];
                     if (cand[3] == cand[2]) continue;
                     image_of(a.refl[2 * cand[3]], imgx[2], imgy[2], imgx[3], imgy[3]);
-                    eval_candidate<(K >= 4 ? 4 : K), MODE, STATS, GRAD>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st, g);
+                    eval_candidate<(K >= 4 ? 4 : K), MODE, STATS, GRAD, true, TXG>(a, cand, imgx, imgy, txx, txy, rxx, rxy, lane_bad, acc, st, g);
                 }
             }
         }
@@ -910,7 +913,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 mask &= mask - 1;
                 cand[K - 1] = a.cw[chunk * 64 + b];
                 image_of(a.refl[2 * cand[K - 1]], pIx, pIy, imgx[K - 1], imgy[K - 1]);
-                eval_candidate<K, MODE, STATS, false, false>(a, cand, imgx, imgy, rxx, rxy, lane_bad, acc, st);
+                eval_candidate<K, MODE, STATS, false, false, false>(a, cand, imgx, imgy, a.txx, a.txy, rxx, rxy, lane_bad, acc, st);
             }
         }
         // next prefix (lexicographic, no equal neighbours); static indexing keeps pos[] in registers
@@ -980,7 +983,7 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     const float qn = __builtin_nanf("");
     const float bx[4] = {box_ok ? x0 : qn, x1, x1, x0};
     const float by[4] = {y0, y0, y1, y1};
-    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS>(a, rxx, rxy, lane_bad, acc, st);
+    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st);
     if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
     if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled<2, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled<3, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
@@ -1009,7 +1012,8 @@ __global__ void selftest_div_kernel(const float* __restrict__ x, const float* __
 // hand-derived adjoint of every contributing candidate.  One wave per block; the wave's partial sums of
 // the scene-parameter VJP live in LDS and are written to `partial` (reduced in fixed order afterwards,
 // so results are reproducible run to run).
-template <int MODE>
+// GRADK = 0: values only (used for the TX-grid forward sweep, which has no culled kernel of its own).
+template <int MODE, bool TXG, bool GRADK>
 __global__ void __launch_bounds__(64) power_vg_kernel(SweepArgs a) {
     extern __shared__ float wl[];  // [4 N]
     const int lane = threadIdx.x & 63;
@@ -1022,10 +1026,13 @@ __global__ void __launch_bounds__(64) power_vg_kernel(SweepArgs a) {
     const int ccol = col < a.n ? col : a.n - 1;
     const int crow = row < a.m ? row : a.m - 1;
     const long idx = (long)crow * a.n + ccol;
-    const float rxx = a.X[idx], rxy = a.Y[idx];
-    const bool lane_bad = !(fabsf(rxx) < 1e18f) || !(fabsf(rxy) < 1e18f) || !(fabsf(a.txx) < 1e18f) ||
+    const float gx_ = a.X[idx], gy_ = a.Y[idx];
+    // (a.txx, a.txy) is the FIXED end point: the transmitter for an RX grid, the receiver for a TX grid
+    const float txx = TXG ? gx_ : a.txx, txy = TXG ? gy_ : a.txy;
+    const float rxx = TXG ? a.txx : gx_, rxy = TXG ? a.txy : gy_;
+    const bool lane_bad = !(fabsf(gx_) < 1e18f) || !(fabsf(gy_) < 1e18f) || !(fabsf(a.txx) < 1e18f) ||
                           !(fabsf(a.txy) < 1e18f);
-    const bool scene = a.partial != nullptr;
+    const bool scene = GRADK && a.partial != nullptr;
     if (scene) {
         for (int i = lane; i < 4 * a.N; i += 64) wl[i] = 0.0f;
         __syncthreads();
@@ -1037,20 +1044,24 @@ __global__ void __launch_bounds__(64) power_vg_kernel(SweepArgs a) {
     g.scene = scene;
     float acc = 0.0f;
     WaveStats st;
-    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, true>(a, rxx, rxy, lane_bad, acc, st, &g);
-    if (a.min_order <= 1 && a.max_order >= 1) sweep_order<1, MODE, false, true>(a, rxx, rxy, lane_bad, acc, st, &g);
-    if (a.min_order <= 2 && a.max_order >= 2) sweep_order<2, MODE, false, true>(a, rxx, rxy, lane_bad, acc, st, &g);
-    if (a.min_order <= 3 && a.max_order >= 3) sweep_order<3, MODE, false, true>(a, rxx, rxy, lane_bad, acc, st, &g);
-    if (a.min_order <= 4 && a.max_order >= 4) sweep_order<4, MODE, false, true>(a, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, GRADK, TXG>(a, txx, txy, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 1 && a.max_order >= 1) sweep_order<1, MODE, false, GRADK, TXG>(a, txx, txy, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 2 && a.max_order >= 2) sweep_order<2, MODE, false, GRADK, TXG>(a, txx, txy, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 3 && a.max_order >= 3) sweep_order<3, MODE, false, GRADK, TXG>(a, txx, txy, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 4 && a.max_order >= 4) sweep_order<4, MODE, false, GRADK, TXG>(a, txx, txy, rxx, rxy, lane_bad, acc, st, &g);
     if (in_range) {
         if (a.out_mode == D2D_OUT_ADD) {
             a.out[idx] = a.out[idx] + acc;
-            a.grad[2 * idx] = a.grad[2 * idx] + g.grx;
-            a.grad[2 * idx + 1] = a.grad[2 * idx + 1] + g.gry;
+            if (GRADK) {
+                a.grad[2 * idx] = a.grad[2 * idx] + g.grx;
+                a.grad[2 * idx + 1] = a.grad[2 * idx + 1] + g.gry;
+            }
         } else {
             a.out[idx] = acc;
-            a.grad[2 * idx] = g.grx;
-            a.grad[2 * idx + 1] = g.gry;
+            if (GRADK) {
+                a.grad[2 * idx] = g.grx;
+                a.grad[2 * idx + 1] = g.gry;
+            }
         }
     }
     if (scene) {
@@ -1523,7 +1534,8 @@ struct OptSweepArgs {
     const float* __restrict__ Y;
     float* __restrict__ out;
     long cells;
-    float txx, txy;
+    float txx, txy;  // the fixed end point (transmitter for an RX grid, receiver for a TX grid)
+    int grid_is_tx;
     int mode;
     float alpha, tol, seg_lo, seg_hi;
     float fnum[D2D_MAX_ORDER + 1];
@@ -1535,7 +1547,9 @@ struct OptSweepArgs {
 __global__ void __launch_bounds__(64) power_opt_kernel(OptSweepArgs a) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.cells) return;
-    const float rxx = a.X[idx], rxy = a.Y[idx];
+    const float gx_ = a.X[idx], gy_ = a.Y[idx];
+    const float txx = a.grid_is_tx ? gx_ : a.txx, txy = a.grid_is_tx ? gy_ : a.txy;
+    const float rxx = a.grid_is_tx ? a.txx : gx_, rxy = a.grid_is_tx ? a.txy : gy_;
     const Truth L{a.mode, a.alpha};
     float acc = 0.0f;
     for (int c = 0; c < a.C; ++c) {
@@ -1549,8 +1563,8 @@ __global__ void __launch_bounds__(64) power_opt_kernel(OptSweepArgs a) {
         }
         float px[NP], py[NP];
         float loss = 0.0f;
-        if (k == 0) image_solve(a.T, 0, cd, a.txx, a.txy, rxx, rxy, px, py);
-        else loss = opt_solve(a.T, a.A, k, cd, th0, a.txx, a.txy, rxx, rxy, px, py);
+        if (k == 0) image_solve(a.T, 0, cd, txx, txy, rxx, rxy, px, py);
+        else loss = opt_solve(a.T, a.A, k, cd, th0, txx, txy, rxx, rxy, px, py);
         float on, hit, valid;
         literal_validity(a.T, L, k, cd, px, py, loss, a.tol, a.seg_lo, a.seg_hi, on, hit, valid);
         const float r = literal_length(k, px, py);

@@ -401,28 +401,22 @@ class Scene(Plottable):
             acc = (acc + out["valid"][:, c].reshape(X.shape) * val).astype(F)
         return acc
 
-    def accumulate_on_receivers_grid_over_paths(
-        self, X, Y, fun: PathFun, fun_args: tuple = (), fun_kwargs: Optional[Mapping] = None, *, reduce_all: bool = False,
-        grad: bool = False, value_and_grad: bool = False, path_cls: type = ImagePath,
-        path_cls_kwargs: Optional[Mapping] = None, receiver_cls: type = Point, min_order: int = 0, max_order: int = 1,
-        order: Optional[int] = None, filter_objects: Optional[Callable[[Object], bool]] = None, key=None, **kwargs,
-    ):
-        """Power-map sweep: for every transmitter, ``Z[i, j] = sum_candidates valid * fun`` with the receiver at
-        ``(X[i, j], Y[i, j])`` (reference scene.py:1803-1953). Returns an iterator of ``(tx name, Z)``, or their
-        sum if ``reduce_all``. One fused kernel launch per transmitter when ``fun`` is native."""
+    def _grid_sweep(self, X, Y, fixed_items, grid_is_rx, point_cls, fun, fun_args, fun_kwargs, reduce_all, grad,
+                    value_and_grad, path_cls, path_cls_kwargs, min_order, max_order, order, filter_objects, key, kwargs):
+        """Shared driver of the two grid sweeps: ``fixed_items`` are the named end points that stay put (transmitters
+        for an RX grid, receivers for a TX grid); one fused launch per fixed point when ``fun`` is native."""
         X = np.ascontiguousarray(X, dtype=F)
         Y = np.ascontiguousarray(Y, dtype=F)
         native, common = self._sweep_params(fun, fun_args, fun_kwargs, path_cls, path_cls_kwargs, min_order, max_order,
                                             order, kwargs)
-        txs = list(self.transmitters.items())
         want_grad = bool(grad or value_and_grad)
 
         if native is None:
             if want_grad:
                 raise L.D2DUnsupported(-4, "grad / value_and_grad need a natively fused fun (differt2d_amd.utils): an "
                                            "arbitrary Python callable cannot be differentiated by the hand-derived kernels")
-            gen = ((name, self._emit_grid(X, Y, tx, True, receiver_cls, fun, fun_args, fun_kwargs, common, filter_objects,
-                                          path_cls, path_cls_kwargs, key)) for name, tx in txs)
+            gen = ((name, self._emit_grid(X, Y, pt, grid_is_rx, point_cls, fun, fun_args, fun_kwargs, common,
+                                          filter_objects, path_cls, path_cls_kwargs, key)) for name, pt in fixed_items)
             if reduce_all:
                 Z = F(0.0)
                 for _, p in gen:
@@ -438,7 +432,7 @@ class Scene(Plottable):
                 raise L.D2DUnsupported(-4, "grad / value_and_grad are implemented for ImagePath only")
             cands = self.all_path_candidates(min_order, max_order, order=order, filter_objects=filter_objects)
         sextra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, cands or [], key)
-        extra = {**extra, **sextra}
+        extra = {**extra, **sextra, "grid_role": L.GRID_RX if grid_is_rx else L.GRID_TX}
 
         def fetch():
             if value_and_grad:  # takes precedence over grad (reference scene.py:1920-1923)
@@ -447,32 +441,46 @@ class Scene(Plottable):
                 return ctx.get_grad_rx()
             return ctx.get_map()
 
-        def launch(tx, out_mode):
+        def launch(pt, out_mode):
             params = make_params(fun=name, out_mode=out_mode, **extra, **common)
             if theta0 is not None:
                 ctx.set_theta0(theta0)
             if want_grad:
-                ctx.launch_vg(params, tx.xy, scene_vjp=False)
+                ctx.launch_vg(params, pt.xy, scene_vjp=False)
             else:
-                ctx.launch(params, tx.xy)
+                ctx.launch(params, pt.xy)
 
         if reduce_all:
-            if not txs:
+            if not fixed_items:
                 return (F(0.0), F(0.0)) if value_and_grad else F(0.0)
             self._upload(ctx, filter_objects)
             ctx.set_grid(X, Y)
-            for i, (_, tx) in enumerate(txs):
-                launch(tx, L.OUT_ADD if i else L.OUT_OVERWRITE)
+            for i, (_, pt) in enumerate(fixed_items):
+                launch(pt, L.OUT_ADD if i else L.OUT_OVERWRITE)
             return fetch()
 
         def results():
-            for tx_name, tx in txs:
+            for pt_name, pt in fixed_items:
                 self._upload(ctx, filter_objects)
                 ctx.set_grid(X, Y)
-                launch(tx, L.OUT_OVERWRITE)
-                yield tx_name, fetch()
+                launch(pt, L.OUT_OVERWRITE)
+                yield pt_name, fetch()
 
         return results()
+
+    def accumulate_on_receivers_grid_over_paths(
+        self, X, Y, fun: PathFun, fun_args: tuple = (), fun_kwargs: Optional[Mapping] = None, *, reduce_all: bool = False,
+        grad: bool = False, value_and_grad: bool = False, path_cls: type = ImagePath,
+        path_cls_kwargs: Optional[Mapping] = None, receiver_cls: type = Point, min_order: int = 0, max_order: int = 1,
+        order: Optional[int] = None, filter_objects: Optional[Callable[[Object], bool]] = None, key=None, **kwargs,
+    ):
+        """Power-map sweep: for every transmitter, ``Z[i, j] = sum_candidates valid * fun`` with the receiver at
+        ``(X[i, j], Y[i, j])`` (reference scene.py:1803-1953). Returns an iterator of ``(tx name, Z)``, or their
+        sum if ``reduce_all``; ``grad`` / ``value_and_grad`` add the per-cell gradient w.r.t. the receiver position
+        (last axis ``(d/dx, d/dy)``). One fused kernel launch per transmitter when ``fun`` is native."""
+        return self._grid_sweep(X, Y, list(self.transmitters.items()), True, receiver_cls, fun, fun_args, fun_kwargs,
+                                reduce_all, grad, value_and_grad, path_cls, path_cls_kwargs, min_order, max_order, order,
+                                filter_objects, key, kwargs)
 
     def receivers_grid_value_and_vjp(
         self, X, Y, fun: PathFun, fun_kwargs: Optional[Mapping] = None, *, cotangent=None, path_cls: type = ImagePath,
@@ -507,18 +515,8 @@ class Scene(Plottable):
         path_cls_kwargs: Optional[Mapping] = None, transmitter_cls: type = Point, min_order: int = 0, max_order: int = 1,
         order: Optional[int] = None, filter_objects: Optional[Callable[[Object], bool]] = None, key=None, **kwargs,
     ):
-        """Transmitter-grid twin (reference scene.py:1489-1648): one map per receiver. Traced on the GPU per
-        (cell, candidate); ``fun`` is evaluated on the host (no fused kernel for this orientation yet)."""
-        X = np.ascontiguousarray(X, dtype=F)
-        Y = np.ascontiguousarray(Y, dtype=F)
-        if grad or value_and_grad:
-            raise L.D2DUnsupported(-4, "grad / value_and_grad need the gradient kernels (not in this build)")
-        _, common = self._sweep_params(fun, fun_args, fun_kwargs, path_cls, path_cls_kwargs, min_order, max_order, order, kwargs)
-        gen = ((name, self._emit_grid(X, Y, rx, False, transmitter_cls, fun, fun_args, fun_kwargs, common, filter_objects,
-                                      path_cls, path_cls_kwargs, key)) for name, rx in self.receivers.items())
-        if reduce_all:
-            Z = F(0.0)
-            for _, p in gen:
-                Z = (Z + p).astype(F)
-            return Z
-        return gen
+        """Transmitter-grid twin (reference scene.py:1489-1648): one map per receiver, the transmitter sits at
+        ``(X[i, j], Y[i, j])``; gradients are w.r.t. the transmitter position (scene.py:1617-1620)."""
+        return self._grid_sweep(X, Y, list(self.receivers.items()), False, transmitter_cls, fun, fun_args, fun_kwargs,
+                                reduce_all, grad, value_and_grad, path_cls, path_cls_kwargs, min_order, max_order, order,
+                                filter_objects, key, kwargs)

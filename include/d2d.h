@@ -55,6 +55,9 @@ enum { D2D_ACT_HARD_SIGMOID = 0, D2D_ACT_SIGMOID = 1 };
  *   ONE             1.0 (the map then counts valid paths -- "intersection counts") */
 enum { D2D_FUN_RECEIVED_POWER = 0, D2D_FUN_LENGTH_SQUARED = 1, D2D_FUN_LENGTH = 2, D2D_FUN_ONE = 3 };
 
+/* Which end of the paths the grid cells are. */
+enum { D2D_GRID_RX = 0, D2D_GRID_TX = 1 };
+
 /* How a sweep combines with what the output map already holds. */
 enum {
     D2D_OUT_OVERWRITE = 0, /* Z  = facc                                              */
@@ -78,7 +81,12 @@ typedef struct d2d_params {
     int32_t solver;     /* D2D_SOLVER_* */
     int32_t steps;      /* differt2d/optimize.py:50 (100): Adam steps of MinPath / FermatPath */
     int32_t out_mode;   /* D2D_OUT_* */
-    int32_t reserved[4];
+    int32_t grid_role;  /* D2D_GRID_RX: the grid cells are receivers and `tx` is the transmitter
+                           (accumulate_on_receivers_grid_over_paths, differt2d/scene.py:1803-1953);
+                           D2D_GRID_TX: the grid cells are transmitters and the `tx` argument of the launch is the
+                           fixed RECEIVER (accumulate_on_transmitters_grid_over_paths, differt2d/scene.py:1489-1648);
+                           the per-cell gradient is then taken w.r.t. the transmitter (scene.py:1617-1620) */
+    int32_t reserved[3];
 } d2d_params;
 
 typedef struct d2d_ctx d2d_ctx;

@@ -32,6 +32,7 @@ class OrcParams(C.Structure):
         ("r_coef", C.c_float),
         ("height", C.c_float),
         ("prune", C.c_int32),
+        ("grid_is_tx", C.c_int32),
     ]
 
 
@@ -70,11 +71,12 @@ def lib():
 
 
 def make_params(min_order=0, max_order=1, order=None, approx=False, function="hard_sigmoid", alpha=100.0,
-                tol=1e-2, patch=0.0, seg_tol=0.005, fun="received_power", r_coef=0.5, height=0.1, prune=False):
+                tol=1e-2, patch=0.0, seg_tol=0.005, fun="received_power", r_coef=0.5, height=0.1, prune=False,
+                grid_role="rx"):
     if order is not None:
         min_order = max_order = order
     return OrcParams(min_order, max_order, int(bool(approx)), ACT_IDS[function], alpha, tol, patch, seg_tol,
-                     FUN_IDS[fun], r_coef, height, int(bool(prune)))
+                     FUN_IDS[fun], r_coef, height, int(bool(prune)), 1 if grid_role == "tx" else 0)
 
 
 def _allowed_ptr(allowed):
@@ -90,7 +92,8 @@ def num_candidates(N, min_order, max_order, allowed=None):
 
 
 def power_map(walls, tx, X, Y, allowed=None, nthreads=0, **kw):
-    """C-oracle power map for one transmitter; X, Y any shape, returns the same shape."""
+    """C-oracle power map for one transmitter (grid_role="rx") or one receiver (grid_role="tx", `tx` is then the
+    fixed receiver and the grid cells are transmitters); X, Y any shape, returns the same shape."""
     walls = np.ascontiguousarray(walls, dtype=np.float32).reshape(-1, 2, 2)
     Xc = np.ascontiguousarray(X, dtype=np.float32)
     Yc = np.ascontiguousarray(Y, dtype=np.float32)

@@ -48,6 +48,7 @@ typedef struct orc_params {
     int32_t fun_id;   /* 0 received_power, 1 length**2, 2 length, 3 one */
     float r_coef, height;
     int32_t prune;    /* 1: skip work whose result is provably discarded (exact); 0: evaluate everything */
+    int32_t grid_is_tx; /* 0: grid cells are receivers (scene.py:1803-1953); 1: transmitters, `tx` is the fixed receiver (scene.py:1489-1648) */
 } orc_params;
 
 typedef struct {
@@ -280,7 +281,22 @@ int orc_power_map(const float* walls, int N, const uint8_t* allowed, const orc_p
         float acc = 0.0f;
         for (long ci = 0; ci < total; ++ci) {
             float valid, f;
-            eval_candidate(W, N, C[ci].idx, C[ci].k, C[ci].img, tx[0], tx[1], X[c], Y[c], p, &valid, &f);
+            if (!p->grid_is_tx) {
+                eval_candidate(W, N, C[ci].idx, C[ci].k, C[ci].img, tx[0], tx[1], X[c], Y[c], p, &valid, &f);
+            } else {
+                /* the cell is the transmitter: its images are per cell (geometry.py:1086-1091) */
+                float img[2 * ORC_MAX_ORDER];
+                float ix = X[c], iy = Y[c];
+                for (int i = 0; i < C[ci].k; ++i) {
+                    const wall_t* ww = &W[C[ci].idx[i]];
+                    float dxp = ix - ww->ox, dyp = iy - ww->oy;
+                    float dn = dxp * ww->nx + dyp * ww->ny;
+                    ix = ix - 2.0f * dn * ww->nx;
+                    iy = iy - 2.0f * dn * ww->ny;
+                    img[2 * i] = ix; img[2 * i + 1] = iy;
+                }
+                eval_candidate(W, N, C[ci].idx, C[ci].k, img, X[c], Y[c], tx[0], tx[1], p, &valid, &f);
+            }
             acc = acc + valid * f;
         }
         out[c] = acc;

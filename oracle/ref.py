@@ -847,14 +847,16 @@ def facc(tx, scene_objs, cands, rx, fun="received_power", fun_kwargs=None, solve
 
 def power_map(walls, tx, Xg, Yg, min_order=0, max_order=1, order=None, fun="received_power",
               fun_kwargs=None, approx=False, objs=None, filter_nodes=None, solver="image",
-              theta0s=None, steps=100, xp=NUMPY, **kw):
+              theta0s=None, steps=100, xp=NUMPY, grid_role="rx", **kw):
     """Scene.accumulate_on_receivers_grid_over_paths for ONE transmitter (scene.py:1803-1953):
-    grid = dstack((X, Y)); Z = vmap(vmap(facc))(tx, grid)."""
+    grid = dstack((X, Y)); Z = vmap(vmap(facc))(tx, grid).  With grid_role="tx" the grid cells are the
+    transmitters and ``tx`` is the fixed receiver (accumulate_on_transmitters_grid_over_paths, scene.py:1489-1648)."""
     scene_objs = objs if objs is not None else walls_to_objs(walls, xp)
     cands = all_path_candidates(len(scene_objs), min_order, max_order, order, filter_nodes)
-    rx = vec(xp.asarray(Xg), xp.asarray(Yg), xp)
-    return facc(xp.asarray(tx), scene_objs, cands, rx, fun, fun_kwargs, solver, approx, xp,
-                theta0s=theta0s, steps=steps, **kw)
+    grid = vec(xp.asarray(Xg), xp.asarray(Yg), xp)
+    fixed = xp.asarray(tx)
+    a, b = (fixed, grid) if grid_role == "rx" else (grid, fixed)
+    return facc(a, scene_objs, cands, b, fun, fun_kwargs, solver, approx, xp, theta0s=theta0s, steps=steps, **kw)
 
 
 def grid(bbox, m=50, n=None):

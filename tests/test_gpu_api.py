@@ -169,17 +169,63 @@ def test_accumulate_on_receivers_grid_los(native):
     np.testing.assert_allclose(per_tx["tx1"], np.stack([2 * (X - 1.0), 2 * Y], axis=-1), rtol=1e-5, atol=1e-5)
 
 
-def test_accumulate_on_transmitters_grid_los():
-    # tests/test_scene.py:487-556 (values)
+@pytest.mark.parametrize("native", [True, False])
+def test_accumulate_on_transmitters_grid_los(native):
+    # tests/test_scene.py:487-556
     from differt2d_amd.geometry import Point
     from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import path_length_squared
 
+    fun = path_length_squared if native else _length_sq
     scene = Scene(transmitters={}, objects=[], receivers={"rx0": Point(xy=[0.0, 0.0]), "rx1": Point(xy=[0.0, 1.0])})
     x = np.linspace(-3, 3, 10).astype(F)
     X, Y = np.meshgrid(x, x)
-    got = dict(scene.accumulate_on_transmitters_grid_over_paths(X, Y, fun=_length_sq, max_order=1, approx=False))
+    got = dict(scene.accumulate_on_transmitters_grid_over_paths(X, Y, fun=fun, max_order=1, approx=False, key=1234))
     np.testing.assert_allclose(got["rx0"], X**2 + Y**2, rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(got["rx1"], X**2 + (Y - 1.0) ** 2, rtol=1e-6, atol=1e-6)
+    expected_Z = X**2 + Y**2 + X**2 + (Y - 1.0) ** 2
+    Z = scene.accumulate_on_transmitters_grid_over_paths(X, Y, fun=fun, reduce_all=True, max_order=1, approx=False)
+    np.testing.assert_allclose(Z, expected_Z, rtol=1e-6, atol=1e-5)
+    if not native:
+        return
+    expected_dZ = np.stack([2 * X, 2 * Y], axis=-1) + np.stack([2 * X, 2 * (Y - 1.0)], axis=-1)
+    dZ = scene.accumulate_on_transmitters_grid_over_paths(X, Y, fun=fun, reduce_all=True, grad=True, max_order=1, approx=False)
+    np.testing.assert_allclose(dZ, expected_dZ, rtol=1e-5, atol=1e-5)
+    Z2, dZ2 = scene.accumulate_on_transmitters_grid_over_paths(X, Y, fun=fun, reduce_all=True, value_and_grad=True,
+                                                               max_order=1, approx=False)
+    np.testing.assert_allclose(Z2, expected_Z, rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(dZ2, expected_dZ, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("approx,function", [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")])
+def test_transmitters_grid_with_walls_matches_oracle(approx, function):
+    # the benchmark harness of the reference sweeps a TX grid on basic_scene (tests/benchmarks/test_scene.py:9-29)
+    from differt2d_amd import logic
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import received_power
+    from oracle import c_oracle as CO
+    from oracle import ref as R
+
+    scene = Scene.basic_scene()
+    X, Y = scene.grid(m=27, n=19)
+    X, Y = X * F(0.97) + F(0.013), Y * F(0.97) + F(0.017)
+    kw = dict(min_order=0, max_order=2, approx=approx, function=function)
+    got = scene.accumulate_on_transmitters_grid_over_paths(X, Y, fun=received_power, reduce_all=True, min_order=0, max_order=2,
+                                                           approx=approx, function=getattr(logic, function))
+    want = CO.power_map(_scene_walls(scene), scene.receivers["rx"].xy, X, Y, grid_role="tx", **kw)
+    if function == "sigmoid":
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-5)
+    else:
+        assert np.array_equal(got, want)
+    # per-cell gradient w.r.t. the transmitter vs autodiff of the oracle (order <= 1: basic_scene's collinear walls
+    # make the reference's own order-2 gradient NaN everywhere)
+    Z, dZ = scene.accumulate_on_transmitters_grid_over_paths(X, Y, fun=received_power, reduce_all=True, value_and_grad=True,
+                                                             max_order=1, approx=approx, function=getattr(logic, function))
+    g = R.power_map_value_and_grads(_scene_walls(scene), scene.receivers["rx"].xy, X, Y, dtype="float64", grid_role="tx",
+                                    min_order=0, max_order=1, approx=approx, function=function)
+    assert np.array_equal(np.isnan(dZ), np.isnan(g["grad_rx"]))
+    scale = np.nanmax(np.abs(g["grad_rx"]))
+    assert np.nanmax(np.abs(dZ - g["grad_rx"])) <= 3e-5 * scale
 
 
 # ---- power maps with walls: Scene API == oracle (the reference has no numeric pin here) --------
