@@ -18,6 +18,7 @@ No CPU implementation of the path solve / validity exists in this package.
 from __future__ import annotations
 
 import dataclasses
+import json
 import operator
 from collections.abc import Iterator, Mapping, Sequence
 from itertools import groupby, product
@@ -162,8 +163,28 @@ class Scene(Plottable):
         return cls(transmitters={}, receivers={}, objects=[Wall(xys=xys) for xys in np.asarray(walls, dtype=F)])
 
     @classmethod
-    def from_geojson(cls, *args, **kwargs):
-        raise NotImplementedError("Scene.from_geojson is outside the accelerated path (SURVEY.md section 8f, row 4)")
+    def from_geojson(cls, s_or_fp, tx_loc: str = "NW", rx_loc: str = "SE") -> "Scene":
+        """Scene from a GeoJSON document (string-like or file-like): one ``Wall`` per consecutive pair of points of
+        every ``Polygon`` feature's outer ring, wrapping around (so a closed ring also yields one zero-length wall,
+        as in the reference); TX / RX sit on corners of the bounding box (reference scene.py:428-668)."""
+        if hasattr(s_or_fp, "read"):
+            s_or_fp = s_or_fp.read()
+        if not isinstance(s_or_fp, (str, bytes, bytearray)):
+            raise NotImplementedError(f"Unsupported type {type(s_or_fp)}")
+        document = json.loads(s_or_fp)
+        walls = []
+        for feature in document.get("features", []):
+            geometry = feature.get("geometry", None)
+            if not geometry or geometry["type"] != "Polygon":
+                continue
+            ring = geometry["coordinates"][0]
+            for i in range(len(ring)):
+                walls.append(Wall(xys=np.array([ring[i - 1], ring[i]], dtype=F)))
+        scene = cls(objects=walls)
+        if walls:
+            return scene.with_transmitters(tx=Point(xy=scene.get_location(tx_loc))).with_receivers(
+                rx=Point(xy=scene.get_location(rx_loc)))
+        return scene.with_transmitters(tx=Point(xy=[0.0, 0.0])).with_receivers(rx=Point(xy=[1.0, 1.0]))
 
     @classmethod
     def from_scene_name(cls, scene_name: SceneName, *args, **kwargs) -> "Scene":

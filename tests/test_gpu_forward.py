@@ -161,3 +161,35 @@ def test_errors_are_loud(ctx):
         ctx.launch(make_params(max_order=7), [0.1, 0.1])
     with pytest.raises(L.D2DError):
         ctx.launch(make_params(approx=True, alpha=0.0), [0.1, 0.1])
+
+
+@pytest.mark.parametrize("approx,function", MODES)
+def test_geojson_scene_degenerate_walls_and_large_offsets(ctx, approx, function):
+    """The reference's example.geojson (28 walls, two of zero length, coordinates ~(4.6, 50.7) with wall lengths
+    ~1e-4: fp32 is at its limits) -- every culling / filter margin must still be conservative: bit-exact maps."""
+    import os
+
+    from differt2d_amd.scene import Scene
+
+    scene = Scene.from_geojson(open(os.path.join(os.path.dirname(__file__), "golden", "example.geojson")).read())
+    walls = np.stack([o.xys for o in scene.objects])
+    tx = scene.transmitters["tx"].xy
+    X, Y = scene.grid(m=24, n=20)
+    ctx.set_scene(walls)
+    for lo, hi in [(0, 1), (2, 2)]:
+        kw = dict(min_order=lo, max_order=hi, approx=approx, function=function)
+        _compare(ctx.power_map(tx, X, Y, **kw), _oracle(walls, tx, X, Y, **kw), function)
+
+
+@pytest.mark.parametrize("approx,function", MODES[:2])
+@pytest.mark.parametrize("scale,offset", [(1e-3, 0.0), (1e3, 0.0), (1.0, 1e3), (1e-2, -50.0)])
+def test_scaled_and_shifted_scenes(ctx, approx, function, scale, offset):
+    """Margins of the culling and of the filters are relative to the magnitudes involved: tiny, huge and far-from-origin
+    scenes must stay bit-exact."""
+    tx, walls = random_scene(14, seed=23)
+    X, Y = unit_grid(33, 25)
+    s, o = F(scale), F(offset)
+    walls, tx, X, Y = walls * s + o, tx * s + o, X * s + o, Y * s + o
+    ctx.set_scene(walls)
+    kw = dict(min_order=0, max_order=2, approx=approx, function=function, height=float(0.1 * scale))
+    _compare(ctx.power_map(tx, X, Y, **kw), _oracle(walls, tx, X, Y, **kw), function)

@@ -210,3 +210,27 @@ def test_approx_flag_semantics():
     logic.set_approx(before)
     with pytest.raises(L.D2DUnsupported):
         logic.native_activation_name(lambda x, a: x)
+
+
+# ---- geojson (reference tests/test_scene.py:215-247; fixture = the reference's own examples/example.geojson) ----
+
+
+@pytest.mark.parametrize("how", ["text", "bytes", "bytearray", "file"])
+def test_from_geojson(how):
+    import json
+
+    path = os.path.join(ROOT, "tests", "golden", "example.geojson")
+    src = {"text": lambda: open(path).read(), "bytes": lambda: open(path, "rb").read(),
+           "bytearray": lambda: bytearray(open(path, "rb").read()), "file": lambda: open(path)}[how]()
+    scene = Scene.from_geojson(src, tx_loc="SW", rx_loc="NE")
+    if hasattr(src, "close"):
+        src.close()
+    bbox = scene.bounding_box()
+    assert len(scene.transmitters) == 1 and len(scene.receivers) == 1 and len(scene.objects) == 28
+    assert np.array_equal(scene.transmitters["tx"].xy, bbox[0]) and np.array_equal(scene.receivers["rx"].xy, bbox[1])
+    empty = Scene.from_geojson('{"features": []}')
+    assert len(empty.objects) == 0 and len(empty.transmitters) == 1 and len(empty.receivers) == 1
+    with pytest.raises(NotImplementedError):
+        Scene.from_geojson(12345)
+    with pytest.raises(json.JSONDecodeError):
+        Scene.from_geojson(path)  # a path string is not a JSON document
