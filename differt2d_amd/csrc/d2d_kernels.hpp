@@ -64,7 +64,8 @@ struct SweepArgs {
 //   [4] segment/wall tests evaluated (filter)           [5] tests that took the exact-divide path
 //   [6] sum over [0] of the candidate order k           [7] sum over [1] of k   [8] sum over [3] of (k+1)
 struct WaveStats {
-    unsigned long long c[10];  // [9] candidates that went through the on_objects pre-filter
+    unsigned long long c[10];  // [9] tile-culling levels evaluated
+    int shadow;                // wave state, not a counter: the wall that occluded the wave's previous candidate
 };
 
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p); }
@@ -319,6 +320,97 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     bool on_zero = (MODE == MODE_HARD) ? !on_b : (MODE == MODE_HSIG) ? (on_c == 0.0f) : (on_z <= -89.0f);
     if (K > 0 && !wave_any(!on_zero || bad)) return;  // valid == 0 in every lane: acc + 0.0
 
+    // Lanes for which the occlusion result can still change the output.  (is_valid = all(on_objects,
+    // not intersects, loss < tol): the three terms commute, so the cheap-to-refute occlusion comes before the loss.)
+    const bool live = !on_zero || bad;
+    if (STATS) st.c[2] += 1;
+
+    // ---- intersects_with_objects, geometry.py:856-906 / 623-639 / 82-173 -------------------
+    float bx[K + 1], by[K + 1];
+#pragma unroll
+    for (int i = 0; i <= K; ++i) {
+        bx[i] = px[i] - px[i + 1];  // B = P3 - P4
+        by[i] = py[i] - py[i + 1];
+    }
+    bool hit_b = false;     // MODE_HARD
+    float hit_c = 0.0f;     // MODE_HSIG (false_value = 0/6)
+    float hit_z = -3.0e38f; // MODE_SIG: max over tests of min(z1..z4); "no test yet" = false_value handled below
+    bool any_test = false;
+    bool active = live;     // lanes still undecided
+    // The wall that finished off the previous candidate of this wave is tried first ("shadow cache"): or / max
+    // do not depend on the order of the tests, and neighbouring candidates tend to share their occluder.
+    for (int jj = -1; jj < a.N; ++jj) {
+        int j = jj;
+        if (jj < 0) {
+            if (GRAD || st.shadow < 0 || st.shadow >= a.N) continue;
+            j = st.shadow;
+        } else if (!GRAD && jj == st.shadow) {
+            continue;
+        }
+        const float4 w = a.occl[j];
+#pragma unroll
+        for (int i = 0; i <= K; ++i) {
+            const int ig0 = (i == 0) ? -1 : cand[i - 1];
+            const int ig1 = (i == K) ? -1 : cand[i];
+            if (j == ig0 || j == ig1) continue;  // wave-uniform
+            float Cx = w.x - px[i], Cy = w.y - py[i];
+            float fa = by[i] * Cx - bx[i] * Cy;   // geometry.py:157
+            float fb = w.z * Cy - w.w * Cx;       // geometry.py:158
+            float fd = w.w * bx[i] - w.z * by[i]; // geometry.py:159
+            // divide-free filter: t = fl(num/fd) certainly outside [flt_lo, flt_hi]?
+            float D = fabsf(fd);
+            float ua = (fd < 0.0f) ? -fa : fa;
+            float ub = (fd < 0.0f) ? -fb : fb;
+            float lo = a.flt_lo * D, hi = a.flt_hi * D;
+            bool miss = (fd == 0.0f) || ((D >= 1e-30f) && ((ua < lo) || (ua > hi) || (ub < lo) || (ub > hi)));
+            if (MODE == MODE_SIG) any_test = true;
+            if (STATS) st.c[4] += 1;
+            const bool need = wave_any(active && (!miss || bad));
+            if (STATS && need) st.c[5] += 1;
+            if (need) {
+                // exact path, geometry.py:163-171
+                bool dz = (fd == 0.0f);
+                float dd = dz ? 1.0f : fd;
+                float ta, tb;
+                div2_exact(fa, fb, dd, ta, tb);
+                ta = dz ? __builtin_inff() : ta;
+                tb = dz ? __builtin_inff() : tb;
+                if (MODE == MODE_HARD) {
+                    bool h = (ta >= a.seg_lo) && (ta <= a.seg_hi) && (tb >= a.seg_lo) && (tb <= a.seg_hi);
+                    hit_b = hit_b || h;
+                } else if (MODE == MODE_HSIG) {
+                    nanflag = nanflag || (ta != ta) || (tb != tb);
+                    float c = fminf(fminf(clampact(ta - a.seg_lo, a.alpha), clampact(a.seg_hi - ta, a.alpha)),
+                                    fminf(clampact(tb - a.seg_lo, a.alpha), clampact(a.seg_hi - tb, a.alpha)));
+                    if (GRAD && c > hit_c) {
+                        hit_i = i;
+                        hit_j = j;
+                    }
+                    hit_c = fmaxf(hit_c, c);
+                } else {
+                    nanflag = nanflag || (ta != ta) || (tb != tb);
+                    float z = fminf(fminf(a.alpha * (ta - a.seg_lo), a.alpha * (a.seg_hi - ta)),
+                                    fminf(a.alpha * (tb - a.seg_lo), a.alpha * (a.seg_hi - tb)));
+                    if (GRAD && z > hit_z) {
+                        hit_i = i;
+                        hit_j = j;
+                    }
+                    hit_z = fmaxf(hit_z, z);
+                }
+            }
+        }
+        // decided lanes: occlusion already makes valid exactly 0
+        if (MODE == MODE_HARD) active = active && (!hit_b || bad);
+        else if (MODE == MODE_HSIG) active = active && (hit_c != 6.0f || bad);
+        else active = active && (hit_z < 17.5f || bad);
+        if (!wave_any(active)) {
+            st.shadow = j;
+            break;
+        }
+    }
+    // every lane occluded (or off its walls): valid == 0 whatever the loss is
+    if (!wave_any(active)) return;
+
     if (STATS) st.c[1] += 1;
     // ---- path loss, geometry.py:1077-1084 / 641-650 ---------------------------------------
     // The loss of an image-method path is rounding noise (~1e-13) unless the path is degenerate, and it only
@@ -349,7 +441,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             bound += __builtin_fmaf(2.0f * c, fabsf(ex) + fabsf(ey), __builtin_fmaf(ex, ex, ey * ey)) + c * c;
         }
         const bool certain = (bound * 1.00001f < a.loss_skip) && !bad;
-        loss_known = !wave_any(!certain && !on_zero);
+        loss_known = !wave_any(!certain && active);
     }
     if (!loss_known) {
 #pragma unroll
@@ -369,84 +461,6 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     bool ok_b = loss < a.tol;                                    // hard: jnp.less
     float ok_x = a.tol - loss;                                   // approx: activation(tol - loss)
     if (MODE != MODE_HARD) nanflag = nanflag || (loss != loss);
-
-    // Lanes for which the occlusion result can still change the output.
-    bool live;
-    if (MODE == MODE_HARD) live = (on_b && ok_b) || bad;
-    else if (MODE == MODE_HSIG) live = !(on_zero || clampact(ok_x, a.alpha) == 0.0f) || bad;
-    else live = !(on_zero || a.alpha * ok_x <= -89.0f) || bad;
-    if (!wave_any(live)) return;
-    if (STATS) st.c[2] += 1;
-
-    // ---- intersects_with_objects, geometry.py:856-906 / 623-639 / 82-173 -------------------
-    float bx[K + 1], by[K + 1];
-#pragma unroll
-    for (int i = 0; i <= K; ++i) {
-        bx[i] = px[i] - px[i + 1];  // B = P3 - P4
-        by[i] = py[i] - py[i + 1];
-    }
-    bool hit_b = false;     // MODE_HARD
-    float hit_c = 0.0f;     // MODE_HSIG (false_value = 0/6)
-    float hit_z = -3.0e38f; // MODE_SIG: max over tests of min(z1..z4); "no test yet" = false_value handled below
-    bool any_test = false;
-    bool active = live;     // lanes still undecided
-    for (int j = 0; j < a.N; ++j) {
-        const float4 w = a.occl[j];
-#pragma unroll
-        for (int i = 0; i <= K; ++i) {
-            const int ig0 = (i == 0) ? -1 : cand[i - 1];
-            const int ig1 = (i == K) ? -1 : cand[i];
-            if (j == ig0 || j == ig1) continue;  // wave-uniform
-            float Cx = w.x - px[i], Cy = w.y - py[i];
-            float fa = by[i] * Cx - bx[i] * Cy;   // geometry.py:157
-            float fb = w.z * Cy - w.w * Cx;       // geometry.py:158
-            float fd = w.w * bx[i] - w.z * by[i]; // geometry.py:159
-            // divide-free filter: t = fl(num/fd) certainly outside [flt_lo, flt_hi]?
-            float D = fabsf(fd);
-            float ua = (fd < 0.0f) ? -fa : fa;
-            float ub = (fd < 0.0f) ? -fb : fb;
-            float lo = a.flt_lo * D, hi = a.flt_hi * D;
-            bool miss = (fd == 0.0f) || ((D >= 1e-30f) && ((ua < lo) || (ua > hi) || (ub < lo) || (ub > hi)));
-            if (MODE == MODE_SIG) any_test = true;
-            if (STATS) st.c[4] += 1;
-            const bool need = wave_any(active && (!miss || bad));
-            if (STATS && need) st.c[5] += 1;
-            if (need) {
-                // exact path, geometry.py:163-171
-                bool dz = (fd == 0.0f);
-                float dd = dz ? 1.0f : fd;
-                float ta = dz ? __builtin_inff() : fa / dd;
-                float tb = dz ? __builtin_inff() : fb / dd;
-                if (MODE == MODE_HARD) {
-                    bool h = (ta >= a.seg_lo) && (ta <= a.seg_hi) && (tb >= a.seg_lo) && (tb <= a.seg_hi);
-                    hit_b = hit_b || h;
-                } else if (MODE == MODE_HSIG) {
-                    nanflag = nanflag || (ta != ta) || (tb != tb);
-                    float c = fminf(fminf(clampact(ta - a.seg_lo, a.alpha), clampact(a.seg_hi - ta, a.alpha)),
-                                    fminf(clampact(tb - a.seg_lo, a.alpha), clampact(a.seg_hi - tb, a.alpha)));
-                    if (GRAD && c > hit_c) {
-                        hit_i = i;
-                        hit_j = j;
-                    }
-                    hit_c = fmaxf(hit_c, c);
-                } else {
-                    nanflag = nanflag || (ta != ta) || (tb != tb);
-                    float z = fminf(fminf(a.alpha * (ta - a.seg_lo), a.alpha * (a.seg_hi - ta)),
-                                    fminf(a.alpha * (tb - a.seg_lo), a.alpha * (a.seg_hi - tb)));
-                    if (GRAD && z > hit_z) {
-                        hit_i = i;
-                        hit_j = j;
-                    }
-                    hit_z = fmaxf(hit_z, z);
-                }
-            }
-        }
-        // decided lanes: occlusion already makes valid exactly 0
-        if (MODE == MODE_HARD) active = active && (!hit_b || bad);
-        else if (MODE == MODE_HSIG) active = active && (hit_c != 6.0f || bad);
-        else active = active && (hit_z < 17.5f || bad);
-        if (!wave_any(active)) break;
-    }
 
     // ---- is_valid, geometry.py:947-963 -----------------------------------------------------
     float valid;
@@ -965,6 +979,7 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     WaveStats st;
 #pragma unroll
     for (int i = 0; i < 10; ++i) st.c[i] = 0;
+    st.shadow = -1;
     // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index)
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt
     for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
@@ -1044,6 +1059,7 @@ __global__ void __launch_bounds__(64) power_vg_kernel(SweepArgs a) {
     g.scene = scene;
     float acc = 0.0f;
     WaveStats st;
+    st.shadow = -1;
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, GRADK, TXG>(a, txx, txy, rxx, rxy, lane_bad, acc, st, &g);
     if (a.min_order <= 1 && a.max_order >= 1) sweep_order<1, MODE, false, GRADK, TXG>(a, txx, txy, rxx, rxy, lane_bad, acc, st, &g);
     if (a.min_order <= 2 && a.max_order >= 2) sweep_order<2, MODE, false, GRADK, TXG>(a, txx, txy, rxx, rxy, lane_bad, acc, st, &g);
