@@ -70,7 +70,8 @@ class Params(C.Structure):
         ("steps", C.c_int32),
         ("out_mode", C.c_int32),
         ("grid_role", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("strict_nan", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 

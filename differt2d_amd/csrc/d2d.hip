@@ -679,6 +679,23 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
         if (p->out_mode == D2D_OUT_OVERWRITE) c->have_vjp = false;
         const size_t lds = (size_t)(4 * c->N + 4) * sizeof(float);
+        if (!txg && !p->strict_nan) {
+            // culled value+grad sweep (default)
+            const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4);
+            if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+#define D2D_LAUNCH_FWDG(MODE_)                                                                                              \
+    do {                                                                                                                    \
+        if (p->max_order <= 2) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 2, true>), grid, block, lds2, c->stream, a); \
+        else if (p->max_order == 3) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 3, true>), grid, block, lds2, c->stream, a); \
+        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 4, true>), grid, block, lds2, c->stream, a);            \
+    } while (0)
+            switch (mode) {
+                case d2d::MODE_HARD: D2D_LAUNCH_FWDG(d2d::MODE_HARD); break;
+                case d2d::MODE_HSIG: D2D_LAUNCH_FWDG(d2d::MODE_HSIG); break;
+                default: D2D_LAUNCH_FWDG(d2d::MODE_SIG); break;
+            }
+        } else
+        {
 #define D2D_LAUNCH_VG(MODE_)                                                                                             \
     do {                                                                                                                \
         if (txg) hipLaunchKernelGGL((d2d::power_vg_kernel<MODE_, true, true>), grid, block, lds, c->stream, a);         \
@@ -688,6 +705,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             case d2d::MODE_HARD: D2D_LAUNCH_VG(d2d::MODE_HARD); break;
             case d2d::MODE_HSIG: D2D_LAUNCH_VG(d2d::MODE_HSIG); break;
             default: D2D_LAUNCH_VG(d2d::MODE_SIG); break;
+        }
         }
         HIP_TRY(hipGetLastError());
         if (grad_mode == 2) {

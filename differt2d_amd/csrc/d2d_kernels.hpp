@@ -871,10 +871,10 @@ __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float
 }
 
 // All candidates of order K >= 1 with tile culling; `tab` = LDS copy of {refl[2N], flt[N]}.
-template <int K, int MODE, bool STATS>
+template <int K, int MODE, bool STATS, bool GRAD = false>
 __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                    const float (&by)[4], float rxx, float rxy, bool lane_bad, float& acc,
-                                                   WaveStats& st) {
+                                                   WaveStats& st, GradCtx* g = nullptr) {
     const int lane = threadIdx.x & 63;
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
     float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];
@@ -927,7 +927,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 mask &= mask - 1;
                 cand[K - 1] = a.cw[chunk * 64 + b];
                 image_of(a.refl[2 * cand[K - 1]], pIx, pIy, imgx[K - 1], imgy[K - 1]);
-                eval_candidate<K, MODE, STATS, false, false, false>(a, cand, imgx, imgy, a.txx, a.txy, rxx, rxy, lane_bad, acc, st);
+                eval_candidate<K, MODE, STATS, GRAD, false, false>(a, cand, imgx, imgy, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, g);
             }
         }
         // next prefix (lexicographic, no equal neighbours); static indexing keeps pos[] in registers
@@ -960,7 +960,11 @@ constexpr int TILE_H = 8;
 #ifndef D2D_FWD_WAVES
 #define D2D_FWD_WAVES 1  // minimum waves per SIMD asked of the register allocator (1 = unconstrained)
 #endif
-template <int MODE, bool STATS, int MAXK>
+// GRADK: also run the hand-derived adjoint of every surviving candidate (value + gradient in one sweep).  Culled
+// candidates contribute exactly 0 to the value and to every adjoint; what culling cannot reproduce are the
+// reference's autodiff NaN artefacts of candidates it never evaluates (see DESIGN.md "NaN parity"): those are
+// covered by the exhaustive power_vg_kernel (d2d_params.strict_nan).
+template <int MODE, bool STATS, int MAXK, bool GRADK = false>
 __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
@@ -981,10 +985,50 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     for (int i = 0; i < 10; ++i) st.c[i] = 0;
     st.shadow = -1;
     // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index)
-    extern __shared__ float4 tab[];  // [2N] refl, [N] flt
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
     for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
     for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    float* wl = reinterpret_cast<float*>(tab + 3 * a.N);
+    const bool scene = GRADK && a.partial != nullptr;
+    if (scene)
+        for (int i = lane; i < 4 * a.N; i += 64) wl[i] = 0.0f;
     __syncthreads();
+    GradCtx g;
+    g.grx = g.gry = g.tbx = g.tby = 0.0f;
+    g.cot = in_range ? (a.cot ? a.cot[idx] : 1.0f) : 0.0f;
+    g.wl = wl;
+    g.scene = scene;
+    if (GRADK && MODE != MODE_HARD && a.max_order >= 1) {
+        // A cell lying exactly on the supporting line of an allowed wall: every candidate ending on that wall has a
+        // zero-length last segment, and the reference's autodiff then returns NaN (sqrt'(0) * 0) whether or not the
+        // candidate is valid -- also for candidates the culling drops, hence this exhaustive (and cheap) check.
+        bool on_line = false;
+        bool poison_all = false;
+        const bool deep = a.max_order >= 2 && a.Nc >= 2;  // candidates (w0, .., w) exist for every other allowed w0
+        for (int i = 0; i < a.Nc; ++i) {
+            const float4 r0 = a.refl[2 * a.cw[i]];
+            float vx = r0.x - rxx, vy = r0.y - rxy;
+            const bool here = (vx * r0.z + vy * r0.w) == 0.0f;
+            on_line = on_line || here;
+            if (scene && wave_any(here)) {
+                poison_all = poison_all || deep;
+                if (lane == 0) {
+                    float* w4 = wl + 4 * a.cw[i];
+                    w4[0] = w4[1] = w4[2] = w4[3] = __builtin_nanf("");
+                }
+            }
+        }
+        if (wave_any(on_line)) {
+            const float qnan = __builtin_nanf("");
+            if (on_line) g.grx = g.gry = qnan;
+            if (scene && on_line) g.tbx = g.tby = qnan;
+            if (scene && poison_all && lane == 0)
+                for (int i = 0; i < a.Nc; ++i) {
+                    float* w4 = wl + 4 * a.cw[i];
+                    w4[0] = w4[1] = w4[2] = w4[3] = qnan;
+                }
+        }
+    }
     // bounding box of the wave's cells (NaN / inf coordinates make every comparison fail: nothing is culled)
     float x0 = rxx, x1 = rxx, y0 = rxy, y1 = rxy;
 #pragma unroll
@@ -998,14 +1042,35 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     const float qn = __builtin_nanf("");
     const float bx[4] = {box_ok ? x0 : qn, x1, x1, x0};
     const float by[4] = {y0, y0, y1, y1};
-    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st);
-    if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
-    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled<2, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
-    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled<3, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
-    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_culled<4, MODE, STATS>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st);
+    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, GRADK>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled<2, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled<3, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_culled<4, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
     if (in_range) {
-        if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
-        else a.out[idx] = acc;
+        if (a.out_mode == D2D_OUT_ADD) {
+            a.out[idx] = a.out[idx] + acc;
+            if (GRADK) {
+                a.grad[2 * idx] = a.grad[2 * idx] + g.grx;
+                a.grad[2 * idx + 1] = a.grad[2 * idx + 1] + g.gry;
+            }
+        } else {
+            a.out[idx] = acc;
+            if (GRADK) {
+                a.grad[2 * idx] = g.grx;
+                a.grad[2 * idx + 1] = g.gry;
+            }
+        }
+    }
+    if (scene) {
+        float sx = wave_sum(g.tbx), sy = wave_sum(g.tby);
+        __syncthreads();
+        float* dst = a.partial + (long)blockIdx.x * (4 * a.N + 2);
+        for (int i = lane; i < 4 * a.N; i += 64) dst[i] = wl[i];
+        if (lane == 0) {
+            dst[4 * a.N] = sx;
+            dst[4 * a.N + 1] = sy;
+        }
     }
     if (STATS && lane == 0 && a.stats) {
 #pragma unroll

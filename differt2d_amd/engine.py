@@ -42,6 +42,7 @@ def make_params(
     steps: int = 100,
     out_mode: int = L.OUT_OVERWRITE,
     grid_role: int = L.GRID_RX,
+    strict_nan: bool = False,
 ) -> L.Params:
     """Builds a ``d2d_params``; keyword names follow the reference's kwargs
     (scene.py:1803-1826, geometry.py:910-919, logic.py:258-267, utils.py:17-24)."""
@@ -58,6 +59,7 @@ def make_params(
     p.fun_id, p.r_coef, p.height = FUN_IDS[fun], float(r_coef), float(height)
     p.solver, p.steps, p.out_mode = SOLVER_IDS[solver], int(steps), int(out_mode)
     p.grid_role = int(grid_role)
+    p.strict_nan = int(bool(strict_nan))
     return p
 
 

@@ -86,7 +86,12 @@ typedef struct d2d_params {
                            D2D_GRID_TX: the grid cells are transmitters and the `tx` argument of the launch is the
                            fixed RECEIVER (accumulate_on_transmitters_grid_over_paths, differt2d/scene.py:1489-1648);
                            the per-cell gradient is then taken w.r.t. the transmitter (scene.py:1617-1620) */
-    int32_t reserved[3];
+    int32_t strict_nan; /* value+grad sweeps only. 0 (default): candidates that tile culling proves invalid are not
+                           evaluated; gradients are finite wherever the reference's are, and NaN where the reference's
+                           autodiff NaN artefacts come from an evaluated candidate or from a cell lying on a wall's
+                           supporting line. 1: every candidate of every cell is evaluated (about 4x slower) so that NaN
+                           positions coincide with the reference's in all cases (DESIGN.md "NaN parity") */
+    int32_t reserved[2];
 } d2d_params;
 
 typedef struct d2d_ctx d2d_ctx;

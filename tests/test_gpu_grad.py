@@ -47,10 +47,12 @@ def _kwargs(d):
     return kw
 
 
+@pytest.mark.parametrize("strict_nan", [False, True], ids=["culled", "strict"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
-def test_against_golden_fixtures(ctx, path):
+def test_against_golden_fixtures(ctx, path, strict_nan):
+    """Both value+grad kernels: the default one (tile culling) and the exhaustive one (d2d_params.strict_nan)."""
     d = np.load(path)
-    kw = _kwargs(d)
+    kw = dict(_kwargs(d), strict_nan=strict_nan)
     ctx.set_scene(d["walls"])
     got = ctx.value_and_grads(d["tx"], d["X"], d["Y"], **kw)
     if kw.get("function") == "sigmoid":
@@ -66,9 +68,10 @@ def test_against_golden_fixtures(ctx, path):
     _close(got["walls_bar"], d["walls_bar_cot"], "walls_bar (cotangent)")
 
 
+@pytest.mark.parametrize("strict_nan", [False, True], ids=["culled", "strict"])
 @pytest.mark.parametrize("approx,function", [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")])
 @pytest.mark.parametrize("fun", ["received_power", "length_squared", "length"])
-def test_against_live_autodiff(ctx, approx, function, fun):
+def test_against_live_autodiff(ctx, approx, function, fun, strict_nan):
     from oracle import ref as R
 
     tx, walls = random_scene(10, seed=17)
@@ -76,7 +79,7 @@ def test_against_live_autodiff(ctx, approx, function, fun):
     kw = dict(min_order=0, max_order=2, approx=approx, function=function, fun=fun)
     want = R.power_map_value_and_grads(walls, tx, X, Y, dtype="float64", **kw)
     ctx.set_scene(walls)
-    got = ctx.value_and_grads(tx, X, Y, **kw)
+    got = ctx.value_and_grads(tx, X, Y, strict_nan=strict_nan, **kw)
     np.testing.assert_allclose(got["value"], want["value"], rtol=2e-5, atol=1e-5)
     for k in ("grad_rx", "tx_bar", "walls_bar"):
         _close(got[k], want[k], k)
@@ -90,12 +93,13 @@ def test_value_map_of_vg_kernel_is_bit_identical_to_forward(ctx):
     ctx.set_scene(walls)
     ctx.set_grid(X, Y)
     for approx in (False, True):
-        p = make_params(max_order=2, approx=approx)
-        ctx.launch(p, tx)
-        a = ctx.get_map()
-        ctx.launch_vg(p, tx, scene_vjp=True)
-        b = ctx.get_map()
-        assert np.array_equal(a, b)
+        for strict in (False, True):
+            p = make_params(max_order=2, approx=approx, strict_nan=strict)
+            ctx.launch(p, tx)
+            a = ctx.get_map()
+            ctx.launch_vg(p, tx, scene_vjp=True)
+            b = ctx.get_map()
+            assert np.array_equal(a, b)
 
 
 def test_los_gradients_analytic(ctx):
@@ -126,3 +130,18 @@ def test_reduce_all_accumulates_gradients(ctx):
     np.testing.assert_array_equal(ctx.get_grad_rx(), a["grad_rx"] + b["grad_rx"])
     _, wb = ctx.get_scene_vjp()
     np.testing.assert_allclose(wb, a["walls_bar"] + b["walls_bar"], rtol=1e-5, atol=1e-4)
+
+
+def test_culled_and_strict_gradients_agree_on_a_larger_grid(ctx):
+    """cfg3-like: 50 walls, orders 0..2, 128 x 128 cells: the culled kernel drops 85 % of the candidates and must
+    reproduce the exhaustive kernel's gradients (no NaN artefacts in this generic-position scene)."""
+    tx, walls = random_scene(50, seed=1234)
+    X, Y = unit_grid(128)
+    ctx.set_scene(walls)
+    for approx in (False, True):
+        a = ctx.value_and_grads(tx, X, Y, max_order=2, approx=approx, strict_nan=False)
+        b = ctx.value_and_grads(tx, X, Y, max_order=2, approx=approx, strict_nan=True)
+        assert np.array_equal(a["value"], b["value"])
+        assert np.array_equal(a["grad_rx"], b["grad_rx"], equal_nan=True)
+        for k in ("tx_bar", "walls_bar"):
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-6 * np.abs(b[k]).max())
