@@ -12,7 +12,10 @@
 #include <vector>
 
 #include "../../include/d2d.h"
-#include "d2d_kernels.hpp"
+#ifndef D2D_KERNELS_HPP
+#define D2D_KERNELS_HPP "d2d_kernels.hpp"
+#endif
+#include D2D_KERNELS_HPP
 
 namespace {
 
@@ -716,7 +719,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
         return D2D_OK;
     }
-    const size_t tab_lds = (size_t)(3 * c->N + 1) * sizeof(float4);
+    const size_t tab_lds = (size_t)(4 * c->N + 1) * sizeof(float4);
     if (tab_lds > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~1300)", c->N);
 #define D2D_LAUNCH_FWD(MODE_, STATS_, MAXK_) \
     hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, STATS_, MAXK_>), grid, block, tab_lds, c->stream, a)

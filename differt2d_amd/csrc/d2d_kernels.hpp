@@ -811,7 +811,8 @@ __device__ __forceinline__ bool s_range(const float (&qx)[4], const float (&qy)[
     smin = __builtin_inff();
     smax = -__builtin_inff();
     E = 0.0f;
-#pragma unroll
+    // partial unroll: the fully unrolled body needs ~35 more VGPRs (85 vs 51) and caps the kernel at 5 waves per SIMD
+#pragma unroll 2
     for (int j = 0; j < 4; ++j) {
         float ux = qx[j] - Ix, uy = qy[j] - Iy;
         float vx = w.ox - qx[j], vy = w.oy - qy[j];
