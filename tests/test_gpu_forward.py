@@ -193,3 +193,43 @@ def test_scaled_and_shifted_scenes(ctx, approx, function, scale, offset):
     ctx.set_scene(walls)
     kw = dict(min_order=0, max_order=2, approx=approx, function=function, height=float(0.1 * scale))
     _compare(ctx.power_map(tx, X, Y, **kw), _oracle(walls, tx, X, Y, **kw), function)
+
+
+@pytest.mark.parametrize("approx,function", MODES[:2])
+def test_cfg4_scene_200_walls_small_grid(ctx, approx, function):
+    """BASELINE.json configs[3] scene (200 random walls, NumPy seed 1234): orders 0..2 on a 16 x 12 patch of the 2048^2 grid
+    (39 801 candidates per cell), and order 3 restricted to 12 candidate walls (filter_objects) so that the oracle finishes."""
+    tx, walls = random_scene(200, seed=1234)
+    x = np.linspace(0.0, 1.0, 2048).astype(F)
+    X, Y = np.meshgrid(x[1000:1016], x[400:412])
+    ctx.set_scene(walls)
+    kw = dict(min_order=0, max_order=2, approx=approx, function=function)
+    _compare(ctx.power_map(tx, X, Y, **kw), _oracle(walls, tx, X, Y, **kw), function)
+    allowed = np.zeros(200, np.uint8)
+    allowed[::17] = 1
+    ctx.set_candidate_mask(allowed)
+    kw = dict(min_order=3, max_order=3, approx=approx, function=function)
+    got = ctx.power_map(tx, X, Y, **kw)
+    ctx.set_candidate_mask(None)
+    _compare(got, _oracle(walls, tx, X, Y, allowed=allowed, **kw), function)
+
+
+def test_bad_inputs_are_rejected_or_propagated(ctx):
+    from differt2d_amd import _lib as L
+
+    with pytest.raises(L.D2DError):
+        ctx.set_scene(np.array([[[0.0, np.nan], [1.0, 0.0]]], F))
+    with pytest.raises(ValueError):
+        ctx.set_grid(np.zeros((3, 4), F), np.zeros((4, 3), F))
+    with pytest.raises((L.D2DError, ValueError)):
+        ctx.set_grid(np.zeros((0, 4), F), np.zeros((0, 4), F))
+    # NaN / inf receiver coordinates: the cell's value is NaN like the reference's, its neighbours are untouched
+    tx, walls = random_scene(9, seed=5)
+    X, Y = unit_grid(16, 8)
+    X = X.copy()
+    X[3, 5] = np.nan
+    X[6, 1] = np.inf
+    ctx.set_scene(walls)
+    got = ctx.power_map(tx, X, Y, max_order=2)
+    want = _oracle(walls, tx, X, Y, max_order=2)
+    assert np.isnan(got[3, 5]) and np.array_equal(got, want, equal_nan=True)
