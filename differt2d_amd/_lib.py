@@ -71,7 +71,8 @@ class Params(C.Structure):
         ("out_mode", C.c_int32),
         ("grid_role", C.c_int32),
         ("strict_nan", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("many", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 

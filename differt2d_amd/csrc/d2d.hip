@@ -214,7 +214,8 @@ d2d::ObjTables obj_tables(d2d_ctx* c) {
 // in double precision and rounded to fp32 (the oracle does the same).
 int adam_cfg(d2d_ctx* c, const d2d_params* p, d2d::AdamCfg* A) {
     const int steps = p->steps;
-    if (steps < 0 || steps > 1000000) return fail(D2D_ERR_INVALID, "steps must lie in 0..1e6, got %d", steps);
+    if (steps < 1 || steps > 1000000) return fail(D2D_ERR_INVALID, "steps must lie in 1..1e6, got %d", steps);
+    if (p->many < 0 || p->many > 4096) return fail(D2D_ERR_INVALID, "many must lie in 0..4096, got %d", p->many);
     if (c->bc_steps != steps) {
         std::vector<float> b1((size_t)steps + 1), b2((size_t)steps + 1);
         for (int t = 1; t <= steps; ++t) {
@@ -232,6 +233,7 @@ int adam_cfg(d2d_ctx* c, const d2d_params* p, d2d::AdamCfg* A) {
     }
     A->solver = p->solver;
     A->steps = steps;
+    A->many = p->many > 1 ? p->many : 1;
     A->bc1 = c->d_bc1.p;
     A->bc2 = c->d_bc2.p;
     A->lr = 0.1f;
@@ -536,11 +538,12 @@ static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx) {
     for (int64_t i = 0; i < C; ++i)
         for (int q = 0; q < order[(size_t)i]; ++q)
             if (c->kind[cand[(size_t)i * D2D_MAX_ORDER + q]] != D2D_VERTEX) need_theta = true;
-    if (need_theta && (int64_t)c->theta0.size() != C * D2D_MAX_ORDER)
-        return fail(D2D_ERR_STATE, "d2d_set_theta0 must provide %lld x %d initial guesses for this sweep (got %zu values)",
-                    (long long)C, D2D_MAX_ORDER, c->theta0.size());
-    std::vector<float> th((size_t)C * D2D_MAX_ORDER + 1, 0.0f);
-    if ((int64_t)c->theta0.size() == C * D2D_MAX_ORDER) std::copy(c->theta0.begin(), c->theta0.end(), th.begin());
+    const int64_t many = p->many > 1 ? p->many : 1;
+    if (need_theta && (int64_t)c->theta0.size() != C * many * D2D_MAX_ORDER)
+        return fail(D2D_ERR_STATE, "d2d_set_theta0 must provide %lld x %lld x %d initial guesses for this sweep (got %zu values)",
+                    (long long)C, (long long)many, D2D_MAX_ORDER, c->theta0.size());
+    std::vector<float> th((size_t)(C * many) * D2D_MAX_ORDER + 1, 0.0f);
+    if ((int64_t)c->theta0.size() == C * many * D2D_MAX_ORDER) std::copy(c->theta0.begin(), c->theta0.end(), th.begin());
     if ((rc = c->d_scand.ensure(cand.size())) || (rc = c->d_sorder.ensure(order.size())) || (rc = c->d_theta0.ensure(th.size()))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_scand.p, cand.data(), cand.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_sorder.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -830,10 +833,10 @@ int d2d_power_map_stats(d2d_ctx* c, const d2d_params* p, const float* tx, uint64
     return D2D_OK;
 }
 
-int d2d_set_theta0(d2d_ctx* c, const float* theta0, int64_t n_candidates) {
+int d2d_set_theta0(d2d_ctx* c, const float* theta0, int64_t n_rows) {
     if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
-    if (n_candidates < 0 || (n_candidates > 0 && !theta0)) return fail(D2D_ERR_INVALID, "bad theta0 arguments");
-    c->theta0.assign(theta0, theta0 + n_candidates * D2D_MAX_ORDER);
+    if (n_rows < 0 || (n_rows > 0 && !theta0)) return fail(D2D_ERR_INVALID, "bad theta0 arguments");
+    c->theta0.assign(theta0, theta0 + n_rows * D2D_MAX_ORDER);
     return D2D_OK;
 }
 
@@ -891,9 +894,10 @@ int d2d_trace_paths(d2d_ctx* c, const d2d_params* p, const float* tx, const floa
     a.solver = p->solver;
     if (opt) {
         if ((rc = adam_cfg(c, p, &a.A))) return rc;
-        if ((rc = c->d_theta0.ensure((size_t)C * D2D_MAX_ORDER + 1))) return rc;
-        if (theta0) HIP_TRY(hipMemcpyAsync(c->d_theta0.p, theta0, (size_t)C * D2D_MAX_ORDER * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        else HIP_TRY(hipMemsetAsync(c->d_theta0.p, 0, (size_t)C * D2D_MAX_ORDER * sizeof(float), c->stream));
+        const size_t nth = (size_t)C * (size_t)a.A.many * D2D_MAX_ORDER;
+        if ((rc = c->d_theta0.ensure(nth + 1))) return rc;
+        if (theta0) HIP_TRY(hipMemcpyAsync(c->d_theta0.p, theta0, nth * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        else HIP_TRY(hipMemsetAsync(c->d_theta0.p, 0, nth * sizeof(float), c->stream));
         a.theta0 = c->d_theta0.p;
     }
     a.cand = c->d_tcand.p;

@@ -1370,6 +1370,7 @@ __device__ __forceinline__ void image_solve(const ObjTables& T, int k, const int
 struct AdamCfg {
     int solver;  // D2D_SOLVER_MINPATH or D2D_SOLVER_FERMAT
     int steps;
+    int many;    // number of random starts; the start whose recorded loss is smallest wins (optimize.py:136-182)
     const float* __restrict__ bc1;  // [steps] 1 - b1^t
     const float* __restrict__ bc2;  // [steps] 1 - b2^t
     float lr, b1, b2, eps;
@@ -1500,11 +1501,12 @@ __device__ __forceinline__ float objective_grad(const ObjTables& T, int solver, 
     return loss;
 }
 
-// Returns the path points and the loss the reference attaches to the path.
-__device__ __forceinline__ float opt_solve(const ObjTables& T, const AdamCfg& A, int k, const int (&cd)[D2D_MAX_ORDER],
-                                           const float (&theta0)[D2D_MAX_ORDER], float txx, float txy, float rxx, float rxy,
-                                           float (&px)[NP], float (&py)[NP]) {
-    float th[D2D_MAX_ORDER], mu[D2D_MAX_ORDER], nu[D2D_MAX_ORDER], g[D2D_MAX_ORDER];
+// One Adam run from theta0: final theta in `th`, returns the objective recorded at the last step (before the last update).
+__device__ __forceinline__ float opt_run(const ObjTables& T, const AdamCfg& A, int k, const int (&cd)[D2D_MAX_ORDER],
+                                         const float* __restrict__ theta0, float txx, float txy, float rxx, float rxy,
+                                         float (&th)[D2D_MAX_ORDER]) {
+    float px[NP], py[NP];
+    float mu[D2D_MAX_ORDER], nu[D2D_MAX_ORDER], g[D2D_MAX_ORDER];
     int nu_ = 0;
 #pragma unroll
     for (int i = 0; i < D2D_MAX_ORDER; ++i) {
@@ -1527,9 +1529,25 @@ __device__ __forceinline__ float opt_solve(const ObjTables& T, const AdamCfg& A,
             }
         }
     }
-    theta_to_points(T, k, cd, th, txx, txy, rxx, rxy, px, py);
+    return last;
+}
+
+// Returns the path points and the loss the reference attaches to the path. theta0: [many][D2D_MAX_ORDER].
+__device__ __forceinline__ float opt_solve(const ObjTables& T, const AdamCfg& A, int k, const int (&cd)[D2D_MAX_ORDER],
+                                           const float* __restrict__ theta0, float txx, float txy, float rxx, float rxy,
+                                           float (&px)[NP], float (&py)[NP]) {
+    float best[D2D_MAX_ORDER], th[D2D_MAX_ORDER];
+    float best_loss = opt_run(T, A, k, cd, theta0, txx, txy, rxx, rxy, best);
+    for (int m = 1; m < A.many; ++m) {  // jnp.argmin: the first minimum wins; NaN losses win like in jnp.argmin
+        float l = opt_run(T, A, k, cd, theta0 + m * D2D_MAX_ORDER, txx, txy, rxx, rxy, th);
+        const bool better = (l < best_loss) || (l != l && best_loss == best_loss);
+        best_loss = better ? l : best_loss;
+#pragma unroll
+        for (int q = 0; q < D2D_MAX_ORDER; ++q) best[q] = better ? th[q] : best[q];
+    }
+    theta_to_points(T, k, cd, best, txx, txy, rxx, rxy, px, py);
     if (A.solver == D2D_SOLVER_FERMAT) return interaction_loss(T, k, cd, px, py);  // geometry.py:1204
-    return last;                                                                    // geometry.py:1284-1288
+    return best_loss;                                                               // geometry.py:1284-1288
 }
 
 struct TraceArgs {
@@ -1583,10 +1601,7 @@ __global__ void __launch_bounds__(64) trace_kernel(TraceArgs a) {
     } else if (k == 0) {
         image_solve(a.T, 0, cd, txx, txy, rxx, rxy, px, py);  // geometry.py:1178-1180 / 1268-1270
     } else {
-        float th0[D2D_MAX_ORDER];
-#pragma unroll
-        for (int i = 0; i < D2D_MAX_ORDER; ++i) th0[i] = a.theta0[c * D2D_MAX_ORDER + i];
-        loss = opt_solve(a.T, a.A, k, cd, th0, txx, txy, rxx, rxy, px, py);
+        loss = opt_solve(a.T, a.A, k, cd, a.theta0 + (long)c * a.A.many * D2D_MAX_ORDER, txx, txy, rxx, rxy, px, py);
     }
     float on, hit, valid;
     literal_validity(a.T, L, k, cd, px, py, loss, a.tol, a.seg_lo, a.seg_hi, on, hit, valid);
@@ -1637,12 +1652,9 @@ __global__ void __launch_bounds__(64) power_opt_kernel(OptSweepArgs a) {
     for (int c = 0; c < a.C; ++c) {
         const int k = a.order[c];
         int cd[D2D_MAX_ORDER];
-        float th0[D2D_MAX_ORDER];
 #pragma unroll
-        for (int i = 0; i < D2D_MAX_ORDER; ++i) {
-            cd[i] = a.cand[c * D2D_MAX_ORDER + i];
-            th0[i] = a.theta0[c * D2D_MAX_ORDER + i];
-        }
+        for (int i = 0; i < D2D_MAX_ORDER; ++i) cd[i] = a.cand[c * D2D_MAX_ORDER + i];
+        const float* th0 = a.theta0 + (long)c * a.A.many * D2D_MAX_ORDER;
         float px[NP], py[NP];
         float loss = 0.0f;
         if (k == 0) image_solve(a.T, 0, cd, txx, txy, rxx, rxy, px, py);

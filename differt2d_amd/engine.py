@@ -43,6 +43,7 @@ def make_params(
     out_mode: int = L.OUT_OVERWRITE,
     grid_role: int = L.GRID_RX,
     strict_nan: bool = False,
+    many: int = 1,
 ) -> L.Params:
     """Builds a ``d2d_params``; keyword names follow the reference's kwargs
     (scene.py:1803-1826, geometry.py:910-919, logic.py:258-267, utils.py:17-24)."""
@@ -60,6 +61,7 @@ def make_params(
     p.solver, p.steps, p.out_mode = SOLVER_IDS[solver], int(steps), int(out_mode)
     p.grid_role = int(grid_role)
     p.strict_nan = int(bool(strict_nan))
+    p.many = int(many)
     return p
 
 
@@ -266,7 +268,7 @@ class Context:
             loss_in = np.ascontiguousarray(loss_in, dtype=np.float32).reshape(P, Cn)
         th = None
         if theta0 is not None:
-            th = np.zeros((max(Cn, 1), L.D2D_MAX_ORDER), np.float32)
+            th = np.zeros((max(len(theta0), 1), L.D2D_MAX_ORDER), np.float32)
             for i, row in enumerate(theta0):
                 row = np.asarray(row, np.float32).reshape(-1)
                 th[i, : row.size] = row

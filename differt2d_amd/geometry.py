@@ -422,19 +422,20 @@ class ImagePath(Path):
         return cls(xys=out["xys"][0, 0, : k + 2], loss=out["loss"][0, 0])
 
 
-def draw_theta0(objects_per_candidate, key, theta0=None):
-    """Initial parametric guesses, one row per candidate: ``U[0, 1)`` per unknown (reference optimize.py:132).
+def draw_theta0(objects_per_candidate, key, theta0=None, many: int = 1):
+    """Initial parametric guesses: ``many`` consecutive rows per candidate, ``U[0, 1)`` per unknown (reference
+    optimize.py:132, 174-178).
 
-    The reference splits ``key`` into one Threefry key per candidate (scene.py:1887-1888); JAX's PRNG is not
-    available here, so a NumPy generator seeded by ``key`` draws the rows in candidate order instead -- same
-    distribution, different numbers.  Pass ``theta0`` explicitly for reproducible comparisons."""
+    The reference splits ``key`` into one Threefry key per candidate (scene.py:1887-1888) and, for ``many > 1``, once
+    more per start; JAX's PRNG is not available here, so a NumPy generator seeded by ``key`` draws the rows in order
+    instead -- same distribution, different numbers.  Pass ``theta0`` explicitly for reproducible comparisons."""
     from .abc import key_to_generator
 
-    counts = [sum(o.parameters_count() for o in objs) for objs in objects_per_candidate]
+    counts = [sum(o.parameters_count() for o in objs) for objs in objects_per_candidate for _ in range(many)]
     if theta0 is not None:
         rows = [np.asarray(r, F).reshape(-1) for r in theta0]
         if len(rows) != len(counts) or any(r.size < c for r, c in zip(rows, counts)):
-            raise ValueError("theta0 must hold one row per candidate with at least as many values as unknowns")
+            raise ValueError("theta0 must hold `many` rows per candidate with at least as many values as unknowns")
         return rows
     if key is None:
         raise TypeError("this path class needs a `key` (or explicit `theta0`) to draw its initial guess")
@@ -443,17 +444,18 @@ def draw_theta0(objects_per_candidate, key, theta0=None):
 
 
 def _opt_kwargs(kwargs):
+    """(steps, many, theta0) from ``path_cls_kwargs`` (reference optimize.py:44-52, 136-143)."""
     kw = dict(kwargs)
     steps = int(kw.pop("steps", 100))
     many = int(kw.pop("many", 1))
     theta0 = kw.pop("theta0", None)
-    if many != 1:
-        raise L.D2DUnsupported(-4, "many != 1 (best of several random starts) is not implemented natively")
+    if many < 1:
+        raise ValueError("many must be >= 1")
     if kw.pop("optimizer", None) is not None:
         raise L.D2DUnsupported(-4, "only the default optimiser (optax.adam(0.1)) is implemented natively")
     if kw:
         raise TypeError(f"unexpected keyword arguments: {sorted(kw)}")
-    return steps, theta0
+    return steps, many, theta0
 
 
 class _OptPath(Path):
@@ -465,11 +467,13 @@ class _OptPath(Path):
 
         objects = list(objects)
         k = len(objects)
-        steps, theta0 = _opt_kwargs(kwargs)
-        th = draw_theta0([objects], key, None if theta0 is None else [theta0]) if k else [np.zeros(0, F)]
+        steps, many, theta0 = _opt_kwargs(kwargs)
+        if theta0 is not None and many == 1 and np.ndim(theta0) == 1:
+            theta0 = [theta0]
+        th = draw_theta0([objects], key, theta0, many) if k else [np.zeros(0, F)] * many
         ctx = default_context()
         ctx.set_scene(*objects_to_tables(objects))
-        p = make_params(max_order=L.D2D_MAX_ORDER, solver=cls.solver, steps=steps)
+        p = make_params(max_order=L.D2D_MAX_ORDER, solver=cls.solver, steps=steps, many=many)
         out = ctx.trace_paths(p, _xy(tx), _xy(rx), [np.arange(k, dtype=np.int32)], theta0=th)
         return cls(xys=out["xys"][0, 0, : k + 2], loss=out["loss"][0, 0])
 

@@ -91,7 +91,9 @@ typedef struct d2d_params {
                            autodiff NaN artefacts come from an evaluated candidate or from a cell lying on a wall's
                            supporting line. 1: every candidate of every cell is evaluated (about 4x slower) so that NaN
                            positions coincide with the reference's in all cases (DESIGN.md "NaN parity") */
-    int32_t reserved[2];
+    int32_t many;       /* differt2d/optimize.py:142: random starts per candidate of MinPath / FermatPath, best recorded loss
+                           wins (0 or 1 = one start; the path classes default to 1, differt2d/geometry.py:1198, 1282) */
+    int32_t reserved[1];
 } d2d_params;
 
 typedef struct d2d_ctx d2d_ctx;
@@ -145,10 +147,11 @@ int d2d_list_candidates(d2d_ctx* ctx, int32_t min_order, int32_t max_order, int3
  * output maps; the value map is zeroed. */
 int d2d_set_grid(d2d_ctx* ctx, const float* X, const float* Y, int32_t m, int32_t n);
 
-/* Initial guesses of the optimiser-based solvers for the NEXT sweeps: theta0[n_candidates][D2D_MAX_ORDER], one row per
- * candidate in enumeration order (unused entries ignored); every RX cell starts from the same guess, as in the
- * reference (differt2d/scene.py:1887-1890, optimize.py:132). */
-int d2d_set_theta0(d2d_ctx* ctx, const float* theta0, int64_t n_candidates);
+/* Initial guesses of the optimiser-based solvers for the NEXT sweeps: theta0[n_candidates * many][D2D_MAX_ORDER]
+ * (n_rows = n_candidates * max(1, params->many)), candidates in enumeration order, the `many` starts of one candidate
+ * consecutive (unused entries ignored); every RX cell starts from the same guesses, as in the reference
+ * (differt2d/scene.py:1887-1890, optimize.py:132, 174-178). */
+int d2d_set_theta0(d2d_ctx* ctx, const float* theta0, int64_t n_rows);
 
 /* Launches the fused forward sweep for transmitter tx[2] on the ctx stream (asynchronous).
  * Inputs and outputs stay resident in HBM. params->solver selects ImagePath (fused image-method kernel) or
@@ -206,7 +209,7 @@ int d2d_power_map(d2d_ctx* ctx, const d2d_params* params, const float* tx, const
  * xys_in[P][C][D2D_MAX_ORDER+2][2] and losses loss_in[P][C] (NULL = 0)) and evaluates it against the
  * current scene. Outputs (row-major, [P][C] leading): xys[..][D2D_MAX_ORDER+2][2] (unused rows NaN),
  * loss, valid (is_valid after nan_to_num; 0/1 in hard mode), and optionally on (on_objects),
- * hit (intersects_with_objects) and length (path_length). theta0[C][D2D_MAX_ORDER] = initial parametric
+ * hit (intersects_with_objects) and length (path_length). theta0[C * max(1, many)][D2D_MAX_ORDER] = initial parametric
  * coordinates of the optimiser-based solvers (MinPath geometry.py:1207-1288, FermatPath :1117-1204; the reference
  * draws them from a per-candidate PRNG key shared by all pairs, scene.py:1887-1890); NULL for ImagePath. Synchronous. */
 int d2d_trace_paths(d2d_ctx* ctx, const d2d_params* params, const float* tx, const float* rx, int32_t P,

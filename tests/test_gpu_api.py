@@ -289,7 +289,7 @@ def test_unsupported_is_loud():
         scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, key=1, grad=True)
     with pytest.raises(L.D2DUnsupported):
         scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, key=1,
-                                                      path_cls_kwargs={"many": 10})
+                                                      path_cls_kwargs={"optimizer": object()})
     with pytest.raises(L.D2DUnsupported):
         scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, function=lambda x, a: x, approx=True)
 

@@ -148,3 +148,29 @@ def test_missing_key_is_an_error():
     X, Y = scene.grid(n=4)
     with pytest.raises(TypeError):
         scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, order=1, reduce_all=True)
+
+
+def test_many_random_starts_pick_the_best():
+    """reference optimize.py:136-182: the start with the smallest recorded loss wins (first one on ties)."""
+    from differt2d_amd.geometry import MinPath, Point, Wall
+    from differt2d_amd.utils import received_power
+
+    wall = Wall(xys=[[0.0, 0.0], [2.0, 0.0]])
+    tx, rx = Point(xy=[0.0, 1.0]), Point(xy=[2.0, 1.0])
+    starts = [[0.9], [0.05], [0.5]]
+    singles = [MinPath.from_tx_objects_rx(tx, [wall], rx, steps=30, theta0=s) for s in starts]
+    best = min(range(3), key=lambda i: float(singles[i].loss))
+    multi = MinPath.from_tx_objects_rx(tx, [wall], rx, steps=30, many=3, theta0=starts)
+    assert np.array_equal(multi.xys, singles[best].xys) and multi.loss == singles[best].loss
+    # and through a sweep: many=3 with three identical starts equals many=1
+    scene = _ris_scene()
+    X, Y = scene.grid(m=8, n=6)
+    cands = scene.all_path_candidates(order=1)
+    rng = np.random.default_rng(0)
+    th1 = [rng.random(sum(o.parameters_count() for o in scene.get_interacting_objects(c)), dtype=F) for c in cands]
+    th3 = [t for t in th1 for _ in range(3)]
+    a = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, order=1, reduce_all=True,
+                                                      path_cls_kwargs={"steps": 50, "theta0": th1})
+    b = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, order=1, reduce_all=True,
+                                                      path_cls_kwargs={"steps": 50, "many": 3, "theta0": th3})
+    assert np.array_equal(a, b)
