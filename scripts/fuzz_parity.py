@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Randomised differential test (GPU box): HIP sweep vs the C oracle on random scenes, bit for bit (hard / hard_sigmoid)
+or within rtol 2e-5 (sigmoid).  Scenes mix random walls with axis-aligned walls at "nice" coordinates and grids that hit
+them exactly, shared end points (corners), tiny / huge scales, offsets, patch, alpha, tol, filters, orders 0..3.
+
+usage: python scripts/fuzz_parity.py [n_cases] [seed]
+"""
+
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from differt2d_amd.engine import Context  # noqa: E402
+from oracle import c_oracle as CO  # noqa: E402
+
+F = np.float32
+
+
+def random_case(rng):
+    n = int(rng.integers(0, 26))
+    kind = rng.integers(0, 4)
+    pts = rng.random((2 * n + 1, 2), dtype=F)
+    walls = pts[1:].reshape(n, 2, 2).copy()
+    if kind >= 1 and n:  # snap some end points to a coarse lattice: axis-aligned / collinear / touching walls
+        m = rng.random(walls.shape) < 0.5
+        walls = np.where(m, np.round(walls * 4) / 4, walls).astype(F)
+    if kind >= 2 and n > 1:  # share end points (corners)
+        for _ in range(n // 2):
+            i, j = rng.integers(0, n, 2)
+            walls[i, 1] = walls[j, 0]
+    tx = pts[0].copy()
+    if rng.random() < 0.3:
+        tx = (np.round(tx * 4) / 4).astype(F)
+    gx, gy = int(rng.integers(1, 41)), int(rng.integers(1, 41))
+    lo, hi = (-0.25, 1.25) if rng.random() < 0.3 else (0.0, 1.0)
+    X, Y = np.meshgrid(np.linspace(lo, hi, gx).astype(F), np.linspace(lo, hi, gy).astype(F))
+    scale = F(10.0 ** rng.integers(-3, 4)) if rng.random() < 0.3 else F(1.0)
+    off = F(rng.choice([0.0, 0.0, 7.0, -300.0]))
+    walls, tx, X, Y = walls * scale + off, tx * scale + off, X * scale + off, Y * scale + off
+    mode = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")][int(rng.integers(0, 3))]
+    max_order = int(rng.integers(0, 4)) if n <= 12 else int(rng.integers(0, 3))
+    min_order = int(rng.integers(0, max_order + 1))
+    kw = dict(min_order=min_order, max_order=max_order, approx=mode[0], function=mode[1],
+              alpha=float(rng.choice([100.0, 50.0, 10.0, 1000.0])), tol=float(rng.choice([1e-2, 1e-3, 0.5])),
+              patch=float(rng.choice([0.0, 0.0, 0.02, -0.05])), fun=str(rng.choice(["received_power", "one", "length"])),
+              height=float(0.1 * scale))
+    allowed = None
+    if n and rng.random() < 0.25:
+        allowed = (rng.random(n) < 0.7).astype(np.uint8)
+    return walls, tx, X, Y, kw, allowed
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    bad = 0
+    t0 = time.time()
+    with Context(0) as ctx:
+        for case in range(n_cases):
+            walls, tx, X, Y, kw, allowed = random_case(rng)
+            ctx.set_scene(walls)
+            ctx.set_candidate_mask(allowed)
+            got = ctx.power_map(tx, X, Y, **kw)
+            want = CO.power_map(walls, tx, X, Y, allowed=allowed, prune=True, **kw)
+            if kw["function"] == "sigmoid" and kw["approx"]:
+                ok = np.allclose(got, want, rtol=2e-5, atol=1e-5 * max(1.0, float(np.nanmax(np.abs(want)))), equal_nan=True)
+            else:
+                ok = np.array_equal(got, want, equal_nan=True)
+            if not ok:
+                bad += 1
+                d = np.abs(got - want)
+                print(f"MISMATCH case {case} seed {seed}: N={len(walls)} grid={X.shape} kw={kw} allowed={allowed is not None} "
+                      f"cells={int((~np.isclose(got, want, rtol=0, atol=0, equal_nan=True)).sum())} max={np.nanmax(d)}", flush=True)
+    print(f"fuzz: {n_cases} cases, {bad} mismatches, {time.time() - t0:.1f} s (seed {seed})")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
