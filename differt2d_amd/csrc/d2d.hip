@@ -106,7 +106,9 @@ struct d2d_ctx {
     int m = 0, n = 0;
     bool have_grid = false;
     DevBuf<float> d_X, d_Y, d_out;
-    DevBuf<unsigned long long> d_stats;
+    DevBuf<unsigned long long> d_stats, d_shadow;
+    float grid_absmax = 0.0f;   // max |coordinate| of the grid (host scan at d2d_set_grid)
+    float scene_absmax = 0.0f;  // max |coordinate| of the objects
     // value+grad
     DevBuf<float> d_grad, d_cot, d_partial;
     DevBuf<double> d_vjp;
@@ -385,6 +387,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_Y.release();
     c->d_out.release();
     c->d_stats.release();
+    c->d_shadow.release();
     c->d_grad.release(); c->d_cot.release(); c->d_partial.release(); c->d_vjp.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -409,6 +412,8 @@ int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float
         if (!(std::fabs(xys[i]) < 1e18f)) return fail(D2D_ERR_INVALID, "object coordinate %zu is not finite (or >= 1e18)", i);
     c->N = n_objects;
     c->xys.assign(xys, xys + 4 * (size_t)n_objects);
+    c->scene_absmax = 0.0f;
+    for (size_t i = 0; i < 4 * (size_t)n_objects; ++i) c->scene_absmax = std::fmax(c->scene_absmax, std::fabs(xys[i]));
     c->kind.assign((size_t)n_objects, (uint8_t)D2D_WALL);
     if (kind) c->kind.assign(kind, kind + n_objects);
     for (int j = 0; j < n_objects; ++j)
@@ -516,6 +521,12 @@ int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t 
     HIP_TRY(hipMemcpyAsync(c->d_Y.p, Y, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_out.p, 0, cells * sizeof(float), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->grid_absmax = 0.0f;
+    for (size_t i = 0; i < cells; ++i) {
+        const float ax = std::fabs(X[i]), ay = std::fabs(Y[i]);
+        if (ax > c->grid_absmax) c->grid_absmax = ax;  // NaN compares false: such cells are handled by the kernel
+        if (ay > c->grid_absmax) c->grid_absmax = ay;
+    }
     c->m = m;
     c->n = n;
     c->have_grid = true;
@@ -632,6 +643,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         mode = (p->act == D2D_ACT_HARD_SIGMOID) ? d2d::MODE_HSIG : d2d::MODE_SIG;
         widen = ((mode == d2d::MODE_HSIG) ? 3.0 : 89.0) / (double)p->alpha;
     }
+    const double widen_in = !p->approx ? 0.0 : ((mode == d2d::MODE_HSIG) ? 3.0 : 17.5) / (double)p->alpha * (1.0 + 1e-5);
     double lo = -((double)p->seg_tol + widen);
     double hi = 1.0 + (double)p->seg_tol + widen;
     a.flt_lo = (float)(lo * (1.0 + 1e-5) - 1e-30);
@@ -658,6 +670,26 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     if (tiles > 0x7fffffffLL) return fail(D2D_ERR_INVALID, "grid too large: %lld tiles", tiles);
     dim3 grid((unsigned)tiles), block(64);
     const bool txg = p->grid_role == D2D_GRID_TX;
+    // first-segment shadow coverage (RX grids: the fixed end point is the transmitter)
+    a.shadow = nullptr;
+    a.shadow_dperp = 0.0f;
+    if (!txg && c->N >= 2 && p->max_order >= 1) {
+        if ((rc = c->d_shadow.ensure((size_t)c->N))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_shadow.p, 0, (size_t)c->N * sizeof(unsigned long long), c->stream));
+        // window where a test is certainly "hit" (hard) / exactly saturated to 1 (approx): shrink [-tol, 1+tol] by widen
+        const double in_lo = -(double)p->seg_tol + widen_in, in_hi = 1.0 + (double)p->seg_tol - widen_in;
+        float ext = std::fmax(std::fmax(c->scene_absmax, c->grid_absmax), std::fmax(std::fabs(tx[0]), std::fabs(tx[1])));
+        if (in_hi > in_lo + 1e-3 && std::isfinite(ext) && ext > 0.0f) {
+            const float dperp = 4096.0f * 1.1920929e-07f * ext * (float)(p->max_order + 1);
+            const int pairs = c->N * c->N;
+            hipLaunchKernelGGL(d2d::shadow_tx_kernel, dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, c->stream, c->d_occl.p,
+                               c->d_refl.p, c->d_kind.p, c->N, tx[0], tx[1], (float)(in_lo + 1e-4), (float)(in_hi - 1e-4), dperp,
+                               c->d_shadow.p);
+            HIP_TRY(hipGetLastError());
+            a.shadow = c->d_shadow.p;
+            a.shadow_dperp = dperp;
+        }
+    }
     if (txg && d_stats) return fail(D2D_ERR_UNSUPPORTED, "the instrumented build covers the RX-grid kernel only");
     if (txg && !grad_mode) {
         // TX grid, values only: the per-lane-image code path without the adjoint

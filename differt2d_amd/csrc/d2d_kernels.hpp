@@ -42,6 +42,11 @@ struct SweepArgs {
     float flt_lo, flt_hi;      // conservative "certainly outside the window" thresholds for the divide-free filter
     float on_lo, on_hi;        // parametric coordinate certainly outside the wall: s < on_lo or s > on_hi => on_objects == 0
     float loss_skip;           // a loss certainly below this cannot change less(loss, tol) (see eval_candidate); < 0: never
+    // first-segment shadow culling (shadow_tx_kernel): bit b of shadow[w] = every point of wall w with parametric
+    // coordinate in [b/64, (b+1)/64] (and within shadow_dperp of the wall's line) is certainly hidden from the fixed
+    // end point by some other object
+    const unsigned long long* __restrict__ shadow;  // [N] or null
+    float shadow_dperp;
     float fnum[D2D_MAX_ORDER + 1];  // r_coef ** k (lax.integer_pow), k = 0..D2D_MAX_ORDER
     float h2;                  // height * height
     int fun_id;
@@ -840,7 +845,8 @@ __device__ __forceinline__ bool s_range(const float (&qx)[4], const float (&qy)[
 // walls[j], images[j] for j = K-1 (last wall) down to 0; level 1 uses the patch box.
 template <int K>
 __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float (&by)[4], const WallC (&w)[K],
-                                               const float (&Ix)[K], const float (&Iy)[K], float on_lo, float on_hi) {
+                                               const float (&Ix)[K], const float (&Iy)[K], float on_lo, float on_hi,
+                                               unsigned long long shadow0, float shadow_dperp) {
     const float eps = 1.1920929e-07f;
     float qx[4], qy[4];
 #pragma unroll
@@ -854,7 +860,19 @@ __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float
         bool ok = s_range(qx, qy, Ix[lvl], Iy[lvl], w[lvl], smin, smax, M, E);
         if (!ok) return false;
         if (smax + M < on_lo || smin - M > on_hi) return true;
-        if (lvl == 0) break;
+        if (lvl == 0) {
+            // First segment (fixed end point -> first wall): if every point the first interaction can occupy is hidden
+            // from the fixed end point by some object, the segment is occluded in every lane: valid == 0.
+            float sa = smin - M - 1e-4f, sb = smax + M + 1e-4f;
+            if (sa >= 0.0f && sb <= 1.0f && 256.0f * eps * E <= shadow_dperp) {
+                int ka = (int)(sa * 64.0f), kb = (int)(sb * 64.0f);
+                ka = ka < 0 ? 0 : ka;
+                kb = kb > 63 ? 63 : kb;
+                unsigned long long need = (kb >= 63 ? ~0ull : ((1ull << (kb + 1)) - 1ull)) & ~((1ull << ka) - 1ull);
+                if ((shadow0 & need) == need) return true;
+            }
+            break;
+        }
         // what is left of wall `lvl` for the next level: sigma in [sa, sb], as a thin quad around the wall
         float sa = fmaxf(smin - M, on_lo), sb = fminf(smax + M, on_hi);
         float d = 64.0f * eps * 2.0f * E;  // the fp32 point may sit this far off the wall's line
@@ -900,7 +918,15 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         const float pIx = (K == 1) ? a.txx : imgx[K >= 2 ? K - 2 : 0];
         const float pIy = (K == 1) ? a.txy : imgy[K >= 2 ? K - 2 : 0];
         const int last_prefix_pos = (K == 1) ? -1 : pos[K >= 2 ? K - 2 : 0];
-        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        // the whole first wall is hidden from the fixed end point: no candidate starting with it can be valid.  Hard mode
+        // only: with soft activations a point slightly beyond the wall's ends is still partially "on" it, and the
+        // coverage bits only speak for parametric coordinates in [0, 1].
+        // (A valid candidate has un != 0 in every step -- un == 0 leaves a zero-length segment, i.e. loss >= 1 > tol, this
+        // shortcut is off for tol > 0.5 -- and s in [0, 1], so its first point does lie on the wall within rounding.)
+        // Not in the value+grad build: the reference's un == 0 autodiff NaN must still be found in every candidate that
+        // the per-candidate tests (which guarantee un != 0) cannot drop.
+        const bool prefix_dead = !GRAD && (MODE == MODE_HARD) && (K >= 2) && a.shadow && (a.tol <= 0.5f) && (a.shadow[cand[0]] == ~0ull);
+        for (int chunk = 0; chunk < (prefix_dead ? 0 : n_chunks); ++chunk) {
             // ---- lanes = candidates: lane l <-> last wall = cw[chunk * 64 + l]
             const int lp = chunk * 64 + lane;
             bool alive = (lp < Nc) && (lp != last_prefix_pos);
@@ -918,7 +944,9 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                     Ix[d] = imgx[d];
                     Iy[d] = imgy[d];
                 }
-                if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi)) alive = false;
+                unsigned long long sh0 = 0ull;
+                if (a.shadow) sh0 = a.shadow[(K == 1) ? wl : cand[0]];
+                if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi, sh0, a.shadow_dperp)) alive = false;
             }
             unsigned long long mask = __ballot(alive);
             if (STATS) st.c[9] += K;
@@ -1087,6 +1115,60 @@ __global__ void selftest_div_kernel(const float* __restrict__ x, const float* __
     q_fast[i] = div_with_rcp(x[i], y[i], rcp_refined(y[i]));
     q_ref[i] = x[i] / y[i];
     q_hostr[i] = div_with_rcp(x[i], y[i], ry[i]);  // with a host-computed correctly rounded reciprocal
+}
+
+// Shadow coverage of every wall as seen from the fixed end point `e` (the transmitter of an RX-grid sweep): one thread per
+// (wall w, blocker j) pair rasterises, into 64 bins of w's parametric range, where the segment e -> p is CERTAINLY
+// reported as intersecting j by the exact path (hard: hit; approx: the four activations exactly saturated), for every
+// p within `dperp` of the bin.  t_a, t_b are linear-fractional in p, so on a thin quad around a bin that does not meet
+// the pole (fd keeps its sign) their ranges are spanned by the 4 vertices.  Margins: 8 eps per product sum for the
+// rounding of either evaluation chain.  Only bins certified at all four vertices are set (atomicOr).
+__global__ void shadow_tx_kernel(const float4* __restrict__ occl, const float4* __restrict__ refl,
+                                 const unsigned char* __restrict__ kind, int N, float ex, float ey, float win_lo, float win_hi,
+                                 float dperp, unsigned long long* __restrict__ shadow) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * N) return;
+    const int w = idx / N, j = idx % N;
+    if (w == j) return;                  // segment 0 ignores the wall it ends on (geometry.py:881-890)
+    if (kind[j] == D2D_VERTEX) return;   // vertices never occlude (geometry.py:407-414)
+    {
+        const float4 t1 = refl[2 * w + 1];
+        if (t1.x * t1.x + t1.y * t1.y == 0.0f) return;  // a zero-length wall has no line for its point to lie on
+    }
+    const float eps = 1.1920929e-07f;
+    const float4 r0 = refl[2 * w], r1 = refl[2 * w + 1];
+    const float4 o = occl[j];  // P1, A
+    const float Cx = o.x - ex, Cy = o.y - ey;                 // C = P1 - P3, P3 = e
+    const float fb = o.z * Cy - o.w * Cx;
+    const float errB = 8.0f * eps * (fabsf(o.z * Cy) + fabsf(o.w * Cx));
+    const float tlen = fabsf(r1.x) + fabsf(r1.y);
+    const float pad = dperp * (r1.w > 0.0f ? 1.0f / r1.w : 0.0f);  // dperp expressed in parametric units of w
+    unsigned long long bits = 0ull;
+    for (int b = 0; b < 64; ++b) {
+        bool ok = true;
+        int sgn = 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float sg = ((v & 1) ? (float)(b + 1) / 64.0f + pad : (float)b / 64.0f - pad);
+            const float off = (v & 2) ? dperp : -dperp;
+            const float qx = r0.x + sg * r1.x + off * r0.z, qy = r0.y + sg * r1.y + off * r0.w;  // P4 = q
+            const float Bx = ex - qx, By = ey - qy;
+            const float fa = By * Cx - Bx * Cy;
+            const float fd = o.w * Bx - o.z * By;
+            const float errA = 8.0f * eps * (fabsf(By * Cx) + fabsf(Bx * Cy));
+            const float errD = 8.0f * eps * (fabsf(o.w * Bx) + fabsf(o.z * By)) + 4.0f * eps * tlen * (fabsf(o.z) + fabsf(o.w));
+            const float ad = fabsf(fd);
+            if (!(ad > 8.0f * errD)) { ok = false; break; }
+            const int sv = fd > 0.0f ? 1 : -1;
+            if (sgn == 0) sgn = sv;
+            if (sv != sgn) { ok = false; break; }
+            const float ta = fa / fd, tb = fb / fd;
+            const float ea = (errA + 2.0f * errD) / (ad - errD) + 4.0f * eps, eb = (errB + 2.0f * errD) / (ad - errD) + 4.0f * eps;
+            if (!(ta - ea >= win_lo && ta + ea <= win_hi && tb - eb >= win_lo && tb + eb <= win_hi)) { ok = false; break; }
+        }
+        if (ok) bits |= (1ull << b);
+    }
+    if (bits) atomicOr(&shadow[w], bits);
 }
 
 // Value + gradient sweep: same forward arithmetic as power_fwd_kernel (bit-identical values), plus the
