@@ -682,12 +682,22 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         if (in_hi > in_lo + 1e-3 && std::isfinite(ext) && ext > 0.0f) {
             const float dperp = 4096.0f * 1.1920929e-07f * ext * (float)(p->max_order + 1);
             const int pairs = c->N * c->N;
+            // bins span the parametric window in which on_objects is not exactly 0 (+ a little)
+            const double dom_lo = (double)a.on_lo - 2e-3, dom_hi = (double)a.on_hi + 2e-3;
+            const double dom_w = (dom_hi - dom_lo) / 64.0;
             hipLaunchKernelGGL(d2d::shadow_tx_kernel, dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, c->stream, c->d_occl.p,
                                c->d_refl.p, c->d_kind.p, c->N, tx[0], tx[1], (float)(in_lo + 1e-4), (float)(in_hi - 1e-4), dperp,
-                               c->d_shadow.p);
+                               (float)dom_lo, (float)dom_w, c->d_shadow.p);
             HIP_TRY(hipGetLastError());
             a.shadow = c->d_shadow.p;
             a.shadow_dperp = dperp;
+            a.shadow_lo = (float)dom_lo;
+            a.shadow_inv = (float)(1.0 / dom_w);
+            // a candidate with un == 0 in some step has a zero-length segment, loss >= 1: is it exactly invalid?
+            const double x = (double)p->tol - 0.999;  // tol - loss at best
+            if (!p->approx) a.shadow_prefix_ok = (p->tol <= 0.5f) ? 1 : 0;
+            else if (mode == d2d::MODE_HSIG) a.shadow_prefix_ok = ((double)p->alpha * x + 3.0 <= -1e-3) ? 1 : 0;
+            else a.shadow_prefix_ok = ((double)p->alpha * x <= -89.5) ? 1 : 0;
         }
     }
     if (txg && d_stats) return fail(D2D_ERR_UNSUPPORTED, "the instrumented build covers the RX-grid kernel only");

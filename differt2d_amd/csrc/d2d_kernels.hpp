@@ -47,6 +47,8 @@ struct SweepArgs {
     // end point by some other object
     const unsigned long long* __restrict__ shadow;  // [N] or null
     float shadow_dperp;
+    float shadow_lo, shadow_inv;  // bin b covers parametric coordinates shadow_lo + [b, b+1] / shadow_inv
+    int shadow_prefix_ok;         // a fully covered first wall kills its whole prefix (see sweep_order_culled)
     float fnum[D2D_MAX_ORDER + 1];  // r_coef ** k (lax.integer_pow), k = 0..D2D_MAX_ORDER
     float h2;                  // height * height
     int fun_id;
@@ -846,7 +848,8 @@ __device__ __forceinline__ bool s_range(const float (&qx)[4], const float (&qy)[
 template <int K>
 __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float (&by)[4], const WallC (&w)[K],
                                                const float (&Ix)[K], const float (&Iy)[K], float on_lo, float on_hi,
-                                               unsigned long long shadow0, float shadow_dperp) {
+                                               unsigned long long shadow0, float shadow_dperp, float shadow_lo,
+                                               float shadow_inv) {
     const float eps = 1.1920929e-07f;
     float qx[4], qy[4];
 #pragma unroll
@@ -863,9 +866,10 @@ __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float
         if (lvl == 0) {
             // First segment (fixed end point -> first wall): if every point the first interaction can occupy is hidden
             // from the fixed end point by some object, the segment is occluded in every lane: valid == 0.
-            float sa = smin - M - 1e-4f, sb = smax + M + 1e-4f;
-            if (sa >= 0.0f && sb <= 1.0f && 256.0f * eps * E <= shadow_dperp) {
-                int ka = (int)(sa * 64.0f), kb = (int)(sb * 64.0f);
+            float sa = fmaxf(smin - M, on_lo) - 1e-4f, sb = fminf(smax + M, on_hi) + 1e-4f;  // lanes outside the window are invalid anyway
+            float fa_ = (sa - shadow_lo) * shadow_inv, fb_ = (sb - shadow_lo) * shadow_inv;
+            if (fa_ >= 0.0f && fb_ < 64.0f && 256.0f * eps * E <= shadow_dperp) {
+                int ka = (int)fa_, kb = (int)fb_;
                 ka = ka < 0 ? 0 : ka;
                 kb = kb > 63 ? 63 : kb;
                 unsigned long long need = (kb >= 63 ? ~0ull : ((1ull << (kb + 1)) - 1ull)) & ~((1ull << ka) - 1ull);
@@ -918,14 +922,13 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         const float pIx = (K == 1) ? a.txx : imgx[K >= 2 ? K - 2 : 0];
         const float pIy = (K == 1) ? a.txy : imgy[K >= 2 ? K - 2 : 0];
         const int last_prefix_pos = (K == 1) ? -1 : pos[K >= 2 ? K - 2 : 0];
-        // the whole first wall is hidden from the fixed end point: no candidate starting with it can be valid.  Hard mode
-        // only: with soft activations a point slightly beyond the wall's ends is still partially "on" it, and the
-        // coverage bits only speak for parametric coordinates in [0, 1].
-        // (A valid candidate has un != 0 in every step -- un == 0 leaves a zero-length segment, i.e. loss >= 1 > tol, this
-        // shortcut is off for tol > 0.5 -- and s in [0, 1], so its first point does lie on the wall within rounding.)
+        // The whole first wall -- over the full parametric window in which on_objects is not exactly 0 -- is hidden from
+        // the fixed end point: no candidate starting with it can be valid.  (A valid candidate has un != 0 in every step:
+        // un == 0 leaves a zero-length segment, i.e. loss >= 1, which the host checks to be exactly invalid for the
+        // current tol / alpha (shadow_prefix_ok); so its first point does lie on the wall's line within rounding.)
         // Not in the value+grad build: the reference's un == 0 autodiff NaN must still be found in every candidate that
         // the per-candidate tests (which guarantee un != 0) cannot drop.
-        const bool prefix_dead = !GRAD && (MODE == MODE_HARD) && (K >= 2) && a.shadow && (a.tol <= 0.5f) && (a.shadow[cand[0]] == ~0ull);
+        const bool prefix_dead = !GRAD && (K >= 2) && a.shadow && a.shadow_prefix_ok && (a.shadow[cand[0]] == ~0ull);
         for (int chunk = 0; chunk < (prefix_dead ? 0 : n_chunks); ++chunk) {
             // ---- lanes = candidates: lane l <-> last wall = cw[chunk * 64 + l]
             const int lp = chunk * 64 + lane;
@@ -946,7 +949,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 }
                 unsigned long long sh0 = 0ull;
                 if (a.shadow) sh0 = a.shadow[(K == 1) ? wl : cand[0]];
-                if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi, sh0, a.shadow_dperp)) alive = false;
+                if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi, sh0, a.shadow_dperp, a.shadow_lo, a.shadow_inv)) alive = false;
             }
             unsigned long long mask = __ballot(alive);
             if (STATS) st.c[9] += K;
@@ -1125,7 +1128,7 @@ __global__ void selftest_div_kernel(const float* __restrict__ x, const float* __
 // rounding of either evaluation chain.  Only bins certified at all four vertices are set (atomicOr).
 __global__ void shadow_tx_kernel(const float4* __restrict__ occl, const float4* __restrict__ refl,
                                  const unsigned char* __restrict__ kind, int N, float ex, float ey, float win_lo, float win_hi,
-                                 float dperp, unsigned long long* __restrict__ shadow) {
+                                 float dperp, float dom_lo, float dom_w, unsigned long long* __restrict__ shadow) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * N) return;
     const int w = idx / N, j = idx % N;
@@ -1149,7 +1152,7 @@ __global__ void shadow_tx_kernel(const float4* __restrict__ occl, const float4* 
         int sgn = 0;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const float sg = ((v & 1) ? (float)(b + 1) / 64.0f + pad : (float)b / 64.0f - pad);
+            const float sg = dom_lo + ((v & 1) ? (float)(b + 1) * dom_w + pad : (float)b * dom_w - pad);
             const float off = (v & 2) ? dperp : -dperp;
             const float qx = r0.x + sg * r1.x + off * r0.z, qy = r0.y + sg * r1.y + off * r0.w;  // P4 = q
             const float Bx = ex - qx, By = ey - qy;
