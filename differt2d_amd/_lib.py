@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libd2d.so")
 
 D2D_MAX_ORDER = 4
-D2D_NUM_STATS = 10
+D2D_NUM_STATS = 16
 D2D_COMM_ID_BYTES = 128
 D2D_ABI_VERSION = 2
 
@@ -101,6 +101,8 @@ SYMBOLS = [
     ("d2d_get_grad_rx", C.c_int, [_ctx, _f32p]),
     ("d2d_get_scene_vjp", C.c_int, [_ctx, _f32p, C.c_void_p]),
     ("d2d_power_map_stats", C.c_int, [_ctx, C.POINTER(Params), _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]),
+    ("d2d_power_map_wave_cycles", C.c_int, [_ctx, C.POINTER(Params), _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS"),
+                                            C.c_int64, C.POINTER(C.c_int64)]),
     ("d2d_selftest_div", C.c_int, [_ctx, _f32p, _f32p, C.c_int64, _f32p, _f32p, _f32p]),
     ("d2d_get_map", C.c_int, [_ctx, _f32p]),
     ("d2d_power_map", C.c_int, [_ctx, C.POINTER(Params), _f32p, _f32p, _f32p, C.c_int32, C.c_int32, _f32p]),

@@ -114,6 +114,7 @@ struct d2d_ctx {
     DevBuf<double> d_vjp;
     bool have_cot = false;
     bool have_vjp = false;
+    bool want_wave_cycles = false;
     // RCCL (one communicator per ctx, collectives run on the ctx stream)
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -663,12 +664,14 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     a.out_mode = p->out_mode;
     a.patch = p->patch;
     a.stats = d_stats;
+    a.wave_cycles = (d_stats && c->want_wave_cycles) ? d_stats + D2D_NUM_STATS : nullptr;
 
     const int tiles_x = (c->n + d2d::TILE_W - 1) / d2d::TILE_W;
     const int tiles_y = (c->m + d2d::TILE_H - 1) / d2d::TILE_H;
     const long long tiles = (long long)tiles_x * tiles_y;
     if (tiles > 0x7fffffffLL) return fail(D2D_ERR_INVALID, "grid too large: %lld tiles", tiles);
     dim3 grid((unsigned)tiles), block(64);
+    dim3 grid_walk((unsigned)tiles);  // one single-wave workgroup per 8 x 8 patch
     const bool txg = p->grid_role == D2D_GRID_TX;
     // first-segment shadow coverage (RX grids: the fixed end point is the transmitter)
     a.shadow = nullptr;
@@ -685,7 +688,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             // bins span the parametric window in which on_objects is not exactly 0 (+ a little)
             const double dom_lo = (double)a.on_lo - 2e-3, dom_hi = (double)a.on_hi + 2e-3;
             const double dom_w = (dom_hi - dom_lo) / 64.0;
-            hipLaunchKernelGGL(d2d::shadow_tx_kernel, dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, c->stream, c->d_occl.p,
+            hipLaunchKernelGGL(d2d::shadow_tx_kernel, dim3((unsigned)pairs), dim3(64), 0, c->stream, c->d_occl.p,
                                c->d_refl.p, c->d_kind.p, c->N, tx[0], tx[1], (float)(in_lo + 1e-4), (float)(in_hi - 1e-4), dperp,
                                (float)dom_lo, (float)dom_w, c->d_shadow.p);
             HIP_TRY(hipGetLastError());
@@ -733,9 +736,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
 #define D2D_LAUNCH_FWDG(MODE_)                                                                                              \
     do {                                                                                                                    \
-        if (p->max_order <= 2) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 2, true>), grid, block, lds2, c->stream, a); \
-        else if (p->max_order == 3) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 3, true>), grid, block, lds2, c->stream, a); \
-        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 4, true>), grid, block, lds2, c->stream, a);            \
+        if (p->max_order <= 2) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 2, true>), grid_walk, block, lds2, c->stream, a); \
+        else if (p->max_order == 3) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 3, true>), grid_walk, block, lds2, c->stream, a); \
+        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 4, true>), grid_walk, block, lds2, c->stream, a);            \
     } while (0)
             switch (mode) {
                 case d2d::MODE_HARD: D2D_LAUNCH_FWDG(d2d::MODE_HARD); break;
@@ -757,8 +760,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
         HIP_TRY(hipGetLastError());
         if (grad_mode == 2) {
+            const long rows = (!txg && !p->strict_nan) ? (long)grid_walk.x : (long)tiles;  // one row of partials per launched wave
             hipLaunchKernelGGL(d2d::vjp_reduce_kernel, dim3((unsigned)n_elem), dim3(256), 0, c->stream, c->d_partial.p,
-                               (long)tiles, n_elem, c->d_vjp.p, (p->out_mode == D2D_OUT_ADD && c->have_vjp) ? 1 : 0);
+                               rows, n_elem, c->d_vjp.p, (p->out_mode == D2D_OUT_ADD && c->have_vjp) ? 1 : 0);
             HIP_TRY(hipGetLastError());
             c->have_vjp = true;
         }
@@ -767,7 +771,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     const size_t tab_lds = (size_t)(4 * c->N + 1) * sizeof(float4);
     if (tab_lds > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~1300)", c->N);
 #define D2D_LAUNCH_FWD(MODE_, STATS_, MAXK_) \
-    hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, STATS_, MAXK_>), grid, block, tab_lds, c->stream, a)
+    hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, STATS_, MAXK_>), grid_walk, block, tab_lds, c->stream, a)
 #define D2D_LAUNCH_FWD_K(MODE_, STATS_)                      \
     do {                                                     \
         if (p->max_order <= 2) D2D_LAUNCH_FWD(MODE_, STATS_, 2); \
@@ -858,6 +862,25 @@ int d2d_selftest_div(d2d_ctx* c, const float* x, const float* y, int64_t n, floa
     HIP_TRY(hipMemcpy(q_ref, d2.p, n * sizeof(float), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(q_hostr, d3.p, n * sizeof(float), hipMemcpyDeviceToHost));
     dx.release(); dy.release(); dr.release(); d1.release(); d2.release(); d3.release();
+    return D2D_OK;
+}
+
+int d2d_power_map_wave_cycles(d2d_ctx* c, const d2d_params* p, const float* tx, uint64_t* cycles, int64_t capacity, int64_t* n_waves) {
+    if (!c || !cycles || !n_waves) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (!c->have_grid) return fail(D2D_ERR_STATE, "no grid set");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const int64_t waves = (int64_t)((c->n + d2d::TILE_W - 1) / d2d::TILE_W) * ((c->m + d2d::TILE_H - 1) / d2d::TILE_H);
+    *n_waves = waves;
+    if (capacity < waves) return fail(D2D_ERR_INVALID, "capacity %lld < %lld waves", (long long)capacity, (long long)waves);
+    if ((rc = c->d_stats.ensure((size_t)D2D_NUM_STATS + (size_t)waves))) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_stats.p, 0, ((size_t)D2D_NUM_STATS + (size_t)waves) * sizeof(unsigned long long), c->stream));
+    c->want_wave_cycles = true;
+    rc = sweep_launch(c, p, tx, c->d_stats.p);
+    c->want_wave_cycles = false;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(cycles, c->d_stats.p + D2D_NUM_STATS, (size_t)waves * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return D2D_OK;
 }
 

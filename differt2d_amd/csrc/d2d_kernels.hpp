@@ -59,7 +59,8 @@ struct SweepArgs {
     const float* __restrict__ cot;   // [m][n] cotangent for the scene VJP, or null (= ones)
     float* __restrict__ partial;     // [n_waves][4 N + 2] per-wave partial sums of the scene VJP, or null
 
-    unsigned long long* stats; // [9] executed-work counters (STATS build only), may be null
+    unsigned long long* stats; // [D2D_NUM_STATS] executed-work counters (STATS build only), may be null
+    unsigned long long* wave_cycles;  // [n_patches] shader clock ticks spent per patch (STATS build only), may be null
 };
 
 #define D2D_EPS 1.1920929e-07f  // jnp.finfo(float32).eps, geometry.py:200
@@ -71,7 +72,7 @@ struct SweepArgs {
 //   [4] segment/wall tests evaluated (filter)           [5] tests that took the exact-divide path
 //   [6] sum over [0] of the candidate order k           [7] sum over [1] of k   [8] sum over [3] of (k+1)
 struct WaveStats {
-    unsigned long long c[10];  // [9] tile-culling levels evaluated
+    unsigned long long c[16];  // [9] tile-culling levels evaluated; [10..15] shader-clock ticks per phase (diagnostic)
     int shadow;                // wave state, not a counter: the wall that occluded the wave's previous candidate
 };
 
@@ -953,6 +954,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
             }
             unsigned long long mask = __ballot(alive);
             if (STATS) st.c[9] += K;
+            const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
             // ---- lanes = RX cells: survivors in ascending order (= the reference's order)
             while (mask) {
                 const int b = __builtin_ctzll(mask);
@@ -961,6 +963,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 image_of(a.refl[2 * cand[K - 1]], pIx, pIy, imgx[K - 1], imgy[K - 1]);
                 eval_candidate<K, MODE, STATS, GRAD, false, false>(a, cand, imgx, imgy, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, g);
             }
+            if (STATS) st.c[14] += __builtin_amdgcn_s_memtime() - te0;  // exact evaluation of the survivors
         }
         // next prefix (lexicographic, no equal neighbours); static indexing keeps pos[] in registers
         if (K == 1) break;
@@ -1000,8 +1003,28 @@ template <int MODE, bool STATS, int MAXK, bool GRADK = false>
 __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
-    const int tile = blockIdx.x;
-    const int tcol = tile % tiles_x, trow = tile / tiles_x;
+    const int tiles_y = (a.m + TILE_H - 1) / TILE_H;
+    const long n_tiles = (long)tiles_x * tiles_y;
+    // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index), staged once per wave
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    float* wl = reinterpret_cast<float*>(tab + 3 * a.N);
+    const bool scene = GRADK && a.partial != nullptr;
+    if (scene)
+        for (int i = lane; i < 4 * a.N; i += 64) wl[i] = 0.0f;
+    __syncthreads();
+    float tbx_sum = 0.0f, tby_sum = 0.0f;  // scene VJP w.r.t. the fixed end point, summed over this wave's patches
+    WaveStats st;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st.c[i] = 0;
+    st.shadow = -1;
+    // One 8 x 8 patch per wave when the host launches one workgroup per patch (the default: measured equal or better
+    // than 8192 persistent waves with static striding or an atomic work queue at 1024^2 .. 4096^2); the loop only
+    // matters for grids with more than 2^31 patches.
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int tcol = (int)(tile % tiles_x), trow = (int)(tile / tiles_x);
     const int col = tcol * TILE_W + (lane & (TILE_W - 1));
     const int row = trow * TILE_H + (lane / TILE_W);
     const bool in_range = (col < a.n) && (row < a.m);
@@ -1012,19 +1035,6 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     const bool lane_bad = !(fabsf(rxx) < 1e18f) || !(fabsf(rxy) < 1e18f) || !(fabsf(a.txx) < 1e18f) ||
                           !(fabsf(a.txy) < 1e18f);
     float acc = 0.0f;  // scene.py:1893
-    WaveStats st;
-#pragma unroll
-    for (int i = 0; i < 10; ++i) st.c[i] = 0;
-    st.shadow = -1;
-    // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index)
-    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
-    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
-    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
-    float* wl = reinterpret_cast<float*>(tab + 3 * a.N);
-    const bool scene = GRADK && a.partial != nullptr;
-    if (scene)
-        for (int i = lane; i < 4 * a.N; i += 64) wl[i] = 0.0f;
-    __syncthreads();
     GradCtx g;
     g.grx = g.gry = g.tbx = g.tby = 0.0f;
     g.cot = in_range ? (a.cot ? a.cot[idx] : 1.0f) : 0.0f;
@@ -1074,9 +1084,16 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     const float qn = __builtin_nanf("");
     const float bx[4] = {box_ok ? x0 : qn, x1, x1, x0};
     const float by[4] = {y0, y0, y1, y1};
+    unsigned long long tq0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (STATS) st.c[10] += tq0 - t_start;  // prologue of the patch
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, GRADK>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, &g);
+    unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (STATS) st.c[11] += tq1 - tq0;      // order 0
     if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
+    unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (STATS) st.c[12] += tq2 - tq1;      // order 1
     if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled<2, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
+    if (STATS) st.c[13] += __builtin_amdgcn_s_memtime() - tq2;  // order 2
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled<3, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
     if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_culled<4, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
     if (in_range) {
@@ -1095,18 +1112,23 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
         }
     }
     if (scene) {
-        float sx = wave_sum(g.tbx), sy = wave_sum(g.tby);
+        tbx_sum += wave_sum(g.tbx);
+        tby_sum += wave_sum(g.tby);
+    }
+    if (STATS && lane == 0 && a.wave_cycles) a.wave_cycles[tile] = __builtin_amdgcn_s_memtime() - t_start;
+    }  // patches of this wave
+    if (scene) {
         __syncthreads();
         float* dst = a.partial + (long)blockIdx.x * (4 * a.N + 2);
         for (int i = lane; i < 4 * a.N; i += 64) dst[i] = wl[i];
         if (lane == 0) {
-            dst[4 * a.N] = sx;
-            dst[4 * a.N + 1] = sy;
+            dst[4 * a.N] = tbx_sum;
+            dst[4 * a.N + 1] = tby_sum;
         }
     }
     if (STATS && lane == 0 && a.stats) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) atomicAdd(&a.stats[i], st.c[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&a.stats[i], st.c[i]);
     }
 }
 
@@ -1129,9 +1151,11 @@ __global__ void selftest_div_kernel(const float* __restrict__ x, const float* __
 __global__ void shadow_tx_kernel(const float4* __restrict__ occl, const float4* __restrict__ refl,
                                  const unsigned char* __restrict__ kind, int N, float ex, float ey, float win_lo, float win_hi,
                                  float dperp, float dom_lo, float dom_w, unsigned long long* __restrict__ shadow) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * N) return;
-    const int w = idx / N, j = idx % N;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(gid & 63);       // one lane per bin: a wave = one (w, j) pair, its ballot = the pair's 64 bits
+    const long idx = gid >> 6;
+    if (idx >= (long)N * N) return;
+    const int w = (int)(idx / N), j = (int)(idx % N);
     if (w == j) return;                  // segment 0 ignores the wall it ends on (geometry.py:881-890)
     if (kind[j] == D2D_VERTEX) return;   // vertices never occlude (geometry.py:407-414)
     {
@@ -1147,7 +1171,7 @@ __global__ void shadow_tx_kernel(const float4* __restrict__ occl, const float4* 
     const float tlen = fabsf(r1.x) + fabsf(r1.y);
     const float pad = dperp * (r1.w > 0.0f ? 1.0f / r1.w : 0.0f);  // dperp expressed in parametric units of w
     unsigned long long bits = 0ull;
-    for (int b = 0; b < 64; ++b) {
+    {
         bool ok = true;
         int sgn = 0;
 #pragma unroll
@@ -1169,9 +1193,9 @@ __global__ void shadow_tx_kernel(const float4* __restrict__ occl, const float4* 
             const float ea = (errA + 2.0f * errD) / (ad - errD) + 4.0f * eps, eb = (errB + 2.0f * errD) / (ad - errD) + 4.0f * eps;
             if (!(ta - ea >= win_lo && ta + ea <= win_hi && tb - eb >= win_lo && tb + eb <= win_hi)) { ok = false; break; }
         }
-        if (ok) bits |= (1ull << b);
+        bits = __ballot(ok);
     }
-    if (bits) atomicOr(&shadow[w], bits);
+    if (bits && b == 0) atomicOr(&shadow[w], bits);
 }
 
 // Value + gradient sweep: same forward arithmetic as power_fwd_kernel (bit-identical values), plus the

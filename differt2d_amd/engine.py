@@ -203,6 +203,15 @@ class Context:
         L.check(self._lib.d2d_power_map_stats(self._ctx, C.byref(params), tx, stats))
         return stats
 
+    def wave_cycles(self, params: L.Params, tx) -> np.ndarray:
+        """Shader-clock ticks per wave (8 x 8 patch) of the instrumented forward sweep, shape (patch rows, patch cols)."""
+        tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(2)
+        ty, tx_ = -(-self.shape[0] // 8), -(-self.shape[1] // 8)
+        out = np.zeros(ty * tx_, np.uint64)
+        n = C.c_int64(0)
+        L.check(self._lib.d2d_power_map_wave_cycles(self._ctx, C.byref(params), tx, out, out.size, C.byref(n)))
+        return out.reshape(ty, tx_)
+
     def selftest_div(self, x, y):
         """(q_fast, q_ref, q_hostr) of the division self-test (include/d2d.h)."""
         x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)

@@ -184,9 +184,15 @@ int d2d_get_scene_vjp(d2d_ctx* ctx, float* tx_bar, float* xys_bar);
  *   [4] segment/wall tests evaluated                             [5] tests that took the exact-divide path
  *   [6] sum of k over [0]    [7] sum of k over the candidates whose loss was evaluated exactly    [8] sum of (k+1) over [3]
  *   [9] tile-culling levels evaluated (one count = 64 candidates x 4 vertex evaluations)
+ *   [10..14] shader-clock ticks summed over waves: patch prologue, order 0, order 1, order 2, exact evaluation of survivors
  * bench.py prices these with SURVEY.md section 8(d)'s per-unit FLOP figures. */
-#define D2D_NUM_STATS 10
+#define D2D_NUM_STATS 16
 int d2d_power_map_stats(d2d_ctx* ctx, const d2d_params* params, const float* tx, uint64_t* stats);
+
+/* Diagnostic (instrumented build): shader-clock ticks each 64-lane wave (= one 8 x 8 patch of cells, row-major over
+ * patches) spent in the sweep -- the load-balance picture behind the roofline numbers. */
+int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const float* tx, uint64_t* cycles, int64_t capacity,
+                              int64_t* n_waves);
 
 /* Diagnostic: evaluates x[i] / y[i] on the GPU three ways -- q_fast: the kernels' bare fma chain on a refined
  * v_rcp; q_ref: the compiler's generic correctly rounded expansion; q_hostr: the bare chain on a host-computed
