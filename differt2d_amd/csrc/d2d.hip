@@ -4,11 +4,13 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/d2d.h"
@@ -107,6 +109,9 @@ struct d2d_ctx {
     bool have_grid = false;
     DevBuf<float> d_X, d_Y, d_out;
     DevBuf<unsigned long long> d_stats, d_shadow;
+    DevBuf<int> d_sched, d_sched_hist;  // patch schedule, {histogram, cursors}
+    DevBuf<unsigned char> d_sched_key;
+    long long sched_min_tiles = 2048;   // launches with fewer patches keep the identity schedule
     float grid_absmax = 0.0f;   // max |coordinate| of the grid (host scan at d2d_set_grid)
     float scene_absmax = 0.0f;  // max |coordinate| of the objects
     // value+grad
@@ -115,6 +120,7 @@ struct d2d_ctx {
     bool have_cot = false;
     bool have_vjp = false;
     bool want_wave_cycles = false;
+    long long split_max_tiles = 8192;   // launches up to this many patches share every patch between 4 waves
     // RCCL (one communicator per ctx, collectives run on the ctx stream)
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -355,6 +361,8 @@ int d2d_create(int device, d2d_ctx** out) {
     if (device < 0 || device >= n) return fail(D2D_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
     d2d_ctx* c = new d2d_ctx();
     c->device = device;
+    if (const char* v = getenv("D2D_SCHED_MIN_TILES")) c->sched_min_tiles = atoll(v);  // tuning knob
+    if (const char* v = getenv("D2D_SPLIT_MAX_TILES")) c->split_max_tiles = atoll(v);  // tuning knob (0: never)
     hipError_t e1 = hipSetDevice(device);
     if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->ev0);
@@ -389,6 +397,9 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_out.release();
     c->d_stats.release();
     c->d_shadow.release();
+    c->d_sched.release();
+    c->d_sched_key.release();
+    c->d_sched_hist.release();
     c->d_grad.release(); c->d_cot.release(); c->d_partial.release(); c->d_vjp.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -703,6 +714,22 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             else a.shadow_prefix_ok = ((double)p->alpha * x <= -89.5) ? 1 : 0;
         }
     }
+    // dearest-first patch schedule for the culled kernels
+    a.sched = nullptr;
+    if (!txg && !(grad_mode && p->strict_nan) && p->max_order >= 2 && c->cw.size() >= 2 && tiles >= c->sched_min_tiles) {
+        if ((rc = c->d_sched.ensure((size_t)tiles))) return rc;
+        if ((rc = c->d_sched_key.ensure((size_t)tiles))) return rc;
+        if ((rc = c->d_sched_hist.ensure(2 * d2d::SCHED_KEYS))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_sched_hist.p, 0, 2 * d2d::SCHED_KEYS * sizeof(int), c->stream));
+        const unsigned sort_blocks = (unsigned)((tiles + 256 * d2d::SCHED_PER_THREAD - 1) / (256 * d2d::SCHED_PER_THREAD));
+        hipLaunchKernelGGL(d2d::patch_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, a, c->d_sched_key.p);
+        hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p,
+                           c->d_sched_hist.p, (long)tiles);
+        hipLaunchKernelGGL(d2d::patch_order_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p,
+                           c->d_sched_hist.p, c->d_sched_hist.p + d2d::SCHED_KEYS, c->d_sched.p, (long)tiles);
+        HIP_TRY(hipGetLastError());
+        a.sched = c->d_sched.p;
+    }
     if (txg && d_stats) return fail(D2D_ERR_UNSUPPORTED, "the instrumented build covers the RX-grid kernel only");
     if (txg && !grad_mode) {
         // TX grid, values only: the per-lane-image code path without the adjoint
@@ -770,8 +797,18 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     }
     const size_t tab_lds = (size_t)(4 * c->N + 1) * sizeof(float4);
     if (tab_lds > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~1300)", c->N);
-#define D2D_LAUNCH_FWD(MODE_, STATS_, MAXK_) \
-    hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, STATS_, MAXK_>), grid_walk, block, tab_lds, c->stream, a)
+    // Launches that hold only a few patches per SIMD are bound by their dearest patch: share every patch between
+    // D2D_SPLIT_W waves there (power_fwd_split_kernel).  Big grids are throughput-bound: one wave per patch.
+    constexpr int D2D_SPLIT_W = 4;
+    const size_t split_lds = tab_lds + (size_t)(D2D_SPLIT_W - 1) * d2d::SPLIT_LIST * 64 * sizeof(float) +
+                             (size_t)((D2D_SPLIT_W - 1) * 65 + D2D_SPLIT_W + 1) * sizeof(int);
+    const bool split = p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= 64 * 1024 && tiles <= c->split_max_tiles;
+#define D2D_LAUNCH_FWD(MODE_, STATS_, MAXK_)                                                                              \
+    do {                                                                                                                  \
+        if (split) hipLaunchKernelGGL((d2d::power_fwd_split_kernel<MODE_, STATS_, MAXK_, D2D_SPLIT_W>),                   \
+                                      grid_walk, dim3(64 * D2D_SPLIT_W), split_lds, c->stream, a);     \
+        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, STATS_, MAXK_>), grid_walk, block, tab_lds, c->stream, a);   \
+    } while (0)
 #define D2D_LAUNCH_FWD_K(MODE_, STATS_)                      \
     do {                                                     \
         if (p->max_order <= 2) D2D_LAUNCH_FWD(MODE_, STATS_, 2); \
@@ -862,6 +899,14 @@ int d2d_selftest_div(d2d_ctx* c, const float* x, const float* y, int64_t n, floa
     HIP_TRY(hipMemcpy(q_ref, d2.p, n * sizeof(float), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(q_hostr, d3.p, n * sizeof(float), hipMemcpyDeviceToHost));
     dx.release(); dy.release(); dr.release(); d1.release(); d2.release(); d3.release();
+    return D2D_OK;
+}
+
+int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return fail(D2D_ERR_INVALID, "d2d_set_option: NULL argument");
+    if (!strcmp(name, "split_max_tiles")) c->split_max_tiles = value;
+    else if (!strcmp(name, "sched_min_tiles")) c->sched_min_tiles = value;
+    else return fail(D2D_ERR_INVALID, "d2d_set_option: unknown option '%s'", name);
     return D2D_OK;
 }
 

@@ -59,6 +59,9 @@ struct SweepArgs {
     const float* __restrict__ cot;   // [m][n] cotangent for the scene VJP, or null (= ones)
     float* __restrict__ partial;     // [n_waves][4 N + 2] per-wave partial sums of the scene VJP, or null
 
+    // patch schedule (patch_cost_kernel / patch_order_kernel): workgroup b takes patch sched[b]; null = identity
+    const int* __restrict__ sched;
+
     unsigned long long* stats; // [D2D_NUM_STATS] executed-work counters (STATS build only), may be null
     unsigned long long* wave_cycles;  // [n_patches] shader clock ticks spent per patch (STATS build only), may be null
 };
@@ -894,11 +897,31 @@ __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float
     return false;
 }
 
+// Ordered list of a wave's non-zero contributions, one column per lane, in LDS (power_fwd_split_kernel).
+constexpr int SPLIT_LIST = 16;  // entries per lane; a wave that needs more raises `over` and its range is redone serially
+struct ListSink {
+    float* col;  // this lane's column: entry i at col[i * 64]
+    int cnt;
+    bool over;
+    __device__ __forceinline__ void push(float v) {
+        if (cnt < SPLIT_LIST) {
+            col[cnt * 64] = v;
+            ++cnt;
+        } else {
+            over = true;
+        }
+    }
+};
+
 // All candidates of order K >= 1 with tile culling; `tab` = LDS copy of {refl[2N], flt[N]}.
-template <int K, int MODE, bool STATS, bool GRAD = false>
+// K >= 2: only the prefixes whose FIRST position lies in [p_lo, p_hi) (positions into cw[]).  LIST: instead of being
+// added to acc, every contribution that is not exactly zero is appended to `sink` (adding an exact zero never changes
+// acc: acc is never -0.0), so that another wave can add them later in the reference's order.
+template <int K, int MODE, bool STATS, bool GRAD = false, bool LIST = false>
 __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                    const float (&by)[4], float rxx, float rxy, bool lane_bad, float& acc,
-                                                   WaveStats& st, GradCtx* g = nullptr) {
+                                                   WaveStats& st, GradCtx* g = nullptr, int p_lo = 0,
+                                                   int p_hi = 0x7fffffff, ListSink* sink = nullptr) {
     const int lane = threadIdx.x & 63;
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
     float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];
@@ -908,9 +931,11 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
     const int n_chunks = (Nc + 63) >> 6;
     // iterate prefixes in lexicographic order
     // first prefix
+    const int p_end = p_hi < Nc ? p_hi : Nc;
+    if (K >= 2) pos[0] = p_lo;
 #pragma unroll
-    for (int d = 0; d < K - 1; ++d) pos[d] = (d & 1) ? 1 : 0;  // 0,1,0,... has no equal neighbours
-    if (K - 1 > 0 && Nc < 2) return;
+    for (int d = 1; d < K - 1; ++d) pos[d] = (pos[d - 1] == 0) ? 1 : 0;  // no equal neighbours
+    if (K - 1 > 0 && (Nc < 2 || p_lo >= p_end)) return;
     if (Nc < 1) return;
     while (true) {
         // images of the prefix
@@ -961,7 +986,13 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 mask &= mask - 1;
                 cand[K - 1] = a.cw[chunk * 64 + b];
                 image_of(a.refl[2 * cand[K - 1]], pIx, pIy, imgx[K - 1], imgy[K - 1]);
-                eval_candidate<K, MODE, STATS, GRAD, false, false>(a, cand, imgx, imgy, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, g);
+                if (LIST) {
+                    float t = 0.0f;
+                    eval_candidate<K, MODE, STATS, GRAD, false, false>(a, cand, imgx, imgy, a.txx, a.txy, rxx, rxy, lane_bad, t, st, g);
+                    if (!(t == 0.0f)) sink->push(t);  // non-zero or NaN
+                } else {
+                    eval_candidate<K, MODE, STATS, GRAD, false, false>(a, cand, imgx, imgy, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, g);
+                }
             }
             if (STATS) st.c[14] += __builtin_amdgcn_s_memtime() - te0;  // exact evaluation of the survivors
         }
@@ -974,7 +1005,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
             if (carry) {
                 pos[d] += 1;
                 if (d > 0 && pos[d] == pos[d - 1]) pos[d] += 1;
-                if (pos[d] < Nc) {
+                if (pos[d] < (d == 0 ? p_end : Nc)) {
                     carry = false;
                     stop = d;
                 }
@@ -1019,10 +1050,10 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.c[i] = 0;
     st.shadow = -1;
-    // One 8 x 8 patch per wave when the host launches one workgroup per patch (the default: measured equal or better
-    // than 8192 persistent waves with static striding or an atomic work queue at 1024^2 .. 4096^2); the loop only
-    // matters for grids with more than 2^31 patches.
-    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // One 8 x 8 patch per wave, one wave per workgroup: measured equal or better than persistent waves walking several
+    // patches (static striding or an atomic work queue) at 1024^2 .. 4096^2, and it keeps the VGPR count lower.
+    const long tile0 = blockIdx.x;
+    const long tile = a.sched ? (long)a.sched[tile0] : tile0;
     const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tcol = (int)(tile % tiles_x), trow = (int)(tile / tiles_x);
     const int col = tcol * TILE_W + (lane & (TILE_W - 1));
@@ -1116,10 +1147,10 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
         tby_sum += wave_sum(g.tby);
     }
     if (STATS && lane == 0 && a.wave_cycles) a.wave_cycles[tile] = __builtin_amdgcn_s_memtime() - t_start;
-    }  // patches of this wave
     if (scene) {
         __syncthreads();
-        float* dst = a.partial + (long)blockIdx.x * (4 * a.N + 2);
+        // one row per patch: the row order of the fp64 reduction must not depend on the schedule
+        float* dst = a.partial + tile * (4 * a.N + 2);
         for (int i = lane; i < 4 * a.N; i += 64) dst[i] = wl[i];
         if (lane == 0) {
             dst[4 * a.N] = tbx_sum;
@@ -1129,6 +1160,232 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     if (STATS && lane == 0 && a.stats) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) atomicAdd(&a.stats[i], st.c[i]);
+    }
+}
+
+// Forward sweep with every 8 x 8 patch shared by W waves (one workgroup).  Patches differ a lot in cost and the dearest
+// ones sit on the critical path of a launch that only holds a few patches per SIMD (1024^2: 16), so the orders K >= 2
+// are cut into W contiguous ranges of first-wall positions (balanced over the first walls that the shadow masks do not
+// kill outright).  Wave 0 adds its range to acc directly; waves 1 .. W-1 record their non-zero contributions as ordered
+// per-lane lists in LDS, which wave 0 then adds in range order: the same left-to-right fp32 sum as the reference's
+// (scene.py:1893-1916), bit for bit.  A list that overflows is discarded and wave 0 redoes that range itself.
+template <int K, int MODE, bool STATS, int W>
+__device__ __forceinline__ void split_order(const SweepArgs& a, const float4* tab, float* lists, int* meta,
+                                            const float (&bx)[4], const float (&by)[4], float rxx, float rxy,
+                                            bool lane_bad, float& acc, WaveStats& st) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int Nc = a.Nc;
+    int* cnts = meta;             // [(W - 1)][64]
+    int* flags = meta + (W - 1) * 64;  // [(W - 1)] overflow, then [W + 1] range boundaries
+    int* bounds = flags + (W - 1);
+    // boundaries: position of the alive first wall of rank A * w / W
+    const bool use_dead = a.shadow && a.shadow_prefix_ok;
+    const int n_chunks = (Nc + 63) >> 6;
+    int A = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int pp = c * 64 + lane;
+        const bool alive = pp < Nc && !(use_dead && a.shadow[a.cw[pp]] == ~0ull);
+        A += __builtin_popcountll(__ballot(alive));
+    }
+    auto boundary = [&](int r) -> int {
+        if (r <= 0) return 0;
+        if (r >= A) return Nc;
+        for (int c = 0; c < n_chunks; ++c) {
+            const int pp = c * 64 + lane;
+            const bool alive = pp < Nc && !(use_dead && a.shadow[a.cw[pp]] == ~0ull);
+            unsigned long long m = __ballot(alive);
+            const int n = __builtin_popcountll(m);
+            if (r < n) {
+                for (; r > 0; --r) m &= m - 1;
+                return c * 64 + __builtin_ctzll(m);
+            }
+            r -= n;
+        }
+        return Nc;
+    };
+    const int my_lo = boundary((int)(((long)A * wv) / W));
+    const int my_hi = (wv == W - 1) ? Nc : boundary((int)(((long)A * (wv + 1)) / W));
+    if (lane == 0) {
+        bounds[wv] = my_lo;
+        if (wv == W - 1) bounds[W] = my_hi;
+    }
+    if (wv != 0) {
+        ListSink sink;
+        sink.col = lists + (size_t)(wv - 1) * SPLIT_LIST * 64 + lane;
+        sink.cnt = 0;
+        sink.over = false;
+        float dummy = 0.0f;
+        sweep_order_culled<K, MODE, STATS, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, my_lo, my_hi, &sink);
+        cnts[(wv - 1) * 64 + lane] = sink.cnt;
+        const bool over = wave_any(sink.over);
+        if (lane == 0) flags[wv - 1] = over ? 1 : 0;
+    }
+#pragma unroll 1
+    for (int w = 0; w < W; ++w) {
+        if (w == 1) __syncthreads();  // uniform: every wave runs this loop
+        if (wv == 0) {
+            if (w == 0 || flags[w - 1]) {
+                const int lo = (w == 0) ? my_lo : bounds[w], hi = (w == 0) ? my_hi : bounds[w + 1];
+                sweep_order_culled<K, MODE, STATS, false, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, nullptr, lo, hi, nullptr);
+            } else {
+                const int n = cnts[(w - 1) * 64 + lane];
+                int nmax = n;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+                const float* col = lists + (size_t)(w - 1) * SPLIT_LIST * 64 + lane;
+                for (int i = 0; i < nmax; ++i)
+                    if (i < n) acc = acc + col[i * 64];  // scene.py:1909, in candidate order
+            }
+        }
+    }
+    __syncthreads();  // lists and meta are reused by the next order
+}
+
+template <int MODE, bool STATS, int MAXK, int W>
+__global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then the contribution lists and their bookkeeping
+    for (int i = threadIdx.x; i < 2 * a.N; i += 64 * W) tab[i] = a.refl[i];
+    for (int i = threadIdx.x; i < a.N; i += 64 * W) tab[2 * a.N + i] = a.flt[i];
+    float* lists = reinterpret_cast<float*>(tab + 3 * a.N);
+    int* meta = reinterpret_cast<int*>(lists + (size_t)(W - 1) * SPLIT_LIST * 64);
+    __syncthreads();
+    const long slot = blockIdx.x;
+    WaveStats st;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st.c[i] = 0;
+    st.shadow = -1;
+    const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int tile = a.sched ? a.sched[slot] : (int)slot;
+    const int tcol = tile % tiles_x, trow = tile / tiles_x;
+    const int col = tcol * TILE_W + (lane & (TILE_W - 1));
+    const int row = trow * TILE_H + (lane / TILE_W);
+    const bool in_range = (col < a.n) && (row < a.m);
+    const int ccol = col < a.n ? col : a.n - 1;
+    const int crow = row < a.m ? row : a.m - 1;
+    const long idx = (long)crow * a.n + ccol;
+    const float rxx = a.X[idx], rxy = a.Y[idx];
+    const bool lane_bad = !(fabsf(rxx) < 1e18f) || !(fabsf(rxy) < 1e18f) || !(fabsf(a.txx) < 1e18f) ||
+                          !(fabsf(a.txy) < 1e18f);
+    float acc = 0.0f;  // scene.py:1893
+    float x0 = rxx, x1 = rxx, y0 = rxy, y1 = rxy;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, off, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
+        y0 = fminf(y0, __shfl_xor(y0, off, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+    }
+    const bool box_ok = !wave_any(lane_bad);
+    const float qn = __builtin_nanf("");
+    const float bx[4] = {box_ok ? x0 : qn, x1, x1, x0};
+    const float by[4] = {y0, y0, y1, y1};
+    const bool writer = wv == 0;
+    if (writer) {
+        if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, false>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, nullptr);
+        if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, nullptr);
+    }
+    if (a.min_order <= 2 && a.max_order >= 2) split_order<2, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) split_order<3, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) split_order<4, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st);
+    if (writer && in_range) {
+        if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
+        else a.out[idx] = acc;
+    }
+    if (STATS && writer && lane == 0 && a.wave_cycles) a.wave_cycles[tile] = __builtin_amdgcn_s_memtime() - t_start;
+    if (STATS && lane == 0 && a.stats) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atomicAdd(&a.stats[i], st.c[i]);
+    }
+}
+
+// Patch schedule.  The hardware starts workgroups in blockIdx order, and a dear patch that starts late is the tail of the
+// launch (1024^2, 50 walls: patches cost up to 3.6x the mean; starting the dear ones first is worth 20-30 %).  Cost
+// proxy of a patch: the number of order-1 candidates the tile culling cannot drop (first walls that are both reachable
+// from the patch and not in the fixed end point's shadow) -- every one of them opens a prefix of higher-order candidates.
+// patch_cost_kernel: one wave per patch -> key in [0, 63] + histogram;  patch_order_kernel: counting sort, dearest
+// first.  Ties are placed in atomic order: the schedule may differ from run to run, the results cannot.
+constexpr int SCHED_KEYS = 64;
+constexpr int SCHED_PER_THREAD = 16;  // patches per thread in the two counting-sort passes (few, aggregated global atomics)
+__global__ void __launch_bounds__(256) patch_cost_kernel(SweepArgs a, unsigned char* __restrict__ key) {
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
+    const int tiles_y = (a.m + TILE_H - 1) / TILE_H;
+    const long n_tiles = (long)tiles_x * tiles_y;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;  // whole wave
+    const int tcol = (int)(tile % tiles_x), trow = (int)(tile / tiles_x);
+    const int col = tcol * TILE_W + (lane & (TILE_W - 1));
+    const int row = trow * TILE_H + (lane / TILE_W);
+    const int ccol = col < a.n ? col : a.n - 1;
+    const int crow = row < a.m ? row : a.m - 1;
+    const long idx = (long)crow * a.n + ccol;
+    const float rxx = a.X[idx], rxy = a.Y[idx];
+    float x0 = rxx, x1 = rxx, y0 = rxy, y1 = rxy;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, off, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
+        y0 = fminf(y0, __shfl_xor(y0, off, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+    }
+    const float bx[4] = {x0, x1, x1, x0};
+    const float by[4] = {y0, y0, y1, y1};
+    int alive_n = 0;
+    for (int c0 = 0; c0 < a.Nc; c0 += 64) {
+        const int lp = c0 + lane;
+        const int wl = a.cw[lp < a.Nc ? lp : 0];
+        WallC w[1];
+        float Ix[1], Iy[1];
+        const float4 r0 = a.refl[2 * wl], r1 = a.refl[2 * wl + 1], fc = a.flt[wl];
+        w[0] = make_wallc(r0, r1, fc);
+        image_of(r0, a.txx, a.txy, Ix[0], Iy[0]);
+        const unsigned long long sh0 = a.shadow ? a.shadow[wl] : 0ull;
+        const bool alive = lp < a.Nc && !cull_candidate<1>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi, sh0, a.shadow_dperp, a.shadow_lo, a.shadow_inv);
+        alive_n += __builtin_popcountll(__ballot(alive));
+    }
+    if (lane == 0) key[tile] = (unsigned char)(((long)alive_n * (SCHED_KEYS - 1)) / (a.Nc > 0 ? a.Nc : 1));
+}
+
+// pass 1: hist[k] = number of patches with key k
+__global__ void __launch_bounds__(256) patch_hist_kernel(const unsigned char* __restrict__ key, int* __restrict__ hist, long n_tiles) {
+    __shared__ int cnt[SCHED_KEYS];
+    if (threadIdx.x < SCHED_KEYS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const long base = (long)blockIdx.x * (256 * SCHED_PER_THREAD);
+    for (int i = 0; i < SCHED_PER_THREAD; ++i) {
+        const long t = base + (long)i * 256 + threadIdx.x;
+        if (t < n_tiles) atomicAdd(&cnt[key[t]], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < SCHED_KEYS && cnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], cnt[threadIdx.x]);
+}
+
+// pass 2: scatter, dearest key first
+__global__ void __launch_bounds__(256) patch_order_kernel(const unsigned char* __restrict__ key, const int* __restrict__ hist,
+                                                          int* __restrict__ cursor, int* __restrict__ sched, long n_tiles) {
+    __shared__ int cnt[SCHED_KEYS], start[SCHED_KEYS];
+    if (threadIdx.x < SCHED_KEYS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const long base = (long)blockIdx.x * (256 * SCHED_PER_THREAD);
+    int local[SCHED_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < SCHED_PER_THREAD; ++i) {
+        const long t = base + (long)i * 256 + threadIdx.x;
+        local[i] = (t < n_tiles) ? atomicAdd(&cnt[key[t]], 1) : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < SCHED_KEYS) {
+        int s = 0;
+        for (int k = SCHED_KEYS - 1; k > (int)threadIdx.x; --k) s += hist[k];
+        start[threadIdx.x] = s + (cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]) : 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SCHED_PER_THREAD; ++i) {
+        const long t = base + (long)i * 256 + threadIdx.x;
+        if (t < n_tiles) sched[start[key[t]] + local[i]] = (int)t;
     }
 }
 

@@ -203,6 +203,10 @@ class Context:
         L.check(self._lib.d2d_power_map_stats(self._ctx, C.byref(params), tx, stats))
         return stats
 
+    def set_option(self, name: str, value: int) -> None:
+        """Launch-shape tuning (``split_max_tiles``, ``sched_min_tiles``): changes speed, never a result bit."""
+        L.check(self._lib.d2d_set_option(self._ctx, name.encode(), int(value)))
+
     def wave_cycles(self, params: L.Params, tx) -> np.ndarray:
         """Shader-clock ticks per wave (8 x 8 patch) of the instrumented forward sweep, shape (patch rows, patch cols)."""
         tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(2)

@@ -65,6 +65,9 @@ def main():
             walls, tx, X, Y, kw, allowed = random_case(rng)
             ctx.set_scene(walls)
             ctx.set_candidate_mask(allowed)
+            # every launch shape: patches shared between 4 waves or one wave each, identity or dearest-first order
+            ctx.set_option("split_max_tiles", 8192 if case % 2 == 0 else 0)
+            ctx.set_option("sched_min_tiles", 1 if case % 4 < 2 else 1 << 40)
             got = ctx.power_map(tx, X, Y, **kw)
             want = CO.power_map(walls, tx, X, Y, allowed=allowed, prune=True, **kw)
             if kw["function"] == "sigmoid" and kw["approx"]:

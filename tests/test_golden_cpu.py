@@ -9,7 +9,8 @@ import pytest
 from oracle import c_oracle as CO
 from oracle import ref as R
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+                if not os.path.basename(p).startswith("cfg4_samples"))  # those: test_gpu_forward.py (full-size configs[3])
 
 
 def test_fixtures_exist():
@@ -37,3 +38,23 @@ def test_oracle_fp32_autodiff_matches_golden_fp64():
     for k in ("grad_rx", "tx_bar", "walls_bar"):
         scale = np.abs(d[k]).max()
         assert np.abs(g[k] - d[k]).max() <= 2e-5 * scale
+
+
+def test_cfg4_sample_fixtures_are_consistent():
+    """Full-size configs[3] samples (scripts/make_golden_cfg4.py): shapes, and two cells recomputed for orders 0..2."""
+    import os
+
+    from conftest import random_scene
+    from oracle import c_oracle
+
+    tx, walls = random_scene(200, seed=1234)
+    x = np.linspace(0.0, 1.0, 2048).astype(np.float32)
+    for mode, kw in (("hard", dict(approx=False)), ("hsig", dict(approx=True, function="hard_sigmoid"))):
+        z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"cfg4_samples_{mode}.npz"))
+        ij = z["ij"]
+        assert z["per_order"].shape == (4, len(ij)) and z["total"].shape == (len(ij),)
+        sel = [0, len(ij) - 1]
+        X, Y = x[ij[sel, 1]], x[ij[sel, 0]]
+        for k in range(3):
+            got = c_oracle.power_map(walls, tx, X, Y, min_order=k, max_order=k, prune=True, **kw)
+            assert np.array_equal(got, z["per_order"][k][sel])

@@ -5,6 +5,8 @@ divide/sqrt, no contraction); sigmoid mode within rtol 2e-5 / atol 1e-5 (expf im
 differ by an ulp; BASELINE.json's tolerance is 1e-5).
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -16,11 +18,16 @@ F = np.float32
 MODES = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")]
 
 
-@pytest.fixture(scope="module")
-def ctx():
+# Launch shapes: these grids are small, so by default every patch is shared between 4 waves (power_fwd_split_kernel) in
+# identity order; the second variant forces what big grids get: one wave per patch, dearest patches first.
+@pytest.fixture(scope="module", params=["shared_patches", "one_wave_per_patch_scheduled"])
+def ctx(request):
     from differt2d_amd.engine import Context
 
     with Context(0) as c:
+        if request.param == "one_wave_per_patch_scheduled":
+            c.set_option("split_max_tiles", 0)
+            c.set_option("sched_min_tiles", 1)
         yield c
 
 
@@ -212,6 +219,26 @@ def test_cfg4_scene_200_walls_small_grid(ctx, approx, function):
     got = ctx.power_map(tx, X, Y, **kw)
     ctx.set_candidate_mask(None)
     _compare(got, _oracle(walls, tx, X, Y, allowed=allowed, **kw), function)
+
+
+@pytest.mark.parametrize("mode", ["hard", "hsig"])
+def test_cfg4_full_size_against_sampled_oracle_cells(ctx, mode):
+    """BASELINE.json configs[3] at FULL size -- 200 walls, 2048 x 2048 cells, orders 0..3 = 7 960 201 candidates per cell
+    (3.3e13 candidate evaluations) -- against 48 cells the C oracle computed in full (scripts/make_golden_cfg4.py, ~10 s
+    of CPU per cell and core): bit for bit, plus order 3 on its own."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"cfg4_samples_{mode}.npz"))
+    kw = dict(approx=False) if mode == "hard" else dict(approx=True, function="hard_sigmoid")
+    tx, walls = random_scene(200, seed=1234)
+    x = np.linspace(0.0, 1.0, 2048).astype(F)
+    X, Y = np.meshgrid(x, x)
+    ij = z["ij"]
+    ctx.set_scene(walls)
+    got = ctx.power_map(tx, X, Y, min_order=0, max_order=3, **kw)
+    assert np.array_equal(got[ij[:, 0], ij[:, 1]], z["total"])
+    assert np.isfinite(got).all() and (got >= 0).all()
+    got3 = ctx.power_map(tx, X, Y, order=3, **kw)
+    assert np.array_equal(got3[ij[:, 0], ij[:, 1]], z["per_order"][3])
+    assert (z["per_order"][3] != 0).sum() >= 5  # the sample does see third-order paths
 
 
 def test_bad_inputs_are_rejected_or_propagated(ctx):
