@@ -82,6 +82,8 @@ struct d2d_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evk0 = nullptr, evk1 = nullptr;  // around the dominant kernel of the last sweep ("time_kernel" option)
+    bool time_kernel = false, have_kernel_time = false;
     // scene (host copies)
     int N = 0;
     bool have_scene = false;
@@ -367,6 +369,8 @@ int d2d_create(int device, d2d_ctx** out) {
     if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->ev0);
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->ev1);
+    if (e1 == hipSuccess) e1 = hipEventCreate(&c->evk0);
+    if (e1 == hipSuccess) e1 = hipEventCreate(&c->evk1);
     if (e1 != hipSuccess) {
         delete c;
         return fail(D2D_ERR_HIP, "context creation failed: %s", hipGetErrorString(e1));
@@ -403,6 +407,8 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_grad.release(); c->d_cot.release(); c->d_partial.release(); c->d_vjp.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->evk0) (void)hipEventDestroy(c->evk0);
+    if (c->evk1) (void)hipEventDestroy(c->evk1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -731,6 +737,16 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         a.sched = c->d_sched.p;
     }
     if (txg && d_stats) return fail(D2D_ERR_UNSUPPORTED, "the instrumented build covers the RX-grid kernel only");
+    // everything above is preparation (memsets, shadow masks, schedule); what follows is the sweep kernel itself
+    c->have_kernel_time = false;
+    if (c->time_kernel) HIP_TRY(hipEventRecord(c->evk0, c->stream));
+#define D2D_KERNEL_DONE()                                        \
+    do {                                                         \
+        if (c->time_kernel) {                                    \
+            HIP_TRY(hipEventRecord(c->evk1, c->stream));         \
+            c->have_kernel_time = true;                          \
+        }                                                        \
+    } while (0)
     if (txg && !grad_mode) {
         // TX grid, values only: the per-lane-image code path without the adjoint
         const size_t lds0 = (size_t)(4 * c->N + 4) * sizeof(float);
@@ -741,6 +757,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             default: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_SIG, true, false>), grid, block, lds0, c->stream, a); break;
         }
         HIP_TRY(hipGetLastError());
+        D2D_KERNEL_DONE();
         return D2D_OK;
     }
     if (grad_mode) {
@@ -786,6 +803,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
         }
         HIP_TRY(hipGetLastError());
+        D2D_KERNEL_DONE();
         if (grad_mode == 2) {
             const long rows = (!txg && !p->strict_nan) ? (long)grid_walk.x : (long)tiles;  // one row of partials per launched wave
             hipLaunchKernelGGL(d2d::vjp_reduce_kernel, dim3((unsigned)n_elem), dim3(256), 0, c->stream, c->d_partial.p,
@@ -829,6 +847,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
     }
     HIP_TRY(hipGetLastError());
+    D2D_KERNEL_DONE();
     return D2D_OK;
 }
 
@@ -906,6 +925,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return fail(D2D_ERR_INVALID, "d2d_set_option: NULL argument");
     if (!strcmp(name, "split_max_tiles")) c->split_max_tiles = value;
     else if (!strcmp(name, "sched_min_tiles")) c->sched_min_tiles = value;
+    else if (!strcmp(name, "time_kernel")) c->time_kernel = value != 0;
     else return fail(D2D_ERR_INVALID, "d2d_set_option: unknown option '%s'", name);
     return D2D_OK;
 }
@@ -1150,6 +1170,16 @@ int d2d_comm_allreduce_host(d2d_ctx* c, double* values, int32_t n, int32_t op) {
     RCCL_TRY(rccl().AllReduce(c->d_hostred.p, c->d_hostred.p, (size_t)n, ncclFloat64, op ? ncclMax : ncclSum, c->comm, c->stream));
     HIP_TRY(hipMemcpyAsync(values, c->d_hostred.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return D2D_OK;
+}
+
+int d2d_last_kernel_ms(d2d_ctx* c, float* ms) {
+    if (!c || !ms) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (!c->have_kernel_time) return fail(D2D_ERR_INVALID, "no timed sweep: set the \"time_kernel\" option, then launch");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipEventSynchronize(c->evk1));
+    HIP_TRY(hipEventElapsedTime(ms, c->evk0, c->evk1));
     return D2D_OK;
 }
 

@@ -353,9 +353,9 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     for (int jj = -1; jj < a.N; ++jj) {
         int j = jj;
         if (jj < 0) {
-            if (GRAD || st.shadow < 0 || st.shadow >= a.N) continue;
+            if (st.shadow < 0 || st.shadow >= a.N) continue;
             j = st.shadow;
-        } else if (!GRAD && jj == st.shadow) {
+        } else if (jj == st.shadow) {
             continue;
         }
         const float4 w = a.occl[j];
@@ -393,7 +393,8 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     nanflag = nanflag || (ta != ta) || (tb != tb);
                     float c = fminf(fminf(clampact(ta - a.seg_lo, a.alpha), clampact(a.seg_hi - ta, a.alpha)),
                                     fminf(clampact(tb - a.seg_lo, a.alpha), clampact(a.seg_hi - tb, a.alpha)));
-                    if (GRAD && c > hit_c) {
+                    // arg-max as the reference's ascending (j, i) scan finds it: the first of equal maxima
+                    if (GRAD && (c > hit_c || (c == hit_c && hit_j >= 0 && (j < hit_j || (j == hit_j && i < hit_i))))) {
                         hit_i = i;
                         hit_j = j;
                     }
@@ -402,7 +403,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     nanflag = nanflag || (ta != ta) || (tb != tb);
                     float z = fminf(fminf(a.alpha * (ta - a.seg_lo), a.alpha * (a.seg_hi - ta)),
                                     fminf(a.alpha * (tb - a.seg_lo), a.alpha * (a.seg_hi - tb)));
-                    if (GRAD && z > hit_z) {
+                    if (GRAD && (z > hit_z || (z == hit_z && hit_j >= 0 && (j < hit_j || (j == hit_j && i < hit_i))))) {
                         hit_i = i;
                         hit_j = j;
                     }
@@ -847,6 +848,21 @@ __device__ __forceinline__ bool s_range(const float (&qx)[4], const float (&qy)[
     return (pos || neg) && fin;
 }
 
+// The pole part of s_range on its own: may un = (rx - image) . n vanish (or be non-finite) somewhere in the patch?
+__device__ __forceinline__ bool pole_possible(const float (&qx)[4], const float (&qy)[4], float Ix, float Iy, float nx, float ny) {
+    const float eps = 1.1920929e-07f;
+    bool pos = true, neg = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float ux = qx[j] - Ix, uy = qy[j] - Iy;
+        float un = __builtin_fmaf(ux, nx, uy * ny);
+        float du = 8.0f * eps * __builtin_fmaf(fabsf(nx), fabsf(qx[j]) + fabsf(Ix), fabsf(ny) * (fabsf(qy[j]) + fabsf(Iy)));
+        pos = pos && (un > du);
+        neg = neg && (un < -du);
+    }
+    return !(pos || neg);
+}
+
 // true = the candidate is certainly invalid for every cell of the patch.
 // walls[j], images[j] for j = K-1 (last wall) down to 0; level 1 uses the patch box.
 template <int K>
@@ -954,8 +970,13 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         // current tol / alpha (shadow_prefix_ok); so its first point does lie on the wall's line within rounding.)
         // Not in the value+grad build: the reference's un == 0 autodiff NaN must still be found in every candidate that
         // the per-candidate tests (which guarantee un != 0) cannot drop.
-        const bool prefix_dead = !GRAD && (K >= 2) && a.shadow && a.shadow_prefix_ok && (a.shadow[cand[0]] == ~0ull);
-        for (int chunk = 0; chunk < (prefix_dead ? 0 : n_chunks); ++chunk) {
+                // The value+grad build does not skip the prefix outright: where a cell sits exactly on the pole of the LAST
+        // reflection (un == 0 in the first step of the backward scan, geometry.py:1105), the reference's autodiff returns
+        // NaN whether or not the candidate is valid.  A dead prefix therefore keeps the candidates whose last-wall pole
+        // may cross the patch (a cheap test, few survivors) and evaluates those exactly.  NaN artefacts that only arise
+        // deeper in a dead prefix's chain are not reproduced (d2d_params.strict_nan is the exhaustive kernel).
+        const bool prefix_dead = (K >= 2) && a.shadow && a.shadow_prefix_ok && (a.shadow[cand[0]] == ~0ull);
+        for (int chunk = 0; chunk < ((prefix_dead && !GRAD) ? 0 : n_chunks); ++chunk) {
             // ---- lanes = candidates: lane l <-> last wall = cw[chunk * 64 + l]
             const int lp = chunk * 64 + lane;
             bool alive = (lp < Nc) && (lp != last_prefix_pos);
@@ -975,7 +996,8 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 }
                 unsigned long long sh0 = 0ull;
                 if (a.shadow) sh0 = a.shadow[(K == 1) ? wl : cand[0]];
-                if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi, sh0, a.shadow_dperp, a.shadow_lo, a.shadow_inv)) alive = false;
+                if (GRAD && prefix_dead) alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
+                else if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi, sh0, a.shadow_dperp, a.shadow_lo, a.shadow_inv)) alive = false;
             }
             unsigned long long mask = __ballot(alive);
             if (STATS) st.c[9] += K;

@@ -207,6 +207,12 @@ class Context:
         """Launch-shape tuning (``split_max_tiles``, ``sched_min_tiles``): changes speed, never a result bit."""
         L.check(self._lib.d2d_set_option(self._ctx, name.encode(), int(value)))
 
+    def last_kernel_ms(self) -> float:
+        """Duration of the sweep kernel of the last launch (needs ``set_option("time_kernel", 1)``)."""
+        ms = C.c_float(0.0)
+        L.check(self._lib.d2d_last_kernel_ms(self._ctx, C.byref(ms)))
+        return float(ms.value)
+
     def wave_cycles(self, params: L.Params, tx) -> np.ndarray:
         """Shader-clock ticks per wave (8 x 8 patch) of the instrumented forward sweep, shape (patch rows, patch cols)."""
         tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(2)

@@ -197,9 +197,15 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
 /* Launch-shape tuning of a context; never changes a result bit (tests sweep these to cover every kernel variant).
  *   "split_max_tiles": launches of at most this many 8 x 8 patches share every patch between 4 waves (default 8192; 0 = never)
  *   "sched_min_tiles": launches of at least this many patches start their dearest patches first (default 2048)
+ *   "time_kernel": non-zero = bracket the sweep kernel of every launch with HIP events (see d2d_last_kernel_ms)
  * Also read once at d2d_create from the environment: D2D_SPLIT_MAX_TILES, D2D_SCHED_MIN_TILES. No reference counterpart
  * (XLA picks its own launch shapes). Returns D2D_ERR_INVALID for an unknown name. */
 int d2d_set_option(d2d_ctx* ctx, const char* name, int64_t value);
+
+/* Duration of the sweep kernel proper of the last launch on this context -- without the preparation kernels in front
+ * of it (shadow masks, patch schedule) and the VJP reduction behind it -- from HIP events recorded on the context's
+ * stream; needs the "time_kernel" option. Waits for that kernel. This is the figure bench.py's roofline uses. */
+int d2d_last_kernel_ms(d2d_ctx* ctx, float* ms);
 
 /* Diagnostic: evaluates x[i] / y[i] on the GPU three ways -- q_fast: the kernels' bare fma chain on a refined
  * v_rcp; q_ref: the compiler's generic correctly rounded expansion; q_hostr: the bare chain on a host-computed
