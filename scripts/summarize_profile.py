@@ -52,7 +52,9 @@ for approx in (0, 1):
                 f"{2 * g('SQ_INSTS_VALU') / simd_cycles:.3f}; "
                 f"executed lane-ops/s = {64 * g('SQ_INSTS_VALU') / (avg_ms * 1e-3) / 1e12:.1f} T/s "
                 f"(non-FMA peak 78.6 T/s, FMA peak 157.3 TFLOP/s).\n"
-                f"HBM: FETCH_SIZE {g('FETCH_SIZE'):.0f} KiB (x2 on gfx950 per MI355X_MICROARCH.md = "
-                f"{2 * g('FETCH_SIZE') * 1024 / 1e6:.1f} MB), WRITE_SIZE {g('WRITE_SIZE'):.0f} KiB "
-                f"({g('WRITE_SIZE') * 1024 / 1e6:.1f} MB) per launch; algorithmic 12.6 MB.\n")
+                f"HBM: FETCH_SIZE {g('FETCH_SIZE'):.0f} KiB = {g('FETCH_SIZE') * 1024 / 1e6:.1f} MB as counted (these are "
+                f"4-byte-per-lane loads: MI355X_MICROARCH.md's x2 correction is calibrated for 16-B-per-lane streaming reads "
+                f"only, so {2 * g('FETCH_SIZE') * 1024 / 1e6:.1f} MB is the upper bound), WRITE_SIZE {g('WRITE_SIZE'):.0f} KiB "
+                f"({g('WRITE_SIZE') * 1024 / 1e6:.1f} MB) per launch; algorithmic 12.6 MB (8.4 read + 4.2 written). "
+                f"bench.py's roofline.traffic = FETCH_SIZE + WRITE_SIZE as counted.\n")
     print(open(os.path.join(root, "profiles", f"{tag}_a{approx}_summary.md")).read())
