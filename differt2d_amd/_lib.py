@@ -115,7 +115,7 @@ SYMBOLS = [
     ("d2d_comm_init", C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32]),
     ("d2d_comm_destroy", C.c_int, [_ctx]),
     ("d2d_comm_allgather_map", C.c_int, [_ctx, C.c_int32]),
-    ("d2d_comm_get_gathered", C.c_int, [_ctx, _f32p]),
+    ("d2d_comm_get_gathered", C.c_int, [_ctx, _f32p, C.c_int64]),
     ("d2d_comm_allreduce_vjp", C.c_int, [_ctx]),
     ("d2d_comm_allreduce_host", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_int32, C.c_int32]),
     ("d2d_timer_begin", C.c_int, [_ctx]),

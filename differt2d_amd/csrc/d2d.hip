@@ -126,7 +126,11 @@ struct d2d_ctx {
     // RCCL (one communicator per ctx, collectives run on the ctx stream)
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
-    DevBuf<float> d_gather;
+    DevBuf<float> d_gather, d_send;
+    // the all-gather of step k runs on its own stream, overlapped with the sweep of step k+1
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    bool gather_inflight = false;
     DevBuf<double> d_hostred;
     size_t gathered = 0;  // floats per rank in d_gather
 };
@@ -383,8 +387,10 @@ void d2d_destroy(d2d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
     c->d_gather.release();
+    c->d_send.release();
     c->d_hostred.release();
     c->d_occl.release();
     c->d_refl.release();
@@ -407,6 +413,10 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_grad.release(); c->d_cot.release(); c->d_partial.release(); c->d_vjp.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->evk0) (void)hipEventDestroy(c->evk0);
     if (c->evk1) (void)hipEventDestroy(c->evk1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -418,6 +428,10 @@ int d2d_synchronize(d2d_ctx* c) {
     int rc = set_device(c);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->gather_inflight) {
+        HIP_TRY(hipEventSynchronize(c->ev_done));
+        c->gather_inflight = false;
+    }
     return D2D_OK;
 }
 
@@ -1092,6 +1106,13 @@ int d2d_comm_unique_id(uint8_t* id) {
     return D2D_OK;
 }
 
+// Every later operation on the context's main stream that touches the communicator or the gathered map first waits for
+// the all-gather in flight on the communication stream.
+static int join_gather(d2d_ctx* c) {
+    if (c->gather_inflight) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
+    return D2D_OK;
+}
+
 int d2d_comm_init(d2d_ctx* c, const uint8_t* id, int32_t rank, int32_t world) {
     if (!c || !id) return fail(D2D_ERR_INVALID, "NULL argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(D2D_ERR_INVALID, "bad rank %d of %d", rank, world);
@@ -1115,6 +1136,8 @@ int d2d_comm_destroy(d2d_ctx* c) {
     if (c->comm) {
         (void)set_device(c);
         (void)hipStreamSynchronize(c->stream);
+        if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+        c->gather_inflight = false;
         rccl().CommDestroy(c->comm);
         c->comm = nullptr;
     }
@@ -1133,16 +1156,33 @@ int d2d_comm_allgather_map(d2d_ctx* c, int32_t what) {
     if (rc) return rc;
     const size_t per_rank = (size_t)c->m * c->n * (what ? 2 : 1);
     if ((rc = c->d_gather.ensure(per_rank * (size_t)c->world))) return rc;
-    RCCL_TRY(rccl().AllGather(what ? c->d_grad.p : c->d_out.p, c->d_gather.p, per_rank, ncclFloat32, c->comm, c->stream));
+    if ((rc = c->d_send.ensure(per_rank))) return rc;
+    if (!c->comm_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    }
+    // main stream: (previous gather has finished reading the staging copy) -> copy this step's shard -> ready;
+    // communication stream: ready -> all-gather -> done.  The next sweep does not wait for `done`.
+    if ((rc = join_gather(c))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_send.p, what ? c->d_grad.p : c->d_out.p, per_rank * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_ready, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
+    RCCL_TRY(rccl().AllGather(c->d_send.p, c->d_gather.p, per_rank, ncclFloat32, c->comm, c->comm_stream));
+    HIP_TRY(hipEventRecord(c->ev_done, c->comm_stream));
+    c->gather_inflight = true;
     c->gathered = per_rank;
     return D2D_OK;
 }
 
-int d2d_comm_get_gathered(d2d_ctx* c, float* out) {
+int d2d_comm_get_gathered(d2d_ctx* c, float* out, int64_t capacity) {
     if (!c || !out) return fail(D2D_ERR_INVALID, "NULL argument");
     if (!c->gathered) return fail(D2D_ERR_STATE, "nothing has been gathered");
+    if (capacity != (int64_t)(c->gathered * (size_t)c->world))
+        return fail(D2D_ERR_INVALID, "the last all-gather holds %lld floats (%d ranks), the buffer %lld", (long long)(c->gathered * (size_t)c->world), c->world, (long long)capacity);
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = join_gather(c))) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->d_gather.p, c->gathered * (size_t)c->world * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return D2D_OK;
@@ -1154,6 +1194,7 @@ int d2d_comm_allreduce_vjp(d2d_ctx* c) {
     if (!c->have_vjp) return fail(D2D_ERR_STATE, "no scene-VJP sweep has run");
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = join_gather(c))) return rc;  // collectives of one communicator execute in issue order
     RCCL_TRY(rccl().AllReduce(c->d_vjp.p, c->d_vjp.p, (size_t)(4 * c->N + 2), ncclFloat64, ncclSum, c->comm, c->stream));
     return D2D_OK;
 }
@@ -1166,6 +1207,7 @@ int d2d_comm_allreduce_host(d2d_ctx* c, double* values, int32_t n, int32_t op) {
     int rc = set_device(c);
     if (rc) return rc;
     if ((rc = c->d_hostred.ensure((size_t)n))) return rc;
+    if ((rc = join_gather(c))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_hostred.p, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     RCCL_TRY(rccl().AllReduce(c->d_hostred.p, c->d_hostred.p, (size_t)n, ncclFloat64, op ? ncclMax : ncclSum, c->comm, c->stream));
     HIP_TRY(hipMemcpyAsync(values, c->d_hostred.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1195,6 +1237,7 @@ int d2d_timer_end(d2d_ctx* c, float* ms) {
     if (!c || !ms) return fail(D2D_ERR_INVALID, "NULL argument");
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = join_gather(c))) return rc;  // the timed region ends when the last all-gather has landed
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));

@@ -324,7 +324,7 @@ class Context:
     def comm_get_gathered(self, world: int, grad: bool = False) -> np.ndarray:
         shape = (world, *self.shape, 2) if grad else (world, *self.shape)
         out = np.empty(shape, np.float32)
-        L.check(self._lib.d2d_comm_get_gathered(self._ctx, out.reshape(-1)))
+        L.check(self._lib.d2d_comm_get_gathered(self._ctx, out.reshape(-1), out.size))
         return out
 
     def comm_allreduce_vjp(self):

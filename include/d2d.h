@@ -245,12 +245,14 @@ int d2d_comm_unique_id(uint8_t* id /* [D2D_COMM_ID_BYTES] */);
 /* Collective: ncclCommInitRank on the ctx's device. */
 int d2d_comm_init(d2d_ctx* ctx, const uint8_t* id, int32_t rank, int32_t world);
 int d2d_comm_destroy(d2d_ctx* ctx);
-/* Collective, asynchronous on the ctx stream: all-gathers this rank's resident map (what = 0: value map,
- * m*n floats; what = 1: grad_rx map, m*n*2 floats; every rank must hold the same m, n) into a resident
- * buffer [world][...]. */
+/* Collective, asynchronous: all-gathers this rank's resident map (what = 0: value map, m*n floats; what = 1:
+ * grad_rx map, m*n*2 floats; every rank must hold the same m, n) into a resident buffer [world][...]. The map is
+ * first copied aside on the ctx stream and the all-gather runs on a second stream behind that copy, so the NEXT sweep
+ * on this ctx overlaps with it; d2d_synchronize, d2d_timer_end, d2d_comm_get_gathered and the other collectives wait
+ * for the all-gather in flight. */
 int d2d_comm_allgather_map(d2d_ctx* ctx, int32_t what);
-/* Synchronises and copies the gathered buffer to out[world * per_rank]. */
-int d2d_comm_get_gathered(d2d_ctx* ctx, float* out);
+/* Synchronises and copies the gathered buffer to out[world * per_rank]; capacity (in floats) must be exactly that. */
+int d2d_comm_get_gathered(d2d_ctx* ctx, float* out, int64_t capacity);
 /* Collective, asynchronous: sums the resident scene VJP (fp64, 4N+2 values) over ranks in place. */
 int d2d_comm_allreduce_vjp(d2d_ctx* ctx);
 

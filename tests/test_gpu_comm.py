@@ -50,4 +50,27 @@ def _roundtrip():
         ctx.comm_allgather_map(grad=True)
         g = ctx.comm_get_gathered(1, grad=True)
         assert np.array_equal(g[0], ctx.get_grad_rx())
+        # the all-gather of step k runs on its own stream while step k+1 sweeps: the gathered map must be step k's
+        # even though the next sweep has already overwritten the context's value map
+        txs = [np.array([0.3 + 0.05 * k, 0.4], np.float32) for k in range(4)]
+        maps = []
+        for t in txs:
+            ctx.launch(p, t)
+            maps.append(ctx.get_map())
+        assert not np.array_equal(maps[0], maps[1])
+        for k, t in enumerate(txs):
+            ctx.launch(p, t)
+            ctx.comm_allgather_map()              # sweep + all-gather, no host synchronisation
+            if k + 1 < len(txs):
+                ctx.launch(p, txs[k + 1])         # overwrites d_out while the gather may still be in flight
+                assert np.array_equal(ctx.comm_get_gathered(1)[0], maps[k])
+                assert np.array_equal(ctx.get_map(), maps[k + 1])
+        for t in txs:                             # back-to-back steps, one synchronisation at the end
+            ctx.launch(p, t)
+            ctx.comm_allgather_map()
+        ctx.synchronize()
+        with pytest.raises(Exception):            # a buffer of the wrong size is refused, not overrun
+            ctx.comm_get_gathered(1, grad=True)
+        assert np.array_equal(ctx.comm_get_gathered(1)[0], maps[-1])
+        assert ctx.comm_allreduce_host([3.0], "max")[0] == 3.0
         ctx.comm_destroy()
