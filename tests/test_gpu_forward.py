@@ -156,6 +156,26 @@ def test_cfg2_subgrid_50_walls_order2(ctx, approx, function):
         assert np.array_equal(got, want), f"{(got != want).sum()} cells disagree on the valid-path count"
 
 
+@pytest.mark.parametrize("approx,function", MODES[:2])
+def test_cfg2_full_size_sampled_cells_and_block_invariance(ctx, approx, function):
+    """BASELINE.json configs[1] exactly as bench.py runs it (50 walls, 1024 x 1024 cells, orders 0..2): 4096 random cells
+    against the oracle, bit for bit; and a block cut out at an offset that is not a multiple of the 8 x 8 patch must
+    reproduce the same cells (every cell is independent: what the culling decides per patch cannot matter)."""
+    tx, walls = random_scene(50, seed=1234)
+    x = np.linspace(0.0, 1.0, 1024).astype(F)
+    X, Y = np.meshgrid(x, x)
+    ctx.set_scene(walls)
+    kw = dict(min_order=0, max_order=2, approx=approx, function=function)
+    got = ctx.power_map(tx, X, Y, **kw)
+    rng = np.random.default_rng(7)
+    ii, jj = rng.integers(0, 1024, 4096), rng.integers(0, 1024, 4096)
+    want = _oracle(walls, tx, X[ii, jj], Y[ii, jj], **kw)
+    assert np.array_equal(got[ii, jj], want)
+    assert (want > 0).sum() > 100  # the sample sees plenty of lit cells
+    block = ctx.power_map(tx, X[403:446, 617:700], Y[403:446, 617:700], **kw)
+    assert np.array_equal(block, got[403:446, 617:700])
+
+
 def test_errors_are_loud(ctx):
     from differt2d_amd import _lib as L
     from differt2d_amd.engine import make_params
