@@ -114,6 +114,54 @@ def file_rendezvous_cleanup(rank: int):
         shutil.rmtree(rendezvous_dir(), ignore_errors=True)
 
 
+class FileHostComm:
+    """Control plane of last resort for ONE node: barrier and all-reduce of a few host doubles through small files in
+    the rendezvous directory (busy-polled).  bench.py falls back to it when the RCCL communicator cannot be created,
+    so that the row-sharded sweep -- which needs no data-path collective -- can still be timed over all ranks."""
+
+    def __init__(self, rank: int, world: int, directory: Optional[str] = None):
+        import os
+
+        self.rank, self.world = int(rank), int(world)
+        self.dir = directory or rendezvous_dir() + "_ctl"
+        os.makedirs(self.dir, exist_ok=True)
+        self.seq = 0
+
+    def allreduce(self, values, op: str = "sum") -> np.ndarray:
+        import os
+        import time
+
+        v = np.atleast_1d(np.asarray(values, dtype=np.float64))
+        self.seq += 1
+        mine = os.path.join(self.dir, f"r{self.seq}_{self.rank}.npy")
+        with open(mine + ".tmp", "wb") as f:
+            np.save(f, v)
+        os.replace(mine + ".tmp", mine)
+        parts = []
+        t0 = time.time()
+        for r in range(self.world):
+            path = os.path.join(self.dir, f"r{self.seq}_{r}.npy")
+            while True:
+                try:
+                    with open(path, "rb") as f:
+                        parts.append(np.load(f))
+                    break
+                except (OSError, ValueError, EOFError):
+                    if time.time() - t0 > 600.0:
+                        raise TimeoutError(f"rank {self.rank}: rank {r} never reached step {self.seq}")
+                    time.sleep(0)
+        if self.seq > 2:  # everybody has read round seq-2 by now (it took part in round seq-1 after reading it)
+            try:
+                os.remove(os.path.join(self.dir, f"r{self.seq - 2}_{self.rank}.npy"))
+            except OSError:
+                pass
+        stack = np.stack(parts)
+        return stack.max(0) if op == "max" else stack.sum(0)
+
+    def barrier(self):
+        self.allreduce([1.0], "sum")
+
+
 class GlooHostComm:
     """Host-array all-gather / all-reduce over an initialised ``torch.distributed`` group (CPU tests)."""
 

@@ -116,3 +116,38 @@ def test_file_rendezvous_ships_the_unique_id(tmp_path):
     finally:
         del os.environ["D2D_RDZV_DIR"]
     assert not os.path.exists(d)
+
+
+def _filecomm_worker(rank, world, d, q):
+    sys.path.insert(0, ROOT)
+    from differt2d_amd.parallel import FileHostComm
+
+    comm = FileHostComm(rank, world, directory=d)
+    out = []
+    for it in range(6):  # several rounds: old round files are removed as it goes
+        comm.barrier()
+        out.append(float(comm.allreduce([rank + 10.0 * it], "max")[0]))
+        out.append(float(comm.allreduce([rank + 1.0], "sum")[0]))
+    q.put((rank, out, sorted(os.listdir(d))))
+
+
+def test_file_host_comm_barrier_and_allreduce(tmp_path):
+    """bench.py's control plane of last resort (no RCCL communicator): world_size 3 over files."""
+    import multiprocessing as mp
+
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    d = str(tmp_path / "ctl")
+    world = 3
+    procs = [mpctx.Process(target=_filecomm_worker, args=(r, world, d, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    want = []
+    for it in range(6):
+        want += [world - 1 + 10.0 * it, world * (world + 1) / 2]
+    for rank, out, _ in res:
+        assert out == want, (rank, out)
+    assert max(len(files) for _, _, files in res) <= 3 * world  # at most the last few rounds are left behind
