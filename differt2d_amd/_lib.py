@@ -102,6 +102,9 @@ SYMBOLS = [
     ("d2d_get_scene_vjp", C.c_int, [_ctx, _f32p, C.c_void_p]),
     ("d2d_power_map_stats", C.c_int, [_ctx, C.POINTER(Params), _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]),
     ("d2d_set_option", C.c_int, [_ctx, C.c_char_p, C.c_int64]),
+    ("d2d_debug_set_schedule", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), C.c_int64]),
+    ("d2d_debug_get_schedule", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"),
+                                         np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.c_int64]),
     ("d2d_last_kernel_ms", C.c_int, [_ctx, C.POINTER(C.c_float)]),
     ("d2d_power_map_wave_cycles", C.c_int, [_ctx, C.POINTER(Params), _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS"),
                                             C.c_int64, C.POINTER(C.c_int64)]),

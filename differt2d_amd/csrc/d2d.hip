@@ -111,8 +111,13 @@ struct d2d_ctx {
     bool have_grid = false;
     DevBuf<float> d_X, d_Y, d_out;
     DevBuf<unsigned long long> d_stats, d_shadow;
-    DevBuf<int> d_sched, d_sched_hist;  // patch schedule, {histogram, cursors}
+    DevBuf<int> d_sched;                // patch schedule (its sort's histogram and cursors live behind d_shadow)
     DevBuf<unsigned char> d_sched_key;
+    DevBuf<unsigned> d_cost;            // what every patch cost in the last culled sweep of this grid (ticks >> 6)
+    long long cost_tiles = 0;           // 0 = no history (scene, grid or candidate mask changed since)
+    DevBuf<int> d_sched_override;       // diagnostic: a caller-supplied schedule (d2d_debug_set_schedule)
+    long long sched_override_n = 0;
+    bool use_cost_history = true;
     long long sched_min_tiles = 2048;   // launches with fewer patches keep the identity schedule
     float grid_absmax = 0.0f;   // max |coordinate| of the grid (host scan at d2d_set_grid)
     float scene_absmax = 0.0f;  // max |coordinate| of the objects
@@ -409,7 +414,8 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_shadow.release();
     c->d_sched.release();
     c->d_sched_key.release();
-    c->d_sched_hist.release();
+    c->d_sched_override.release();
+    c->d_cost.release();
     c->d_grad.release(); c->d_cot.release(); c->d_partial.release(); c->d_vjp.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -437,6 +443,7 @@ int d2d_synchronize(d2d_ctx* c) {
 
 int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float* phi, int32_t n_objects) {
     if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    c->cost_tiles = 0;  // the patch-cost history describes another sweep
     if (n_objects < 0 || (n_objects > 0 && !xys)) return fail(D2D_ERR_INVALID, "bad scene arguments");
     int rc = set_device(c);
     if (rc) return rc;
@@ -464,6 +471,7 @@ int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float
 
 int d2d_set_candidate_mask(d2d_ctx* c, const uint8_t* allowed) {
     if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    c->cost_tiles = 0;  // the patch-cost history describes another sweep
     if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
     int rc = set_device(c);
     if (rc) return rc;
@@ -542,6 +550,7 @@ int d2d_list_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int32_
 
 int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t n) {
     if (!c || !X || !Y) return fail(D2D_ERR_INVALID, "NULL argument");
+    c->cost_tiles = 0;  // the patch-cost history describes another sweep
     if (m <= 0 || n <= 0) return fail(D2D_ERR_INVALID, "grid must be at least 1 x 1, got %d x %d", m, n);
     int rc = set_device(c);
     if (rc) return rc;
@@ -707,9 +716,12 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     // first-segment shadow coverage (RX grids: the fixed end point is the transmitter)
     a.shadow = nullptr;
     a.shadow_dperp = 0.0f;
+    bool prep_zeroed = false;
     if (!txg && c->N >= 2 && p->max_order >= 1) {
-        if ((rc = c->d_shadow.ensure((size_t)c->N))) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_shadow.p, 0, (size_t)c->N * sizeof(unsigned long long), c->stream));
+        // [N] masks, then the {histogram, cursors} of the patch schedule's counting sort: one memset for both
+        if ((rc = c->d_shadow.ensure((size_t)c->N + d2d::SCHED_KEYS))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_shadow.p, 0, ((size_t)c->N + d2d::SCHED_KEYS) * sizeof(unsigned long long), c->stream));
+        prep_zeroed = true;
         // window where a test is certainly "hit" (hard) / exactly saturated to 1 (approx): shrink [-tol, 1+tol] by widen
         const double in_lo = -(double)p->seg_tol + widen_in, in_hi = 1.0 + (double)p->seg_tol - widen_in;
         float ext = std::fmax(std::fmax(c->scene_absmax, c->grid_absmax), std::fmax(std::fabs(tx[0]), std::fabs(tx[1])));
@@ -739,16 +751,33 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     if (!txg && !(grad_mode && p->strict_nan) && p->max_order >= 2 && c->cw.size() >= 2 && tiles >= c->sched_min_tiles) {
         if ((rc = c->d_sched.ensure((size_t)tiles))) return rc;
         if ((rc = c->d_sched_key.ensure((size_t)tiles))) return rc;
-        if ((rc = c->d_sched_hist.ensure(2 * d2d::SCHED_KEYS))) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_sched_hist.p, 0, 2 * d2d::SCHED_KEYS * sizeof(int), c->stream));
-        const unsigned sort_blocks = (unsigned)((tiles + 256 * d2d::SCHED_PER_THREAD - 1) / (256 * d2d::SCHED_PER_THREAD));
-        hipLaunchKernelGGL(d2d::patch_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, a, c->d_sched_key.p);
-        hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p,
-                           c->d_sched_hist.p, (long)tiles);
-        hipLaunchKernelGGL(d2d::patch_order_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p,
-                           c->d_sched_hist.p, c->d_sched_hist.p + d2d::SCHED_KEYS, c->d_sched.p, (long)tiles);
+        if (!prep_zeroed) {
+            if ((rc = c->d_shadow.ensure((size_t)c->N + d2d::SCHED_KEYS))) return rc;
+            HIP_TRY(hipMemsetAsync(c->d_shadow.p + c->N, 0, d2d::SCHED_KEYS * sizeof(unsigned long long), c->stream));
+        }
+        int* hist = reinterpret_cast<int*>(c->d_shadow.p + c->N);  // [SCHED_KEYS] counts, [SCHED_KEYS] cursors
+        // cost key: what the patch cost last time, when this context has swept the same grid before (optimisation
+        // loops, repeated maps); otherwise a proxy computed from the geometry
+        if (c->cost_tiles == tiles && c->use_cost_history)
+            hipLaunchKernelGGL(d2d::patch_key_from_cost_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, c->stream,
+                               c->d_cost.p, c->d_sched_key.p, (long)tiles);
+        else
+            hipLaunchKernelGGL(d2d::patch_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, a, c->d_sched_key.p);
+        {
+            const unsigned sort_blocks = (unsigned)((tiles + 256 * d2d::SCHED_PER_THREAD - 1) / (256 * d2d::SCHED_PER_THREAD));
+            hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p, hist, (long)tiles);
+            hipLaunchKernelGGL(d2d::patch_order_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p, hist,
+                               hist + d2d::SCHED_KEYS, c->d_sched.p, (long)tiles);
+        }
         HIP_TRY(hipGetLastError());
         a.sched = c->d_sched.p;
+    }
+    if (c->sched_override_n == tiles && !txg) a.sched = c->d_sched_override.p;
+    a.cost_out = nullptr;
+    if (a.sched && !d_stats) {
+        if ((rc = c->d_cost.ensure((size_t)tiles))) return rc;
+        a.cost_out = c->d_cost.p;  // the kernels launched below count the work of every patch
+        c->cost_tiles = tiles;     // (stream order: the next launch's key kernel runs after this sweep)
     }
     if (txg && d_stats) return fail(D2D_ERR_UNSUPPORTED, "the instrumented build covers the RX-grid kernel only");
     // everything above is preparation (memsets, shadow masks, schedule); what follows is the sweep kernel itself
@@ -940,7 +969,37 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "split_max_tiles")) c->split_max_tiles = value;
     else if (!strcmp(name, "sched_min_tiles")) c->sched_min_tiles = value;
     else if (!strcmp(name, "time_kernel")) c->time_kernel = value != 0;
+    else if (!strcmp(name, "cost_history")) c->use_cost_history = value != 0;
     else return fail(D2D_ERR_INVALID, "d2d_set_option: unknown option '%s'", name);
+    return D2D_OK;
+}
+
+int d2d_debug_set_schedule(d2d_ctx* c, const int32_t* order, int64_t n) {
+    if (!c || (n > 0 && !order)) return fail(D2D_ERR_INVALID, "NULL argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    c->sched_override_n = 0;
+    if (n <= 0) return D2D_OK;
+    std::vector<char> seen((size_t)n, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (order[i] < 0 || order[i] >= n || seen[(size_t)order[i]]) return fail(D2D_ERR_INVALID, "schedule is not a permutation of 0..%lld", (long long)n - 1);
+        seen[(size_t)order[i]] = 1;
+    }
+    if ((rc = c->d_sched_override.ensure((size_t)n))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_sched_override.p, order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->sched_override_n = n;
+    return D2D_OK;
+}
+
+int d2d_debug_get_schedule(d2d_ctx* c, int32_t* order, uint8_t* key, int64_t n) {
+    if (!c || !order || !key) return fail(D2D_ERR_INVALID, "NULL argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (!c->d_sched.p || !c->d_sched_key.p || (size_t)n > c->d_sched.n) return fail(D2D_ERR_STATE, "no schedule of %lld patches has been built", (long long)n);
+    HIP_TRY(hipMemcpyAsync(order, c->d_sched.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(key, c->d_sched_key.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return D2D_OK;
 }
 

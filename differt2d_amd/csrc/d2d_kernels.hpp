@@ -61,11 +61,16 @@ struct SweepArgs {
 
     // patch schedule (patch_cost_kernel / patch_order_kernel): workgroup b takes patch sched[b]; null = identity
     const int* __restrict__ sched;
+    unsigned* __restrict__ cost_out;  // [n_patches] work this patch took (feeds the next launch's schedule), or null
 
     unsigned long long* stats; // [D2D_NUM_STATS] executed-work counters (STATS build only), may be null
     unsigned long long* wave_cycles;  // [n_patches] shader clock ticks spent per patch (STATS build only), may be null
 };
 
+// Work counter of the patch a wave is sweeping, in units of ~25 wave-instructions (wave-uniform: one s_add).  It feeds
+// the next launch's dearest-first schedule.  (A/B on one MI355X: ordering by elapsed ticks instead costs nothing to
+// measure but schedules 5 % worse at 1024^2; this counter costs 4 % at 4096^2, where the schedule hardly matters.)
+#define D2D_WORK(x) (st.work += (x))
 #define D2D_EPS 1.1920929e-07f  // jnp.finfo(float32).eps, geometry.py:200
 
 // Executed-work counters of one wave (wave-uniform, live in SGPRs). Only the STATS build of the
@@ -77,6 +82,7 @@ struct SweepArgs {
 struct WaveStats {
     unsigned long long c[16];  // [9] tile-culling levels evaluated; [10..15] shader-clock ticks per phase (diagnostic)
     int shadow;                // wave state, not a counter: the wall that occluded the wave's previous candidate
+    unsigned work;             // every build: work done for this patch in units of ~25 wave-instructions (feeds the schedule)
 };
 
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p); }
@@ -235,6 +241,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         if (!wave_any(!cull)) return;
     }
 
+    D2D_WORK(6 + 2 * K);  // backward scan + on_objects
     if (STATS) {
         st.c[0] += 1;
         st.c[6] += K;
@@ -335,6 +342,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // not intersects, loss < tol): the three terms commute, so the cheap-to-refute occlusion comes before the loss.)
     const bool live = !on_zero || bad;
     if (STATS) st.c[2] += 1;
+    D2D_WORK(1);
 
     // ---- intersects_with_objects, geometry.py:856-906 / 623-639 / 82-173 -------------------
     float bx[K + 1], by[K + 1];
@@ -378,6 +386,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             if (STATS) st.c[4] += 1;
             const bool need = wave_any(active && (!miss || bad));
             if (STATS && need) st.c[5] += 1;
+            D2D_WORK(need ? 3 : 1);
             if (need) {
                 // exact path, geometry.py:163-171
                 bool dz = (fd == 0.0f);
@@ -424,6 +433,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     if (!wave_any(active)) return;
 
     if (STATS) st.c[1] += 1;
+    D2D_WORK(4 * K);
     // ---- path loss, geometry.py:1077-1084 / 641-650 ---------------------------------------
     // The loss of an image-method path is rounding noise (~1e-13) unless the path is degenerate, and it only
     // enters through less(loss, tol).  Certificate: evaluate the specular residuals e_i cheaply (v_rsq, fma);
@@ -498,6 +508,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // valid is exactly 0 in every lane (all occluded): acc + 0 * fun == acc, and every adjoint is 0
     if (!wave_any(valid != 0.0f || bad)) return;
     if (STATS) st.c[3] += 1, st.c[8] += K + 1;
+    D2D_WORK(6);
     // ---- fun(path), geometry.py:176-203 and utils.py:17-54 ---------------------------------
     float r = 0.0f;
 #pragma unroll
@@ -1001,6 +1012,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
             }
             unsigned long long mask = __ballot(alive);
             if (STATS) st.c[9] += K;
+            D2D_WORK(5 * K);  // one culling level = 4 vertex evaluations
             const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
             // ---- lanes = RX cells: survivors in ascending order (= the reference's order)
             while (mask) {
@@ -1072,6 +1084,7 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.c[i] = 0;
     st.shadow = -1;
+    st.work = 0;
     // One 8 x 8 patch per wave, one wave per workgroup: measured equal or better than persistent waves walking several
     // patches (static striding or an atomic work queue) at 1024^2 .. 4096^2, and it keeps the VGPR count lower.
     const long tile0 = blockIdx.x;
@@ -1169,6 +1182,7 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
         tby_sum += wave_sum(g.tby);
     }
     if (STATS && lane == 0 && a.wave_cycles) a.wave_cycles[tile] = __builtin_amdgcn_s_memtime() - t_start;
+    if (!STATS && a.cost_out && lane == 0) a.cost_out[tile] = st.work;
     if (scene) {
         __syncthreads();
         // one row per patch: the row order of the fp64 reduction must not depend on the schedule
@@ -1278,6 +1292,7 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.c[i] = 0;
     st.shadow = -1;
+    st.work = 0;
     const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tile = a.sched ? a.sched[slot] : (int)slot;
     const int tcol = tile % tiles_x, trow = tile / tiles_x;
@@ -1316,6 +1331,17 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
         else a.out[idx] = acc;
     }
     if (STATS && writer && lane == 0 && a.wave_cycles) a.wave_cycles[tile] = __builtin_amdgcn_s_memtime() - t_start;
+    if (!STATS && a.cost_out) {  // workgroup-uniform: the work of the patch = the sum over its W waves
+        __shared__ unsigned wave_work[W];
+        if (lane == 0) wave_work[wv] = st.work;
+        __syncthreads();
+        if (wv == 0 && lane == 0) {
+            unsigned sum = 0;
+#pragma unroll
+            for (int i = 0; i < W; ++i) sum += wave_work[i];
+            a.cost_out[tile] = sum;
+        }
+    }
     if (STATS && lane == 0 && a.stats) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) atomicAdd(&a.stats[i], st.c[i]);
@@ -1328,7 +1354,7 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
 // from the patch and not in the fixed end point's shadow) -- every one of them opens a prefix of higher-order candidates.
 // patch_cost_kernel: one wave per patch -> key in [0, 63] + histogram;  patch_order_kernel: counting sort, dearest
 // first.  Ties are placed in atomic order: the schedule may differ from run to run, the results cannot.
-constexpr int SCHED_KEYS = 64;
+constexpr int SCHED_KEYS = 256;  // = blockDim of the two sort passes
 constexpr int SCHED_PER_THREAD = 16;  // patches per thread in the two counting-sort passes (few, aggregated global atomics)
 __global__ void __launch_bounds__(256) patch_cost_kernel(SweepArgs a, unsigned char* __restrict__ key) {
     const int lane = threadIdx.x & 63;
@@ -1368,6 +1394,16 @@ __global__ void __launch_bounds__(256) patch_cost_kernel(SweepArgs a, unsigned c
         alive_n += __builtin_popcountll(__ballot(alive));
     }
     if (lane == 0) key[tile] = (unsigned char)(((long)alive_n * (SCHED_KEYS - 1)) / (a.Nc > 0 ? a.Nc : 1));
+}
+
+// Cost key of a patch from the work it took the last time this context swept the same grid (counted by the sweep kernels
+// themselves in units of ~25 wave-instructions: deterministic, unlike elapsed time): 8 buckets per octave, 9 % resolution.
+__global__ void __launch_bounds__(256) patch_key_from_cost_kernel(const unsigned* __restrict__ cost, unsigned char* __restrict__ key, long n_tiles) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const float c = (float)(cost[t] | 1u);
+    int k = (int)(8.0f * __log2f(c)) - 16;  // 2^2 .. 2^34 units -> 0 .. 255
+    key[t] = (unsigned char)(k < 0 ? 0 : (k > SCHED_KEYS - 1 ? SCHED_KEYS - 1 : k));
 }
 
 // pass 1: hist[k] = number of patches with key k
@@ -1514,6 +1550,7 @@ __global__ void __launch_bounds__(64) power_vg_kernel(SweepArgs a) {
     float acc = 0.0f;
     WaveStats st;
     st.shadow = -1;
+    st.work = 0;
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, GRADK, TXG>(a, txx, txy, rxx, rxy, lane_bad, acc, st, &g);
     if (a.min_order <= 1 && a.max_order >= 1) sweep_order<1, MODE, false, GRADK, TXG>(a, txx, txy, rxx, rxy, lane_bad, acc, st, &g);
     if (a.min_order <= 2 && a.max_order >= 2) sweep_order<2, MODE, false, GRADK, TXG>(a, txx, txy, rxx, rxy, lane_bad, acc, st, &g);

@@ -207,6 +207,20 @@ class Context:
         """Launch-shape tuning (``split_max_tiles``, ``sched_min_tiles``): changes speed, never a result bit."""
         L.check(self._lib.d2d_set_option(self._ctx, name.encode(), int(value)))
 
+    def debug_set_schedule(self, order=None) -> None:
+        """Diagnostic: later launches of ``len(order)`` patches start their patches in this order (None: built-in)."""
+        if order is None:
+            L.check(self._lib.d2d_debug_set_schedule(self._ctx, np.zeros(1, np.int32), 0))
+        else:
+            o = np.ascontiguousarray(order, dtype=np.int32)
+            L.check(self._lib.d2d_debug_set_schedule(self._ctx, o, o.size))
+
+    def debug_get_schedule(self, n_patches: int):
+        """Diagnostic: (order, cost keys) of the schedule built by the last scheduled launch."""
+        order, key = np.empty(n_patches, np.int32), np.empty(n_patches, np.uint8)
+        L.check(self._lib.d2d_debug_get_schedule(self._ctx, order, key, n_patches))
+        return order, key
+
     def last_kernel_ms(self) -> float:
         """Duration of the sweep kernel of the last launch (needs ``set_option("time_kernel", 1)``)."""
         ms = C.c_float(0.0)

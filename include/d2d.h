@@ -197,10 +197,19 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
 /* Launch-shape tuning of a context; never changes a result bit (tests sweep these to cover every kernel variant).
  *   "split_max_tiles": launches of at most this many 8 x 8 patches share every patch between 4 waves (default 8192; 0 = never)
  *   "sched_min_tiles": launches of at least this many patches start their dearest patches first (default 2048)
+ *   "cost_history": non-zero (default) = a launch that sweeps the same grid as the previous one orders its patches by the
+ *                   work each took then (counted by the kernels); zero = always by the geometric proxy
  *   "time_kernel": non-zero = bracket the sweep kernel of every launch with HIP events (see d2d_last_kernel_ms)
  * Also read once at d2d_create from the environment: D2D_SPLIT_MAX_TILES, D2D_SCHED_MIN_TILES. No reference counterpart
  * (XLA picks its own launch shapes). Returns D2D_ERR_INVALID for an unknown name. */
 int d2d_set_option(d2d_ctx* ctx, const char* name, int64_t value);
+
+/* Diagnostics of the patch schedule (the order in which the culled kernels start their 8 x 8 patches; it changes
+ * speed, never results): d2d_debug_get_schedule copies the order built by the last scheduled launch and its cost keys
+ * (n = number of patches); d2d_debug_set_schedule makes later launches of exactly n patches use `order` (a permutation
+ * of 0..n-1) instead; n = 0 removes the override. */
+int d2d_debug_set_schedule(d2d_ctx* ctx, const int32_t* order, int64_t n);
+int d2d_debug_get_schedule(d2d_ctx* ctx, int32_t* order, uint8_t* key, int64_t n);
 
 /* Duration of the sweep kernel proper of the last launch on this context -- without the preparation kernels in front
  * of it (shadow masks, patch schedule) and the VJP reduction behind it -- from HIP events recorded on the context's

@@ -176,6 +176,42 @@ def test_cfg2_full_size_sampled_cells_and_block_invariance(ctx, approx, function
     assert np.array_equal(block, got[403:446, 617:700])
 
 
+def test_repeated_sweeps_reschedule_from_the_work_history(ctx):
+    """A context that sweeps the same grid again orders its patches by the work each one took last time (whatever the
+    transmitter was then): only the order changes, never a bit of the maps -- also for the value+grad sweep, whose
+    scene VJP sums per-patch partials."""
+    from differt2d_amd.engine import make_params
+
+    tx, walls = random_scene(24, seed=11)
+    X, Y = unit_grid(72, 56)
+    ctx.set_scene(walls)
+    ctx.set_grid(X, Y)
+    ctx.set_option("sched_min_tiles", 1)
+    try:
+        p = make_params(max_order=2, approx=True)
+        txs = [tx, np.array([0.31, 0.62], F), tx, tx]
+        maps = []
+        for t in txs:
+            ctx.launch(p, t)          # no set_grid in between: the 2nd .. 4th launch use the history
+            maps.append(ctx.get_map())
+        assert np.array_equal(maps[0], maps[2]) and np.array_equal(maps[0], maps[3])
+        assert np.array_equal(maps[0], _oracle(walls, tx, X, Y, max_order=2, approx=True))
+        assert np.array_equal(maps[1], _oracle(walls, txs[1], X, Y, max_order=2, approx=True))
+        vj = []
+        for _ in range(3):
+            ctx.launch_vg(p, tx, scene_vjp=True)
+            vj.append((ctx.get_map(), ctx.get_grad_rx(), *ctx.get_scene_vjp()))
+        for a in vj[1:]:
+            for u, v in zip(vj[0], a):
+                assert np.array_equal(u, v, equal_nan=True)
+        ctx.set_option("cost_history", 0)
+        ctx.launch(p, tx)
+        assert np.array_equal(ctx.get_map(), maps[0])
+    finally:
+        ctx.set_option("cost_history", 1)
+        ctx.set_option("sched_min_tiles", 2048)
+
+
 def test_errors_are_loud(ctx):
     from differt2d_amd import _lib as L
     from differt2d_amd.engine import make_params
