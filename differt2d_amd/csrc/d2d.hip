@@ -118,6 +118,7 @@ struct d2d_ctx {
     DevBuf<int> d_sched_override;       // diagnostic: a caller-supplied schedule (d2d_debug_set_schedule)
     long long sched_override_n = 0;
     bool use_cost_history = true;
+    bool txg_exhaustive = false;        // TX-grid value sweeps with the exhaustive kernel (A/B and tests)
     long long sched_min_tiles = 2048;   // launches with fewer patches keep the identity schedule
     float grid_absmax = 0.0f;   // max |coordinate| of the grid (host scan at d2d_set_grid)
     float scene_absmax = 0.0f;  // max |coordinate| of the objects
@@ -717,7 +718,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     a.shadow = nullptr;
     a.shadow_dperp = 0.0f;
     bool prep_zeroed = false;
-    if (!txg && c->N >= 2 && p->max_order >= 1) {
+    const bool txg_culled = txg && !grad_mode && !c->txg_exhaustive;  // TX grid, values only: culled kernel
+    if ((!txg || txg_culled) && c->N >= 2 && p->max_order >= 1) {
         // [N] masks, then the {histogram, cursors} of the patch schedule's counting sort: one memset for both
         if ((rc = c->d_shadow.ensure((size_t)c->N + d2d::SCHED_KEYS))) return rc;
         HIP_TRY(hipMemsetAsync(c->d_shadow.p, 0, ((size_t)c->N + d2d::SCHED_KEYS) * sizeof(unsigned long long), c->stream));
@@ -748,7 +750,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     }
     // dearest-first patch schedule for the culled kernels
     a.sched = nullptr;
-    if (!txg && !(grad_mode && p->strict_nan) && p->max_order >= 2 && c->cw.size() >= 2 && tiles >= c->sched_min_tiles) {
+    if ((!txg || txg_culled) && !(grad_mode && p->strict_nan) && p->max_order >= 2 && c->cw.size() >= 2 && tiles >= c->sched_min_tiles) {
         if ((rc = c->d_sched.ensure((size_t)tiles))) return rc;
         if ((rc = c->d_sched_key.ensure((size_t)tiles))) return rc;
         if (!prep_zeroed) {
@@ -790,8 +792,27 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             c->have_kernel_time = true;                          \
         }                                                        \
     } while (0)
+    if (txg_culled) {
+        const size_t lds_t = (size_t)(3 * c->N + 1) * sizeof(float4);
+        if (lds_t > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+        a.grad = nullptr; a.cot = nullptr; a.partial = nullptr;
+#define D2D_LAUNCH_TXG(MODE_)                                                                                            \
+    do {                                                                                                                \
+        if (p->max_order <= 2) hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 2>), grid, block, lds_t, c->stream, a); \
+        else if (p->max_order == 3) hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 3>), grid, block, lds_t, c->stream, a); \
+        else hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 4>), grid, block, lds_t, c->stream, a);                \
+    } while (0)
+        switch (mode) {
+            case d2d::MODE_HARD: D2D_LAUNCH_TXG(d2d::MODE_HARD); break;
+            case d2d::MODE_HSIG: D2D_LAUNCH_TXG(d2d::MODE_HSIG); break;
+            default: D2D_LAUNCH_TXG(d2d::MODE_SIG); break;
+        }
+        HIP_TRY(hipGetLastError());
+        D2D_KERNEL_DONE();
+        return D2D_OK;
+    }
     if (txg && !grad_mode) {
-        // TX grid, values only: the per-lane-image code path without the adjoint
+        // TX grid, values only, exhaustive ("txg_exhaustive" option): the per-lane-image code path without the adjoint
         const size_t lds0 = (size_t)(4 * c->N + 4) * sizeof(float);
         a.grad = nullptr; a.cot = nullptr; a.partial = nullptr;
         switch (mode) {
@@ -970,6 +991,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "sched_min_tiles")) c->sched_min_tiles = value;
     else if (!strcmp(name, "time_kernel")) c->time_kernel = value != 0;
     else if (!strcmp(name, "cost_history")) c->use_cost_history = value != 0;
+    else if (!strcmp(name, "txg_exhaustive")) c->txg_exhaustive = value != 0;
     else return fail(D2D_ERR_INVALID, "d2d_set_option: unknown option '%s'", name);
     return D2D_OK;
 }

@@ -876,7 +876,10 @@ __device__ __forceinline__ bool pole_possible(const float (&qx)[4], const float 
 
 // true = the candidate is certainly invalid for every cell of the patch.
 // walls[j], images[j] for j = K-1 (last wall) down to 0; level 1 uses the patch box.
-template <int K>
+// WIDE: the exact path this culls for runs the chain in the other direction (TX grids: images of the CELL, backward scan
+// from the fixed end point), so its interaction points are the same geometric points with a different rounding history:
+// the bound M, derived for the chain evaluated here, is taken four times as wide.
+template <int K, bool WIDE = false>
 __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float (&by)[4], const WallC (&w)[K],
                                                const float (&Ix)[K], const float (&Iy)[K], float on_lo, float on_hi,
                                                unsigned long long shadow0, float shadow_dperp, float shadow_lo,
@@ -893,6 +896,7 @@ __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float
         float smin, smax, M, E;
         bool ok = s_range(qx, qy, Ix[lvl], Iy[lvl], w[lvl], smin, smax, M, E);
         if (!ok) return false;
+        if (WIDE) M *= 4.0f;
         if (smax + M < on_lo || smin - M > on_hi) return true;
         if (lvl == 0) {
             // First segment (fixed end point -> first wall): if every point the first interaction can occupy is hidden
@@ -1346,6 +1350,131 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) atomicAdd(&a.stats[i], st.c[i]);
     }
+}
+
+// TX grids (scene.py:1489-1648): the cells are transmitters, (a.txx, a.txy) is the fixed receiver F.  The reference's op
+// chain (images of the cell, backward scan from F) is what eval_candidate<TXG = true> runs; the culling only has to bound
+// the same geometric interaction points, and a path is its own reverse: the candidate (w_0 .. w_{K-1}) is culled as the
+// chain of F through (w_{K-1} .. w_0) towards the patch, with F's shadow masks on w_{K-1} (the segment w_{K-1} -> F).
+// Prefix = (w_0 .. w_{K-2}) wave-uniform, lanes = last wall, survivors in ascending order: the reference's order.
+template <int K, int MODE>
+__device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const float4* tab, const float (&bx)[4],
+                                                       const float (&by)[4], float cx, float cy, bool lane_bad, float& acc,
+                                                       WaveStats& st) {
+    const int lane = threadIdx.x & 63;
+    int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+    float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];  // images of the lane's cell (per lane)
+    const int Nc = a.Nc;
+    int pos[D2D_MAX_ORDER] = {0, 0, 0, 0};
+    const int n_chunks = (Nc + 63) >> 6;
+#pragma unroll
+    for (int d = 1; d < K - 1; ++d) pos[d] = (pos[d - 1] == 0) ? 1 : 0;
+    if (K - 1 > 0 && Nc < 2) return;
+    if (Nc < 1) return;
+    while (true) {
+#pragma unroll
+        for (int d = 0; d < K - 1; ++d) {
+            cand[d] = a.cw[pos[d]];
+            image_of(a.refl[2 * cand[d]], d == 0 ? cx : imgx[d > 0 ? d - 1 : 0], d == 0 ? cy : imgy[d > 0 ? d - 1 : 0], imgx[d], imgy[d]);
+        }
+        const int last_prefix_pos = (K == 1) ? -1 : pos[K >= 2 ? K - 2 : 0];
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            const int lp = chunk * 64 + lane;
+            bool alive = (lp < Nc) && (lp != last_prefix_pos);
+            {
+                const int wl = a.cw[lp < Nc ? lp : 0];
+                WallC w[K];
+                float Ix[K], Iy[K];
+                const float4 r0 = tab[2 * wl], r1 = tab[2 * wl + 1], fc = tab[2 * a.N + wl];
+                w[0] = make_wallc(r0, r1, fc);
+                image_of(r0, a.txx, a.txy, Ix[0], Iy[0]);
+#pragma unroll
+                for (int j = 1; j < K; ++j) {
+                    const int wd = cand[K - 1 - j];
+                    const float4 q0 = a.refl[2 * wd];
+                    w[j] = make_wallc(q0, a.refl[2 * wd + 1], a.flt[wd]);
+                    image_of(q0, Ix[j - 1], Iy[j - 1], Ix[j], Iy[j]);
+                }
+                const unsigned long long sh0 = a.shadow ? a.shadow[wl] : 0ull;
+                if (alive && cull_candidate<K, true>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi, sh0, a.shadow_dperp, a.shadow_lo, a.shadow_inv)) alive = false;
+            }
+            unsigned long long mask = __ballot(alive);
+            D2D_WORK(5 * K);
+            while (mask) {
+                const int b = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                cand[K - 1] = a.cw[chunk * 64 + b];
+                image_of(a.refl[2 * cand[K - 1]], K == 1 ? cx : imgx[K >= 2 ? K - 2 : 0], K == 1 ? cy : imgy[K >= 2 ? K - 2 : 0], imgx[K - 1], imgy[K - 1]);
+                eval_candidate<K, MODE, false, false, false, true>(a, cand, imgx, imgy, cx, cy, a.txx, a.txy, lane_bad, acc, st, nullptr);
+            }
+        }
+        if (K == 1) break;
+        bool carry = true;
+        int stop = -1;
+#pragma unroll
+        for (int d = K - 2; d >= 0; --d) {
+            if (carry) {
+                pos[d] += 1;
+                if (d > 0 && pos[d] == pos[d - 1]) pos[d] += 1;
+                if (pos[d] < Nc) {
+                    carry = false;
+                    stop = d;
+                }
+            }
+        }
+        if (carry) break;
+#pragma unroll
+        for (int e = 1; e < K - 1; ++e)
+            if (e > stop) pos[e] = (pos[e - 1] == 0) ? 1 : 0;
+    }
+}
+
+template <int MODE, int MAXK>
+__global__ void __launch_bounds__(64) power_fwd_txg_kernel(SweepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    __syncthreads();
+    WaveStats st;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st.c[i] = 0;
+    st.shadow = -1;
+    st.work = 0;
+    const long tile = a.sched ? (long)a.sched[blockIdx.x] : (long)blockIdx.x;
+    const int tcol = (int)(tile % tiles_x), trow = (int)(tile / tiles_x);
+    const int col = tcol * TILE_W + (lane & (TILE_W - 1));
+    const int row = trow * TILE_H + (lane / TILE_W);
+    const bool in_range = (col < a.n) && (row < a.m);
+    const int ccol = col < a.n ? col : a.n - 1;
+    const int crow = row < a.m ? row : a.m - 1;
+    const long idx = (long)crow * a.n + ccol;
+    const float cx = a.X[idx], cy = a.Y[idx];
+    const bool lane_bad = !(fabsf(cx) < 1e18f) || !(fabsf(cy) < 1e18f) || !(fabsf(a.txx) < 1e18f) || !(fabsf(a.txy) < 1e18f);
+    float acc = 0.0f;  // scene.py:1593
+    float x0 = cx, x1 = cx, y0 = cy, y1 = cy;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, off, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
+        y0 = fminf(y0, __shfl_xor(y0, off, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+    }
+    const bool box_ok = !wave_any(lane_bad);
+    const float qn = __builtin_nanf("");
+    const float bx[4] = {box_ok ? x0 : qn, x1, x1, x0};
+    const float by[4] = {y0, y0, y1, y1};
+    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, false, true>(a, cx, cy, a.txx, a.txy, lane_bad, acc, st, nullptr);
+    if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled_txg<1, MODE>(a, tab, bx, by, cx, cy, lane_bad, acc, st);
+    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled_txg<2, MODE>(a, tab, bx, by, cx, cy, lane_bad, acc, st);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled_txg<3, MODE>(a, tab, bx, by, cx, cy, lane_bad, acc, st);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_culled_txg<4, MODE>(a, tab, bx, by, cx, cy, lane_bad, acc, st);
+    if (in_range) {
+        if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
+        else a.out[idx] = acc;
+    }
+    if (a.cost_out && lane == 0) a.cost_out[tile] = st.work;
 }
 
 // Patch schedule.  The hardware starts workgroups in blockIdx order, and a dear patch that starts late is the tail of the

@@ -14,6 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from differt2d_amd import _lib as L
 from differt2d_amd.engine import Context  # noqa: E402
 from oracle import c_oracle as CO  # noqa: E402
 
@@ -68,8 +69,9 @@ def main():
             # every launch shape: patches shared between 4 waves or one wave each, identity or dearest-first order
             ctx.set_option("split_max_tiles", 8192 if case % 2 == 0 else 0)
             ctx.set_option("sched_min_tiles", 1 if case % 4 < 2 else 1 << 40)
-            got = ctx.power_map(tx, X, Y, **kw)
-            want = CO.power_map(walls, tx, X, Y, allowed=allowed, prune=True, **kw)
+            role_tx = case % 3 == 2  # every third case sweeps a TX grid (the cells are transmitters, `tx` the receiver)
+            got = ctx.power_map(tx, X, Y, grid_role=L.GRID_TX if role_tx else L.GRID_RX, **kw)
+            want = CO.power_map(walls, tx, X, Y, allowed=allowed, prune=True, grid_role="tx" if role_tx else "rx", **kw)
             if kw["function"] == "sigmoid" and kw["approx"]:
                 ok = np.allclose(got, want, rtol=2e-5, atol=1e-5 * max(1.0, float(np.nanmax(np.abs(want)))), equal_nan=True)
             else:
@@ -77,7 +79,7 @@ def main():
             if not ok:
                 bad += 1
                 d = np.abs(got - want)
-                print(f"MISMATCH case {case} seed {seed}: N={len(walls)} grid={X.shape} kw={kw} allowed={allowed is not None} "
+                print(f"MISMATCH case {case} seed {seed} {'TX' if role_tx else 'RX'}-grid: N={len(walls)} grid={X.shape} kw={kw} allowed={allowed is not None} "
                       f"cells={int((~np.isclose(got, want, rtol=0, atol=0, equal_nan=True)).sum())} max={np.nanmax(d)}", flush=True)
     print(f"fuzz: {n_cases} cases, {bad} mismatches, {time.time() - t0:.1f} s (seed {seed})")
     sys.exit(1 if bad else 0)

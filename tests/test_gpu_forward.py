@@ -316,3 +316,46 @@ def test_bad_inputs_are_rejected_or_propagated(ctx):
     got = ctx.power_map(tx, X, Y, max_order=2)
     want = _oracle(walls, tx, X, Y, max_order=2)
     assert np.isnan(got[3, 5]) and np.array_equal(got, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("approx,function", MODES)
+def test_tx_grid_culled_kernel_matches_oracle_and_exhaustive_kernel(ctx, approx, function):
+    """accumulate_on_transmitters_grid_over_paths (scene.py:1489-1648): the cells are transmitters.  The culled kernel
+    (a path is its own reverse: culling runs from the fixed receiver towards the patch) against the oracle and against
+    the exhaustive kernel, orders 0..3."""
+    from differt2d_amd import _lib as L
+
+    rx, walls = random_scene(14, seed=21)
+    X, Y = unit_grid(45, 38)
+    ctx.set_scene(walls)
+    kw = dict(min_order=0, max_order=3, approx=approx, function=function)
+    got = ctx.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
+    _compare(got, CO_tx(walls, rx, X, Y, **kw), function)
+    ctx.set_option("txg_exhaustive", 1)
+    try:
+        ref = ctx.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
+    finally:
+        ctx.set_option("txg_exhaustive", 0)
+    assert np.array_equal(got, ref, equal_nan=True)
+    assert (got > 0).mean() > 0.05
+
+
+def test_tx_grid_cfg2_scene_block(ctx):
+    """50 walls, orders 0..2, a 64 x 48 block of the 1024^2 grid as TRANSMITTER positions, receiver fixed."""
+    from differt2d_amd import _lib as L
+
+    rx, walls = random_scene(50, seed=1234)
+    x = np.linspace(0.0, 1.0, 1024).astype(F)
+    X, Y = np.meshgrid(x[930:994], x[960:1008])
+    ctx.set_scene(walls)
+    for approx in (False, True):
+        kw = dict(min_order=0, max_order=2, approx=approx)
+        got = ctx.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
+        assert np.array_equal(got, CO_tx(walls, rx, X, Y, **kw))
+        assert (got > 0).any()
+
+
+def CO_tx(walls, rx, X, Y, **kw):
+    from oracle import c_oracle as CO
+
+    return CO.power_map(walls, rx, X, Y, prune=True, grid_role="tx", **kw)
