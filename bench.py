@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--no-grad", action="store_true", help="skip the value+grad (BASELINE.json configs[2]) timing")
     args = ap.parse_args()
 
+    from differt2d_amd import _lib as L
     from differt2d_amd.engine import Context, make_params
     from differt2d_amd.parallel import RowShards
 
@@ -143,7 +144,8 @@ def main():
     if not distributed and args.gpus != 1:
         raise SystemExit("N > 1 must be launched with torch.distributed.run (one process per GPU)")
 
-    ctx = Context(local_rank)
+    n_dev = max(1, L.device_count())
+    ctx = Context(local_rank % n_dev)  # one GPU per rank; ranks only share a device on a box with fewer GPUs than ranks
     rccl_note = None
     host_comm = None  # control plane: RCCL (d2d_comm_allreduce_host) unless the communicator cannot be created
     if distributed:
@@ -289,8 +291,9 @@ def main():
         print(json.dumps(line), flush=True)
 
     if distributed:
-        ctx.comm_barrier()
-        ctx.comm_destroy()
+        barrier()
+        if host_comm is None:
+            ctx.comm_destroy()
     ctx.close()
 
 
