@@ -93,6 +93,11 @@ struct d2d_ctx {
     std::vector<uint8_t> allowed;  // [N]
     std::vector<int> cw;           // compact list of allowed indices
     float occl_patch = NAN;        // patch the occlusion table was built for
+    // wall-to-wall masks (pair_shadow_kernel): scene-only, rebuilt when the scene or one of these parameters changes
+    DevBuf<unsigned long long> d_pair;
+    bool pair_valid = false;
+    float pair_key[6] = {0, 0, 0, 0, 0, 0};  // patch, seg_tol, approx, act, alpha, dperp
+    bool use_pair_masks = true;
     // scene (device)
     DevBuf<float4> d_occl, d_refl, d_flt;
     DevBuf<int> d_cw;
@@ -417,6 +422,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_sched_key.release();
     c->d_sched_override.release();
     c->d_cost.release();
+    c->d_pair.release();
     c->d_grad.release(); c->d_cot.release(); c->d_partial.release(); c->d_vjp.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -462,6 +468,7 @@ int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float
     if (phi) c->phi.assign(phi, phi + n_objects);
     c->allowed.assign((size_t)n_objects, (uint8_t)1);
     c->occl_patch = NAN;
+    c->pair_valid = false;
     rc = upload_refl(c);
     if (rc) return rc;
     rc = upload_mask(c);
@@ -717,6 +724,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     // first-segment shadow coverage (RX grids: the fixed end point is the transmitter)
     a.shadow = nullptr;
     a.shadow_dperp = 0.0f;
+    a.pair = nullptr;
+    a.pair_dperp = 0.0f;
     bool prep_zeroed = false;
     const bool txg_culled = txg && !grad_mode && !c->txg_exhaustive;  // TX grid, values only: culled kernel
     if ((!txg || txg_culled) && c->N >= 2 && p->max_order >= 1) {
@@ -741,6 +750,26 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             a.shadow_dperp = dperp;
             a.shadow_lo = (float)dom_lo;
             a.shadow_inv = (float)(1.0 / dom_w);
+            // wall-to-wall masks for the segments between two interaction points (orders >= 2): no end point involved,
+            // so they depend on the scene and the validity mode only and are kept until one of those changes
+            if (p->max_order >= 2 && c->N >= 3 && c->N <= 256 && c->use_pair_masks && std::isfinite(c->scene_absmax) && c->scene_absmax > 0.0f) {
+                const float pdperp = 4096.0f * 1.1920929e-07f * c->scene_absmax * (float)(D2D_MAX_ORDER + 1);
+                const float key[6] = {p->patch, p->seg_tol, (float)p->approx, (float)p->act, p->alpha, pdperp};
+                if (!c->pair_valid || std::memcmp(key, c->pair_key, sizeof(key)) != 0) {
+                    const size_t n2 = (size_t)c->N * c->N;
+                    if ((rc = c->d_pair.ensure(n2))) return rc;
+                    HIP_TRY(hipMemsetAsync(c->d_pair.p, 0, n2 * sizeof(unsigned long long), c->stream));
+                    const long long waves = (long long)c->N * c->N * c->N;
+                    hipLaunchKernelGGL(d2d::pair_shadow_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c->stream, c->d_occl.p,
+                                       c->d_refl.p, c->d_kind.p, c->N, (float)(in_lo + 1e-4), (float)(in_hi - 1e-4), pdperp,
+                                       (float)dom_lo, (float)(dom_w * 8.0), c->d_pair.p);
+                    HIP_TRY(hipGetLastError());
+                    std::memcpy(c->pair_key, key, sizeof(key));
+                    c->pair_valid = true;
+                }
+                a.pair = c->d_pair.p;
+                a.pair_dperp = pdperp;
+            }
             // a candidate with un == 0 in some step has a zero-length segment, loss >= 1: is it exactly invalid?
             const double x = (double)p->tol - 0.999;  // tol - loss at best
             if (!p->approx) a.shadow_prefix_ok = (p->tol <= 0.5f) ? 1 : 0;
@@ -991,6 +1020,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "sched_min_tiles")) c->sched_min_tiles = value;
     else if (!strcmp(name, "time_kernel")) c->time_kernel = value != 0;
     else if (!strcmp(name, "cost_history")) c->use_cost_history = value != 0;
+    else if (!strcmp(name, "pair_masks")) c->use_pair_masks = value != 0;
     else if (!strcmp(name, "txg_exhaustive")) c->txg_exhaustive = value != 0;
     else return fail(D2D_ERR_INVALID, "d2d_set_option: unknown option '%s'", name);
     return D2D_OK;

@@ -49,6 +49,11 @@ struct SweepArgs {
     float shadow_dperp;
     float shadow_lo, shadow_inv;  // bin b covers parametric coordinates shadow_lo + [b, b+1] / shadow_inv
     int shadow_prefix_ok;         // a fully covered first wall kills its whole prefix (see sweep_order_culled)
+    // wall-to-wall masks (pair_shadow_kernel): bit (be + 8 * bl) of pair[we * N + wl] = every segment from a point in
+    // bin be of wall we (the earlier interaction, P3) to a point in bin bl of wall wl (the later one, P4) -- 8 bins over
+    // the same parametric window as the 64 shadow bins -- is certainly occluded by some third object
+    const unsigned long long* __restrict__ pair;  // [N * N] or null
+    float pair_dperp;
     float fnum[D2D_MAX_ORDER + 1];  // r_coef ** k (lax.integer_pow), k = 0..D2D_MAX_ORDER
     float h2;                  // height * height
     int fun_id;
@@ -819,10 +824,11 @@ __device__ __forceinline__ void sweep_order(const SweepArgs& a, float txx, float
 // =====================================================================================
 struct WallC {  // what the culling needs of a wall
     float ox, oy, nx, ny, tx, ty, rsq;
+    int idx;
 };
 
-__device__ __forceinline__ WallC make_wallc(const float4& r0, const float4& r1, const float4& fc) {
-    return WallC{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, fc.x};
+__device__ __forceinline__ WallC make_wallc(const float4& r0, const float4& r1, const float4& fc, int idx) {
+    return WallC{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, fc.x, idx};
 }
 
 // Range of s over the convex hull of 4 points; returns false when the region may meet the pole line or
@@ -881,11 +887,14 @@ __device__ __forceinline__ bool pole_possible(const float (&qx)[4], const float 
 // the bound M, derived for the chain evaluated here, is taken four times as wide.
 template <int K, bool WIDE = false>
 __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float (&by)[4], const WallC (&w)[K],
-                                               const float (&Ix)[K], const float (&Iy)[K], float on_lo, float on_hi,
-                                               unsigned long long shadow0, float shadow_dperp, float shadow_lo,
-                                               float shadow_inv) {
+                                               const float (&Ix)[K], const float (&Iy)[K], const SweepArgs& a,
+                                               unsigned long long shadow0) {
     const float eps = 1.1920929e-07f;
+    const float on_lo = a.on_lo, on_hi = a.on_hi, shadow_dperp = a.shadow_dperp, shadow_lo = a.shadow_lo, shadow_inv = a.shadow_inv;
     float qx[4], qy[4];
+    // 8-bin range that the previous (later-in-path) wall's interaction point can occupy, for the wall-to-wall masks
+    int pka = 0, pkb = -1;
+    bool prev_ok = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         qx[j] = bx[j];
@@ -898,6 +907,32 @@ __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float
         if (!ok) return false;
         if (WIDE) M *= 4.0f;
         if (smax + M < on_lo || smin - M > on_hi) return true;
+        if (K >= 2 && a.pair) {
+            // Segment between this wall's interaction point and the next one's (pair_shadow_kernel): if every pair of
+            // bins the two points can occupy is certainly occluded by some third object, valid == 0 in every lane.
+            float sa8 = fmaxf(smin - M, on_lo) - 1e-4f, sb8 = fminf(smax + M, on_hi) + 1e-4f;
+            float fa8 = (sa8 - shadow_lo) * (0.125f * shadow_inv), fb8 = (sb8 - shadow_lo) * (0.125f * shadow_inv);
+            const bool cur_ok = fa8 >= 0.0f && fb8 < 8.0f && 512.0f * eps * E <= a.pair_dperp;
+            int ka = (int)fa8, kb = (int)fb8;
+            ka = ka < 0 ? 0 : ka;
+            kb = kb > 7 ? 7 : kb;
+            if (lvl < K - 1 && prev_ok && cur_ok) {
+                // in path order the earlier point is P3, the later P4 (geometry.py:881-904): rows = later wall's bins
+                const int we = WIDE ? w[lvl + 1 < K ? lvl + 1 : lvl].idx : w[lvl].idx;   // earlier wall (P3 side)
+                const int wl_ = WIDE ? w[lvl].idx : w[lvl + 1 < K ? lvl + 1 : lvl].idx;  // later wall (P4 side)
+                const int ea = WIDE ? pka : ka, eb = WIDE ? pkb : kb;   // earlier wall's bin range
+                const int la = WIDE ? ka : pka, lb = WIDE ? kb : pkb;   // later wall's bin range
+                const unsigned long long m = a.pair[(size_t)we * a.N + wl_];
+                const unsigned long long row = (unsigned long long)(((1u << (eb + 1)) - 1u) & ~((1u << ea) - 1u));
+                unsigned long long need = row * 0x0101010101010101ull;
+                const unsigned long long rows = (lb >= 7 ? ~0ull : ((1ull << (8 * (lb + 1))) - 1ull)) & ~((1ull << (8 * la)) - 1ull);
+                need &= rows;
+                if ((m & need) == need) return true;
+            }
+            prev_ok = cur_ok;
+            pka = ka;
+            pkb = kb;
+        }
         if (lvl == 0) {
             // First segment (fixed end point -> first wall): if every point the first interaction can occupy is hidden
             // from the fixed end point by some object, the segment is occluded in every lane: valid == 0.
@@ -1000,19 +1035,19 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 WallC w[K];
                 float Ix[K], Iy[K];
                 const float4 r0 = tab[2 * wl], r1 = tab[2 * wl + 1], fc = tab[2 * a.N + wl];
-                w[K - 1] = make_wallc(r0, r1, fc);
+                w[K - 1] = make_wallc(r0, r1, fc, wl);
                 image_of(r0, pIx, pIy, Ix[K - 1], Iy[K - 1]);
 #pragma unroll
                 for (int d = 0; d < K - 1; ++d) {
                     const int wd = cand[d];
-                    w[d] = make_wallc(a.refl[2 * wd], a.refl[2 * wd + 1], a.flt[wd]);
+                    w[d] = make_wallc(a.refl[2 * wd], a.refl[2 * wd + 1], a.flt[wd], wd);
                     Ix[d] = imgx[d];
                     Iy[d] = imgy[d];
                 }
                 unsigned long long sh0 = 0ull;
                 if (a.shadow) sh0 = a.shadow[(K == 1) ? wl : cand[0]];
                 if (GRAD && prefix_dead) alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
-                else if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi, sh0, a.shadow_dperp, a.shadow_lo, a.shadow_inv)) alive = false;
+                else if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive = false;
             }
             unsigned long long mask = __ballot(alive);
             if (STATS) st.c[9] += K;
@@ -1386,17 +1421,17 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
                 WallC w[K];
                 float Ix[K], Iy[K];
                 const float4 r0 = tab[2 * wl], r1 = tab[2 * wl + 1], fc = tab[2 * a.N + wl];
-                w[0] = make_wallc(r0, r1, fc);
+                w[0] = make_wallc(r0, r1, fc, wl);
                 image_of(r0, a.txx, a.txy, Ix[0], Iy[0]);
 #pragma unroll
                 for (int j = 1; j < K; ++j) {
                     const int wd = cand[K - 1 - j];
                     const float4 q0 = a.refl[2 * wd];
-                    w[j] = make_wallc(q0, a.refl[2 * wd + 1], a.flt[wd]);
+                    w[j] = make_wallc(q0, a.refl[2 * wd + 1], a.flt[wd], wd);
                     image_of(q0, Ix[j - 1], Iy[j - 1], Ix[j], Iy[j]);
                 }
                 const unsigned long long sh0 = a.shadow ? a.shadow[wl] : 0ull;
-                if (alive && cull_candidate<K, true>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi, sh0, a.shadow_dperp, a.shadow_lo, a.shadow_inv)) alive = false;
+                if (alive && cull_candidate<K, true>(bx, by, w, Ix, Iy, a, sh0)) alive = false;
             }
             unsigned long long mask = __ballot(alive);
             D2D_WORK(5 * K);
@@ -1516,10 +1551,10 @@ __global__ void __launch_bounds__(256) patch_cost_kernel(SweepArgs a, unsigned c
         WallC w[1];
         float Ix[1], Iy[1];
         const float4 r0 = a.refl[2 * wl], r1 = a.refl[2 * wl + 1], fc = a.flt[wl];
-        w[0] = make_wallc(r0, r1, fc);
+        w[0] = make_wallc(r0, r1, fc, wl);
         image_of(r0, a.txx, a.txy, Ix[0], Iy[0]);
         const unsigned long long sh0 = a.shadow ? a.shadow[wl] : 0ull;
-        const bool alive = lp < a.Nc && !cull_candidate<1>(bx, by, w, Ix, Iy, a.on_lo, a.on_hi, sh0, a.shadow_dperp, a.shadow_lo, a.shadow_inv);
+        const bool alive = lp < a.Nc && !cull_candidate<1>(bx, by, w, Ix, Iy, a, sh0);
         alive_n += __builtin_popcountll(__ballot(alive));
     }
     if (lane == 0) key[tile] = (unsigned char)(((long)alive_n * (SCHED_KEYS - 1)) / (a.Nc > 0 ? a.Nc : 1));
@@ -1640,6 +1675,61 @@ __global__ void shadow_tx_kernel(const float4* __restrict__ occl, const float4* 
         bits = __ballot(ok);
     }
     if (bits && b == 0) atomicOr(&shadow[w], bits);
+}
+
+// Wall-to-wall occlusion masks (scene-only: no end point involved, so they are built once per scene / mode).  One wave
+// per (earlier wall we, later wall wl, blocker j); lane = (bin of we) + 8 * (bin of wl).  A bit is set when the segment
+// p -> q is CERTAINLY reported as intersecting j by the exact path for every p within dperp of we's bin and every q
+// within dperp of wl's bin: t_a, t_b and the denominator are (bi)linear-fractional in (p, q), monotone along straight
+// lines in either argument while fd keeps its sign, so their ranges over the two thin quads are spanned by the 4 x 4
+// vertex pairs.  Same margins as shadow_tx_kernel.
+__global__ void __launch_bounds__(256) pair_shadow_kernel(const float4* __restrict__ occl, const float4* __restrict__ refl,
+                                                          const unsigned char* __restrict__ kind, int N, float win_lo, float win_hi,
+                                                          float dperp, float dom_lo, float dom_w8, unsigned long long* __restrict__ pair) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const long idx = gid >> 6;
+    if (idx >= (long)N * N * N) return;
+    const int j = (int)(idx % N), wl = (int)((idx / N) % N), we = (int)(idx / ((long)N * N));
+    if (we == wl || j == we || j == wl) return;  // a segment ignores the two walls it joins (geometry.py:881-904)
+    if (kind[j] == D2D_VERTEX) return;
+    const float4 a0 = refl[2 * we], a1 = refl[2 * we + 1], b0 = refl[2 * wl], b1 = refl[2 * wl + 1];
+    if (a1.x * a1.x + a1.y * a1.y == 0.0f || b1.x * b1.x + b1.y * b1.y == 0.0f) return;
+    const float eps = 1.1920929e-07f;
+    const float4 o = occl[j];  // P1, A
+    const int be = lane & 7, bl = lane >> 3;
+    const float pad_e = dperp * (a1.w > 0.0f ? 1.0f / a1.w : 0.0f), pad_l = dperp * (b1.w > 0.0f ? 1.0f / b1.w : 0.0f);
+    const float tlen = fabsf(a1.x) + fabsf(a1.y) + fabsf(b1.x) + fabsf(b1.y);
+    bool ok = true;
+    int sgn = 0;
+    for (int vp = 0; vp < 4 && ok; ++vp) {
+        const float sp = dom_lo + ((vp & 1) ? (float)(be + 1) * dom_w8 + pad_e : (float)be * dom_w8 - pad_e);
+        const float op = (vp & 2) ? dperp : -dperp;
+        const float px = a0.x + sp * a1.x + op * a0.z, py = a0.y + sp * a1.y + op * a0.w;  // P3 = p
+        const float Cx = o.x - px, Cy = o.y - py;
+        const float fb = o.z * Cy - o.w * Cx;
+        const float errB = 8.0f * eps * (fabsf(o.z * Cy) + fabsf(o.w * Cx)) + 4.0f * eps * tlen * (fabsf(o.z) + fabsf(o.w));
+        for (int vq = 0; vq < 4; ++vq) {
+            const float sq = dom_lo + ((vq & 1) ? (float)(bl + 1) * dom_w8 + pad_l : (float)bl * dom_w8 - pad_l);
+            const float oq = (vq & 2) ? dperp : -dperp;
+            const float qx = b0.x + sq * b1.x + oq * b0.z, qy = b0.y + sq * b1.y + oq * b0.w;  // P4 = q
+            const float Bx = px - qx, By = py - qy;
+            const float fa = By * Cx - Bx * Cy;
+            const float fd = o.w * Bx - o.z * By;
+            const float errA = 8.0f * eps * (fabsf(By * Cx) + fabsf(Bx * Cy)) + 4.0f * eps * tlen * (fabsf(Cx) + fabsf(Cy) + fabsf(Bx) + fabsf(By));
+            const float errD = 8.0f * eps * (fabsf(o.w * Bx) + fabsf(o.z * By)) + 4.0f * eps * tlen * (fabsf(o.z) + fabsf(o.w));
+            const float ad = fabsf(fd);
+            if (!(ad > 8.0f * errD)) { ok = false; break; }
+            const int sv = fd > 0.0f ? 1 : -1;
+            if (sgn == 0) sgn = sv;
+            if (sv != sgn) { ok = false; break; }
+            const float ta = fa / fd, tb = fb / fd;
+            const float ea = (errA + 2.0f * errD) / (ad - errD) + 4.0f * eps, eb = (errB + 2.0f * errD) / (ad - errD) + 4.0f * eps;
+            if (!(ta - ea >= win_lo && ta + ea <= win_hi && tb - eb >= win_lo && tb + eb <= win_hi)) { ok = false; break; }
+        }
+    }
+    const unsigned long long bits = __ballot(ok);
+    if (bits && lane == 0) atomicOr(&pair[(size_t)we * N + wl], bits);
 }
 
 // Value + gradient sweep: same forward arithmetic as power_fwd_kernel (bit-identical values), plus the
