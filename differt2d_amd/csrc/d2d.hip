@@ -726,6 +726,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     a.shadow_dperp = 0.0f;
     a.pair = nullptr;
     a.pair_dperp = 0.0f;
+    a.pair_prefix_ok = 0;
     bool prep_zeroed = false;
     const bool txg_culled = txg && !grad_mode && !c->txg_exhaustive;  // TX grid, values only: culled kernel
     if ((!txg || txg_culled) && c->N >= 2 && p->max_order >= 1) {
@@ -736,6 +737,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         // window where a test is certainly "hit" (hard) / exactly saturated to 1 (approx): shrink [-tol, 1+tol] by widen
         const double in_lo = -(double)p->seg_tol + widen_in, in_hi = 1.0 + (double)p->seg_tol - widen_in;
         float ext = std::fmax(std::fmax(c->scene_absmax, c->grid_absmax), std::fmax(std::fabs(tx[0]), std::fabs(tx[1])));
+        bool pair_ext_ok = false;
         if (in_hi > in_lo + 1e-3 && std::isfinite(ext) && ext > 0.0f) {
             const float dperp = 4096.0f * 1.1920929e-07f * ext * (float)(p->max_order + 1);
             const int pairs = c->N * c->N;
@@ -769,12 +771,14 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
                 }
                 a.pair = c->d_pair.p;
                 a.pair_dperp = pdperp;
+                pair_ext_ok = ext <= 8.0f * c->scene_absmax;  // interaction points of a valid path stay within pdperp of their walls
             }
             // a candidate with un == 0 in some step has a zero-length segment, loss >= 1: is it exactly invalid?
             const double x = (double)p->tol - 0.999;  // tol - loss at best
             if (!p->approx) a.shadow_prefix_ok = (p->tol <= 0.5f) ? 1 : 0;
             else if (mode == d2d::MODE_HSIG) a.shadow_prefix_ok = ((double)p->alpha * x + 3.0 <= -1e-3) ? 1 : 0;
             else a.shadow_prefix_ok = ((double)p->alpha * x <= -89.5) ? 1 : 0;
+            a.pair_prefix_ok = (a.pair && pair_ext_ok && a.shadow_prefix_ok) ? 1 : 0;
         }
     }
     // dearest-first patch schedule for the culled kernels

@@ -54,6 +54,7 @@ struct SweepArgs {
     // the same parametric window as the 64 shadow bins -- is certainly occluded by some third object
     const unsigned long long* __restrict__ pair;  // [N * N] or null
     float pair_dperp;
+    int pair_prefix_ok;  // two consecutive prefix walls that cannot see each other at all kill the prefix (orders >= 3)
     float fnum[D2D_MAX_ORDER + 1];  // r_coef ** k (lax.integer_pow), k = 0..D2D_MAX_ORDER
     float h2;                  // height * height
     int fun_id;
@@ -1025,7 +1026,13 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         // NaN whether or not the candidate is valid.  A dead prefix therefore keeps the candidates whose last-wall pole
         // may cross the patch (a cheap test, few survivors) and evaluates those exactly.  NaN artefacts that only arise
         // deeper in a dead prefix's chain are not reproduced (d2d_params.strict_nan is the exhaustive kernel).
-        const bool prefix_dead = (K >= 2) && a.shadow && a.shadow_prefix_ok && (a.shadow[cand[0]] == ~0ull);
+        bool prefix_dead = (K >= 2) && a.shadow && a.shadow_prefix_ok && (a.shadow[cand[0]] == ~0ull);
+        if (K >= 3 && !GRAD && a.pair && a.pair_prefix_ok) {
+            // two consecutive walls of the prefix whose windows are mutually invisible bin for bin: whatever follows,
+            // the segment between them is occluded (or one of its ends is off its wall)
+#pragma unroll
+            for (int d = 0; d + 1 < K - 1; ++d) prefix_dead = prefix_dead || (a.pair[(size_t)cand[d] * a.N + cand[d + 1]] == ~0ull);
+        }
         for (int chunk = 0; chunk < ((prefix_dead && !GRAD) ? 0 : n_chunks); ++chunk) {
             // ---- lanes = candidates: lane l <-> last wall = cw[chunk * 64 + l]
             const int lp = chunk * 64 + lane;
@@ -1413,7 +1420,12 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
             image_of(a.refl[2 * cand[d]], d == 0 ? cx : imgx[d > 0 ? d - 1 : 0], d == 0 ? cy : imgy[d > 0 ? d - 1 : 0], imgx[d], imgy[d]);
         }
         const int last_prefix_pos = (K == 1) ? -1 : pos[K >= 2 ? K - 2 : 0];
-        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        bool prefix_dead = false;
+        if (K >= 3 && a.pair && a.pair_prefix_ok) {
+#pragma unroll
+            for (int d = 0; d + 1 < K - 1; ++d) prefix_dead = prefix_dead || (a.pair[(size_t)cand[d] * a.N + cand[d + 1]] == ~0ull);
+        }
+        for (int chunk = 0; chunk < (prefix_dead ? 0 : n_chunks); ++chunk) {
             const int lp = chunk * 64 + lane;
             bool alive = (lp < Nc) && (lp != last_prefix_pos);
             {
