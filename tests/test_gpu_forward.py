@@ -212,6 +212,25 @@ def test_repeated_sweeps_reschedule_from_the_work_history(ctx):
         ctx.set_option("sched_min_tiles", 2048)
 
 
+def test_acceleration_masks_do_not_change_results(ctx):
+    """The wall-to-wall masks (built once per scene and mode) and the work-history schedule are accelerators only: maps
+    with and without them are bit-identical, across a mode change and a scene change that must rebuild the masks."""
+    X, Y = unit_grid(64, 48)
+    for seed, n in ((3, 20), (8, 33)):
+        tx, walls = random_scene(n, seed=seed)
+        ctx.set_scene(walls)
+        for kw in (dict(approx=False), dict(approx=True), dict(approx=True, alpha=30.0), dict(approx=False, patch=0.03)):
+            kw = dict(min_order=0, max_order=3 if n <= 20 else 2, **kw)
+            on = ctx.power_map(tx, X, Y, **kw)
+            ctx.set_option("pair_masks", 0)
+            try:
+                off = ctx.power_map(tx, X, Y, **kw)
+            finally:
+                ctx.set_option("pair_masks", 1)
+            assert np.array_equal(on, off, equal_nan=True)
+            assert np.array_equal(on, _oracle(walls, tx, X, Y, **kw))
+
+
 def test_errors_are_loud(ctx):
     from differt2d_amd import _lib as L
     from differt2d_amd.engine import make_params
