@@ -793,14 +793,13 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         int* hist = reinterpret_cast<int*>(c->d_shadow.p + c->N);  // [SCHED_KEYS] counts, [SCHED_KEYS] cursors
         // cost key: what the patch cost last time, when this context has swept the same grid before (optimisation
         // loops, repeated maps); otherwise a proxy computed from the geometry
-        if (c->cost_tiles == tiles && c->use_cost_history)
-            hipLaunchKernelGGL(d2d::patch_key_from_cost_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, c->stream,
-                               c->d_cost.p, c->d_sched_key.p, (long)tiles);
-        else
+        const bool from_history = c->cost_tiles == tiles && c->use_cost_history;
+        if (!from_history)
             hipLaunchKernelGGL(d2d::patch_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, a, c->d_sched_key.p);
         {
             const unsigned sort_blocks = (unsigned)((tiles + 256 * d2d::SCHED_PER_THREAD - 1) / (256 * d2d::SCHED_PER_THREAD));
-            hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p, hist, (long)tiles);
+            hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p,
+                               from_history ? c->d_cost.p : (const unsigned*)nullptr, hist, (long)tiles);
             hipLaunchKernelGGL(d2d::patch_order_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p, hist,
                                hist + d2d::SCHED_KEYS, c->d_sched.p, (long)tiles);
         }

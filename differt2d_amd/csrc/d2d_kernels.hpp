@@ -1574,23 +1574,30 @@ __global__ void __launch_bounds__(256) patch_cost_kernel(SweepArgs a, unsigned c
 
 // Cost key of a patch from the work it took the last time this context swept the same grid (counted by the sweep kernels
 // themselves in units of ~25 wave-instructions: deterministic, unlike elapsed time): 8 buckets per octave, 9 % resolution.
-__global__ void __launch_bounds__(256) patch_key_from_cost_kernel(const unsigned* __restrict__ cost, unsigned char* __restrict__ key, long n_tiles) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    const float c = (float)(cost[t] | 1u);
-    int k = (int)(8.0f * __log2f(c)) - 16;  // 2^2 .. 2^34 units -> 0 .. 255
-    key[t] = (unsigned char)(k < 0 ? 0 : (k > SCHED_KEYS - 1 ? SCHED_KEYS - 1 : k));
+__device__ __forceinline__ unsigned char key_from_cost(unsigned cost) {
+    const int k = (int)(8.0f * __log2f((float)(cost | 1u))) - 16;  // 2^2 .. 2^34 units -> 0 .. 255
+    return (unsigned char)(k < 0 ? 0 : (k > SCHED_KEYS - 1 ? SCHED_KEYS - 1 : k));
 }
 
-// pass 1: hist[k] = number of patches with key k
-__global__ void __launch_bounds__(256) patch_hist_kernel(const unsigned char* __restrict__ key, int* __restrict__ hist, long n_tiles) {
+// pass 1: hist[k] = number of patches with key k; with `cost` (work history) the keys are derived here first
+__global__ void __launch_bounds__(256) patch_hist_kernel(unsigned char* __restrict__ key, const unsigned* __restrict__ cost,
+                                                         int* __restrict__ hist, long n_tiles) {
     __shared__ int cnt[SCHED_KEYS];
     if (threadIdx.x < SCHED_KEYS) cnt[threadIdx.x] = 0;
     __syncthreads();
     const long base = (long)blockIdx.x * (256 * SCHED_PER_THREAD);
     for (int i = 0; i < SCHED_PER_THREAD; ++i) {
         const long t = base + (long)i * 256 + threadIdx.x;
-        if (t < n_tiles) atomicAdd(&cnt[key[t]], 1);
+        if (t < n_tiles) {
+            unsigned char k;
+            if (cost) {
+                k = key_from_cost(cost[t]);
+                key[t] = k;
+            } else {
+                k = key[t];
+            }
+            atomicAdd(&cnt[k], 1);
+        }
     }
     __syncthreads();
     if (threadIdx.x < SCHED_KEYS && cnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], cnt[threadIdx.x]);
