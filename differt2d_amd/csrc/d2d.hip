@@ -104,7 +104,8 @@ struct d2d_ctx {
     DevBuf<unsigned char> d_kind;
     DevBuf<float2> d_sincos;
     // optimiser-based solvers
-    DevBuf<float> d_bc1, d_bc2, d_theta0;
+    DevBuf<float> d_bc1, d_bc2, d_theta0, d_contrib;
+    bool opt_parallel = true;  // optimiser-based sweeps: candidates side by side (same results as one after the other)
     int bc_steps = -1;
     std::vector<float> theta0;  // [C][D2D_MAX_ORDER] as set by d2d_set_theta0
     DevBuf<int> d_scand, d_sorder;
@@ -409,7 +410,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_cw.release();
     c->d_kind.release();
     c->d_sincos.release();
-    c->d_bc1.release(); c->d_bc2.release(); c->d_theta0.release(); c->d_scand.release(); c->d_sorder.release();
+    c->d_bc1.release(); c->d_bc2.release(); c->d_theta0.release(); c->d_contrib.release(); c->d_scand.release(); c->d_sorder.release();
     c->d_tcand.release(); c->d_torder.release(); c->d_ttx.release(); c->d_trx.release();
     c->d_txys_in.release(); c->d_tloss_in.release(); c->d_txys.release(); c->d_tloss.release();
     c->d_tvalid.release(); c->d_ton.release(); c->d_thit.release(); c->d_tlen.release();
@@ -634,7 +635,16 @@ static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx) {
     a.fun_id = p->fun_id;
     a.out_mode = p->out_mode;
     const unsigned blocks = (unsigned)((a.cells + 63) / 64);
-    hipLaunchKernelGGL(d2d::power_opt_kernel, dim3(blocks), dim3(64), 0, c->stream, a);
+    // candidates side by side while the contributions fit a modest scratch buffer (and the grid's y dimension)
+    const bool side_by_side = c->opt_parallel && C >= 2 && C <= 65535 && (long long)C * a.cells <= (1ll << 26);
+    if (side_by_side) {
+        if ((rc = c->d_contrib.ensure((size_t)C * (size_t)a.cells))) return rc;
+        hipLaunchKernelGGL(d2d::power_opt_cand_kernel, dim3(blocks, (unsigned)C), dim3(64), 0, c->stream, a, c->d_contrib.p);
+        hipLaunchKernelGGL(d2d::opt_reduce_kernel, dim3((unsigned)((a.cells + 255) / 256)), dim3(256), 0, c->stream, c->d_contrib.p,
+                           (int)C, a.cells, c->d_out.p, p->out_mode);
+    } else {
+        hipLaunchKernelGGL(d2d::power_opt_kernel, dim3(blocks), dim3(64), 0, c->stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return D2D_OK;
 }
@@ -1024,6 +1034,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "time_kernel")) c->time_kernel = value != 0;
     else if (!strcmp(name, "cost_history")) c->use_cost_history = value != 0;
     else if (!strcmp(name, "pair_masks")) c->use_pair_masks = value != 0;
+    else if (!strcmp(name, "opt_parallel")) c->opt_parallel = value != 0;
     else if (!strcmp(name, "txg_exhaustive")) c->txg_exhaustive = value != 0;
     else return fail(D2D_ERR_INVALID, "d2d_set_option: unknown option '%s'", name);
     return D2D_OK;

@@ -2304,41 +2304,68 @@ struct OptSweepArgs {
     int out_mode;
 };
 
+// valid * fun of one (cell, candidate): solve, validate, evaluate (scene.py:1892-1918 with an optimiser-based path class)
+__device__ __forceinline__ float opt_contribution(const OptSweepArgs& a, int c, float txx, float txy, float rxx, float rxy) {
+    const Truth L{a.mode, a.alpha};
+    const int k = a.order[c];
+    int cd[D2D_MAX_ORDER];
+#pragma unroll
+    for (int i = 0; i < D2D_MAX_ORDER; ++i) cd[i] = a.cand[c * D2D_MAX_ORDER + i];
+    const float* th0 = a.theta0 + (long)c * a.A.many * D2D_MAX_ORDER;
+    float px[NP], py[NP];
+    float loss = 0.0f;
+    if (k == 0) image_solve(a.T, 0, cd, txx, txy, rxx, rxy, px, py);
+    else loss = opt_solve(a.T, a.A, k, cd, th0, txx, txy, rxx, rxy, px, py);
+    float on, hit, valid;
+    literal_validity(a.T, L, k, cd, px, py, loss, a.tol, a.seg_lo, a.seg_hi, on, hit, valid);
+    const float r = literal_length(k, px, py);
+    float f;
+    if (a.fun_id == D2D_FUN_RECEIVED_POWER) {
+        float num = a.fnum[0];
+#pragma unroll
+        for (int q = 1; q <= D2D_MAX_ORDER; ++q)
+            if (q == k) num = a.fnum[q];
+        f = num / (a.h2 + r * r);
+    } else if (a.fun_id == D2D_FUN_LENGTH_SQUARED) f = r * r;
+    else if (a.fun_id == D2D_FUN_LENGTH) f = r;
+    else f = 1.0f;
+    return valid * f;
+}
+
+// One cell per lane, the candidates one after the other (any number of candidates).
 __global__ void __launch_bounds__(64) power_opt_kernel(OptSweepArgs a) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.cells) return;
     const float gx_ = a.X[idx], gy_ = a.Y[idx];
     const float txx = a.grid_is_tx ? gx_ : a.txx, txy = a.grid_is_tx ? gy_ : a.txy;
     const float rxx = a.grid_is_tx ? a.txx : gx_, rxy = a.grid_is_tx ? a.txy : gy_;
-    const Truth L{a.mode, a.alpha};
     float acc = 0.0f;
-    for (int c = 0; c < a.C; ++c) {
-        const int k = a.order[c];
-        int cd[D2D_MAX_ORDER];
-#pragma unroll
-        for (int i = 0; i < D2D_MAX_ORDER; ++i) cd[i] = a.cand[c * D2D_MAX_ORDER + i];
-        const float* th0 = a.theta0 + (long)c * a.A.many * D2D_MAX_ORDER;
-        float px[NP], py[NP];
-        float loss = 0.0f;
-        if (k == 0) image_solve(a.T, 0, cd, txx, txy, rxx, rxy, px, py);
-        else loss = opt_solve(a.T, a.A, k, cd, th0, txx, txy, rxx, rxy, px, py);
-        float on, hit, valid;
-        literal_validity(a.T, L, k, cd, px, py, loss, a.tol, a.seg_lo, a.seg_hi, on, hit, valid);
-        const float r = literal_length(k, px, py);
-        float f;
-        if (a.fun_id == D2D_FUN_RECEIVED_POWER) {
-            float num = a.fnum[0];
-#pragma unroll
-            for (int q = 1; q <= D2D_MAX_ORDER; ++q)
-                if (q == k) num = a.fnum[q];
-            f = num / (a.h2 + r * r);
-        } else if (a.fun_id == D2D_FUN_LENGTH_SQUARED) f = r * r;
-        else if (a.fun_id == D2D_FUN_LENGTH) f = r;
-        else f = 1.0f;
-        acc = acc + valid * f;
-    }
+    for (int c = 0; c < a.C; ++c) acc = acc + opt_contribution(a, c, txx, txy, rxx, rxy);
     if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
     else a.out[idx] = acc;
+}
+
+// The same with the candidates spread over blockIdx.y: every (cell, candidate) is `steps` SEQUENTIAL Adam iterations, so
+// a 300^2 grid with 7 candidates only fills the chip when the candidates run side by side (1.4 -> 10 waves per SIMD).
+// Contributions go to contrib[c][cell]; opt_reduce_kernel adds them in candidate order: the same fp32 sum.
+__global__ void __launch_bounds__(64) power_opt_cand_kernel(OptSweepArgs a, float* __restrict__ contrib) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.cells) return;
+    const int c = blockIdx.y;
+    const float gx_ = a.X[idx], gy_ = a.Y[idx];
+    const float txx = a.grid_is_tx ? gx_ : a.txx, txy = a.grid_is_tx ? gy_ : a.txy;
+    const float rxx = a.grid_is_tx ? a.txx : gx_, rxy = a.grid_is_tx ? a.txy : gy_;
+    contrib[(long)c * a.cells + idx] = opt_contribution(a, c, txx, txy, rxx, rxy);
+}
+
+__global__ void __launch_bounds__(256) opt_reduce_kernel(const float* __restrict__ contrib, int C, long cells, float* __restrict__ out,
+                                                         int out_mode) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= cells) return;
+    float acc = 0.0f;  // scene.py:1893
+    for (int c = 0; c < C; ++c) acc = acc + contrib[(long)c * cells + idx];
+    if (out_mode == D2D_OUT_ADD) out[idx] = out[idx] + acc;
+    else out[idx] = acc;
 }
 
 }  // namespace d2d

@@ -200,6 +200,7 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *   "cost_history": non-zero (default) = a launch that sweeps the same grid as the previous one orders its patches by the
  *                   work each took then (counted by the kernels); zero = always by the geometric proxy
  *   "pair_masks": zero = do not build / use the wall-to-wall occlusion masks (A/B and tests; same results)
+ *   "opt_parallel": zero = MinPath / FermatPath sweeps walk the candidates one after the other in every lane (same results)
  *   "txg_exhaustive": non-zero = TX-grid value sweeps use the exhaustive kernel instead of the culled one (same results)
  *   "time_kernel": non-zero = bracket the sweep kernel of every launch with HIP events (see d2d_last_kernel_ms)
  * Also read once at d2d_create from the environment: D2D_SPLIT_MAX_TILES, D2D_SCHED_MIN_TILES. No reference counterpart
