@@ -729,7 +729,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     const long long tiles = (long long)tiles_x * tiles_y;
     if (tiles > 0x7fffffffLL) return fail(D2D_ERR_INVALID, "grid too large: %lld tiles", tiles);
     dim3 grid((unsigned)tiles), block(64);
-    dim3 grid_walk((unsigned)tiles);  // one single-wave workgroup per 8 x 8 patch
+    dim3 grid_patches((unsigned)tiles);  // one single-wave workgroup per 8 x 8 patch
     const bool txg = p->grid_role == D2D_GRID_TX;
     // first-segment shadow coverage (RX grids: the fixed end point is the transmitter)
     a.shadow = nullptr;
@@ -886,9 +886,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
 #define D2D_LAUNCH_FWDG(MODE_)                                                                                              \
     do {                                                                                                                    \
-        if (p->max_order <= 2) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 2, true>), grid_walk, block, lds2, c->stream, a); \
-        else if (p->max_order == 3) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 3, true>), grid_walk, block, lds2, c->stream, a); \
-        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 4, true>), grid_walk, block, lds2, c->stream, a);            \
+        if (p->max_order <= 2) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 2, true>), grid_patches, block, lds2, c->stream, a); \
+        else if (p->max_order == 3) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 3, true>), grid_patches, block, lds2, c->stream, a); \
+        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 4, true>), grid_patches, block, lds2, c->stream, a);            \
     } while (0)
             switch (mode) {
                 case d2d::MODE_HARD: D2D_LAUNCH_FWDG(d2d::MODE_HARD); break;
@@ -911,7 +911,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         HIP_TRY(hipGetLastError());
         D2D_KERNEL_DONE();
         if (grad_mode == 2) {
-            const long rows = (!txg && !p->strict_nan) ? (long)grid_walk.x : (long)tiles;  // one row of partials per launched wave
+            const long rows = (!txg && !p->strict_nan) ? (long)grid_patches.x : (long)tiles;  // one row of partials per launched wave
             hipLaunchKernelGGL(d2d::vjp_reduce_kernel, dim3((unsigned)n_elem), dim3(256), 0, c->stream, c->d_partial.p,
                                rows, n_elem, c->d_vjp.p, (p->out_mode == D2D_OUT_ADD && c->have_vjp) ? 1 : 0);
             HIP_TRY(hipGetLastError());
@@ -930,8 +930,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
 #define D2D_LAUNCH_FWD(MODE_, STATS_, MAXK_)                                                                              \
     do {                                                                                                                  \
         if (split) hipLaunchKernelGGL((d2d::power_fwd_split_kernel<MODE_, STATS_, MAXK_, D2D_SPLIT_W>),                   \
-                                      grid_walk, dim3(64 * D2D_SPLIT_W), split_lds, c->stream, a);     \
-        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, STATS_, MAXK_>), grid_walk, block, tab_lds, c->stream, a);   \
+                                      grid_patches, dim3(64 * D2D_SPLIT_W), split_lds, c->stream, a);     \
+        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, STATS_, MAXK_>), grid_patches, block, tab_lds, c->stream, a);   \
     } while (0)
 #define D2D_LAUNCH_FWD_K(MODE_, STATS_)                      \
     do {                                                     \

@@ -1125,7 +1125,7 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     if (scene)
         for (int i = lane; i < 4 * a.N; i += 64) wl[i] = 0.0f;
     __syncthreads();
-    float tbx_sum = 0.0f, tby_sum = 0.0f;  // scene VJP w.r.t. the fixed end point, summed over this wave's patches
+    float tbx_sum = 0.0f, tby_sum = 0.0f;  // scene VJP w.r.t. the fixed end point (wave sum)
     WaveStats st;
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.c[i] = 0;
@@ -1755,7 +1755,7 @@ __global__ void __launch_bounds__(256) pair_shadow_kernel(const float4* __restri
 // hand-derived adjoint of every contributing candidate.  One wave per block; the wave's partial sums of
 // the scene-parameter VJP live in LDS and are written to `partial` (reduced in fixed order afterwards,
 // so results are reproducible run to run).
-// GRADK = 0: values only (used for the TX-grid forward sweep, which has no culled kernel of its own).
+// GRADK = 0: values only (the exhaustive TX-grid value sweep behind the "txg_exhaustive" option).
 template <int MODE, bool TXG, bool GRADK>
 __global__ void __launch_bounds__(64) power_vg_kernel(SweepArgs a) {
     extern __shared__ float wl[];  // [4 N]
