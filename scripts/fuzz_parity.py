@@ -21,8 +21,9 @@ from oracle import c_oracle as CO  # noqa: E402
 F = np.float32
 
 
-def random_case(rng):
-    n = int(rng.integers(0, 26))
+def random_case(rng, big=False):
+    # big: more than 64 walls (several 64-lane chunks of last walls per prefix), orders <= 2
+    n = int(rng.integers(65, 140)) if big else int(rng.integers(0, 26))
     kind = rng.integers(0, 4)
     pts = rng.random((2 * n + 1, 2), dtype=F)
     walls = pts[1:].reshape(n, 2, 2).copy()
@@ -44,6 +45,9 @@ def random_case(rng):
     walls, tx, X, Y = walls * scale + off, tx * scale + off, X * scale + off, Y * scale + off
     mode = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")][int(rng.integers(0, 3))]
     max_order = int(rng.integers(0, 4)) if n <= 12 else int(rng.integers(0, 3))
+    if big:
+        gx, gy = int(rng.integers(1, 25)), int(rng.integers(1, 25))
+        X, Y = X[:gy, :gx], Y[:gy, :gx]
     min_order = int(rng.integers(0, max_order + 1))
     kw = dict(min_order=min_order, max_order=max_order, approx=mode[0], function=mode[1],
               alpha=float(rng.choice([100.0, 50.0, 10.0, 1000.0])), tol=float(rng.choice([1e-2, 1e-3, 0.5])),
@@ -58,12 +62,13 @@ def random_case(rng):
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"  # every other case has 65..139 walls
     rng = np.random.default_rng(seed)
     bad = 0
     t0 = time.time()
     with Context(0) as ctx:
         for case in range(n_cases):
-            walls, tx, X, Y, kw, allowed = random_case(rng)
+            walls, tx, X, Y, kw, allowed = random_case(rng, big=big and case % 2 == 1)
             ctx.set_scene(walls)
             ctx.set_candidate_mask(allowed)
             # every launch shape: patches shared between 4 waves or one wave each, identity or dearest-first order
