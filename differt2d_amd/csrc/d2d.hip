@@ -738,7 +738,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     a.pair_dperp = 0.0f;
     a.pair_prefix_ok = 0;
     bool prep_zeroed = false;
-    const bool txg_culled = txg && !grad_mode && !c->txg_exhaustive;  // TX grid, values only: culled kernel
+    const bool txg_culled = txg && !c->txg_exhaustive && !(grad_mode && p->strict_nan);  // TX grid: culled kernels
     if ((!txg || txg_culled) && c->N >= 2 && p->max_order >= 1) {
         // [N] masks, then the {histogram, cursors} of the patch schedule's counting sort: one memset for both
         if ((rc = c->d_shadow.ensure((size_t)c->N + d2d::SCHED_KEYS))) return rc;
@@ -834,7 +834,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             c->have_kernel_time = true;                          \
         }                                                        \
     } while (0)
-    if (txg_culled) {
+    if (txg_culled && !grad_mode) {
         const size_t lds_t = (size_t)(3 * c->N + 1) * sizeof(float4);
         if (lds_t > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
         a.grad = nullptr; a.cot = nullptr; a.partial = nullptr;
@@ -895,6 +895,21 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
                 case d2d::MODE_HSIG: D2D_LAUNCH_FWDG(d2d::MODE_HSIG); break;
                 default: D2D_LAUNCH_FWDG(d2d::MODE_SIG); break;
             }
+        } else if (txg_culled) {
+            // TX grid, culled value+grad sweep
+            const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4);
+            if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+#define D2D_LAUNCH_TXGG(MODE_)                                                                                              \
+    do {                                                                                                                    \
+        if (p->max_order <= 2) hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 2, true>), grid_patches, block, lds2, c->stream, a); \
+        else if (p->max_order == 3) hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 3, true>), grid_patches, block, lds2, c->stream, a); \
+        else hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 4, true>), grid_patches, block, lds2, c->stream, a);            \
+    } while (0)
+            switch (mode) {
+                case d2d::MODE_HARD: D2D_LAUNCH_TXGG(d2d::MODE_HARD); break;
+                case d2d::MODE_HSIG: D2D_LAUNCH_TXGG(d2d::MODE_HSIG); break;
+                default: D2D_LAUNCH_TXGG(d2d::MODE_SIG); break;
+            }
         } else
         {
 #define D2D_LAUNCH_VG(MODE_)                                                                                             \
@@ -911,7 +926,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         HIP_TRY(hipGetLastError());
         D2D_KERNEL_DONE();
         if (grad_mode == 2) {
-            const long rows = (!txg && !p->strict_nan) ? (long)grid_patches.x : (long)tiles;  // one row of partials per launched wave
+            const long rows = (long)tiles;  // one row of partials per patch
             hipLaunchKernelGGL(d2d::vjp_reduce_kernel, dim3((unsigned)n_elem), dim3(256), 0, c->stream, c->d_partial.p,
                                rows, n_elem, c->d_vjp.p, (p->out_mode == D2D_OUT_ADD && c->have_vjp) ? 1 : 0);
             HIP_TRY(hipGetLastError());

@@ -1399,10 +1399,10 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
 // the same geometric interaction points, and a path is its own reverse: the candidate (w_0 .. w_{K-1}) is culled as the
 // chain of F through (w_{K-1} .. w_0) towards the patch, with F's shadow masks on w_{K-1} (the segment w_{K-1} -> F).
 // Prefix = (w_0 .. w_{K-2}) wave-uniform, lanes = last wall, survivors in ascending order: the reference's order.
-template <int K, int MODE>
+template <int K, int MODE, bool GRAD = false>
 __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                        const float (&by)[4], float cx, float cy, bool lane_bad, float& acc,
-                                                       WaveStats& st) {
+                                                       WaveStats& st, GradCtx* g = nullptr) {
     const int lane = threadIdx.x & 63;
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
     float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];  // images of the lane's cell (per lane)
@@ -1421,7 +1421,7 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
         }
         const int last_prefix_pos = (K == 1) ? -1 : pos[K >= 2 ? K - 2 : 0];
         bool prefix_dead = false;
-        if (K >= 3 && a.pair && a.pair_prefix_ok) {
+        if (K >= 3 && !GRAD && a.pair && a.pair_prefix_ok) {
 #pragma unroll
             for (int d = 0; d + 1 < K - 1; ++d) prefix_dead = prefix_dead || (a.pair[(size_t)cand[d] * a.N + cand[d + 1]] == ~0ull);
         }
@@ -1452,7 +1452,7 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
                 mask &= mask - 1;
                 cand[K - 1] = a.cw[chunk * 64 + b];
                 image_of(a.refl[2 * cand[K - 1]], K == 1 ? cx : imgx[K >= 2 ? K - 2 : 0], K == 1 ? cy : imgy[K >= 2 ? K - 2 : 0], imgx[K - 1], imgy[K - 1]);
-                eval_candidate<K, MODE, false, false, false, true>(a, cand, imgx, imgy, cx, cy, a.txx, a.txy, lane_bad, acc, st, nullptr);
+                eval_candidate<K, MODE, false, GRAD, false, true>(a, cand, imgx, imgy, cx, cy, a.txx, a.txy, lane_bad, acc, st, g);
             }
         }
         if (K == 1) break;
@@ -1476,13 +1476,21 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
     }
 }
 
-template <int MODE, int MAXK>
+// GRADK: value + gradient (per cell w.r.t. the transmitter = the cell, scene.py:1617-1620; scene VJP w.r.t. the fixed
+// receiver and the walls) of the candidates the culling cannot drop.  The reference's autodiff NaN artefacts are
+// reproduced for those candidates only (the culling reasons about the reversed chain, whose poles are not the exact
+// chain's): d2d_params.strict_nan selects the exhaustive power_vg_kernel.
+template <int MODE, int MAXK, bool GRADK = false>
 __global__ void __launch_bounds__(64) power_fwd_txg_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
-    extern __shared__ float4 tab[];  // [2N] refl, [N] flt
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
     for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
     for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    float* wl = reinterpret_cast<float*>(tab + 3 * a.N);
+    const bool scene = GRADK && a.partial != nullptr;
+    if (scene)
+        for (int i = lane; i < 4 * a.N; i += 64) wl[i] = 0.0f;
     __syncthreads();
     WaveStats st;
 #pragma unroll
@@ -1500,6 +1508,11 @@ __global__ void __launch_bounds__(64) power_fwd_txg_kernel(SweepArgs a) {
     const float cx = a.X[idx], cy = a.Y[idx];
     const bool lane_bad = !(fabsf(cx) < 1e18f) || !(fabsf(cy) < 1e18f) || !(fabsf(a.txx) < 1e18f) || !(fabsf(a.txy) < 1e18f);
     float acc = 0.0f;  // scene.py:1593
+    GradCtx g;
+    g.grx = g.gry = g.tbx = g.tby = 0.0f;
+    g.cot = in_range ? (a.cot ? a.cot[idx] : 1.0f) : 0.0f;  // clamped duplicate lanes contribute nothing
+    g.wl = wl;
+    g.scene = scene;
     float x0 = cx, x1 = cx, y0 = cy, y1 = cy;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1512,16 +1525,37 @@ __global__ void __launch_bounds__(64) power_fwd_txg_kernel(SweepArgs a) {
     const float qn = __builtin_nanf("");
     const float bx[4] = {box_ok ? x0 : qn, x1, x1, x0};
     const float by[4] = {y0, y0, y1, y1};
-    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, false, true>(a, cx, cy, a.txx, a.txy, lane_bad, acc, st, nullptr);
-    if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled_txg<1, MODE>(a, tab, bx, by, cx, cy, lane_bad, acc, st);
-    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled_txg<2, MODE>(a, tab, bx, by, cx, cy, lane_bad, acc, st);
-    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled_txg<3, MODE>(a, tab, bx, by, cx, cy, lane_bad, acc, st);
-    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_culled_txg<4, MODE>(a, tab, bx, by, cx, cy, lane_bad, acc, st);
+    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, GRADK, true>(a, cx, cy, a.txx, a.txy, lane_bad, acc, st, &g);
+    if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled_txg<1, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
+    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled_txg<2, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled_txg<3, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_culled_txg<4, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
     if (in_range) {
-        if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
-        else a.out[idx] = acc;
+        if (a.out_mode == D2D_OUT_ADD) {
+            a.out[idx] = a.out[idx] + acc;
+            if (GRADK) {
+                a.grad[2 * idx] = a.grad[2 * idx] + g.grx;
+                a.grad[2 * idx + 1] = a.grad[2 * idx + 1] + g.gry;
+            }
+        } else {
+            a.out[idx] = acc;
+            if (GRADK) {
+                a.grad[2 * idx] = g.grx;
+                a.grad[2 * idx + 1] = g.gry;
+            }
+        }
     }
     if (a.cost_out && lane == 0) a.cost_out[tile] = st.work;
+    if (scene) {
+        const float sx = wave_sum(g.tbx), sy = wave_sum(g.tby);
+        __syncthreads();
+        float* dst = a.partial + tile * (4 * a.N + 2);  // one row per patch, whatever the schedule
+        for (int i = lane; i < 4 * a.N; i += 64) dst[i] = wl[i];
+        if (lane == 0) {
+            dst[4 * a.N] = sx;
+            dst[4 * a.N + 1] = sy;
+        }
+    }
 }
 
 // Patch schedule.  The hardware starts workgroups in blockIdx order, and a dear patch that starts late is the tail of the

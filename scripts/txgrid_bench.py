@@ -24,3 +24,14 @@ with Context(0) as ctx:
             print(f"approx={approx} {name}: {dt*1e3:.3f} ms per map", flush=True)
         print("   identical:", np.array_equal(res["culled"], res["exhaustive"], equal_nan=True))
         ctx.set_option("txg_exhaustive", 0)
+    # value + grad (per-cell d/d tx, scene VJP)
+    for approx in (False, True):
+        p = make_params(max_order=2, approx=approx, grid_role=L.GRID_TX)
+        for name, strict in (("culled", False), ("exhaustive (strict_nan)", True)):
+            p.strict_nan = int(strict)
+            for _ in range(2): ctx.launch_vg(p, rx, scene_vjp=True)
+            ctx.synchronize(); t = time.perf_counter()
+            n = 10 if not strict else 3
+            for _ in range(n): ctx.launch_vg(p, rx, scene_vjp=True)
+            ctx.synchronize()
+            print(f"value+grad approx={approx} {name}: {(time.perf_counter() - t) / n * 1e3:.3f} ms", flush=True)
