@@ -135,6 +135,10 @@ struct d2d_ctx {
     bool have_vjp = false;
     bool want_wave_cycles = false;
     long long split_max_tiles = 8192;   // launches up to this many patches share every patch between 4 waves
+    long long heavy_split = 64;        // bigger launches with a work history: this many of the dearest patches are cut in four
+    DevBuf<float> d_heavy_list;
+    DevBuf<int> d_heavy_cnt, d_heavy_done;
+    long long heavy_done_n = 0;
     // RCCL (one communicator per ctx, collectives run on the ctx stream)
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -380,6 +384,7 @@ int d2d_create(int device, d2d_ctx** out) {
     d2d_ctx* c = new d2d_ctx();
     c->device = device;
     if (const char* v = getenv("D2D_SCHED_MIN_TILES")) c->sched_min_tiles = atoll(v);  // tuning knob
+    if (const char* v = getenv("D2D_HEAVY_SPLIT")) c->heavy_split = atoll(v);
     if (const char* v = getenv("D2D_SPLIT_MAX_TILES")) c->split_max_tiles = atoll(v);  // tuning knob (0: never)
     hipError_t e1 = hipSetDevice(device);
     if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -423,6 +428,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_sched_key.release();
     c->d_sched_override.release();
     c->d_cost.release();
+    c->d_heavy_list.release(); c->d_heavy_cnt.release(); c->d_heavy_done.release();
     c->d_pair.release();
     c->d_grad.release(); c->d_cot.release(); c->d_partial.release(); c->d_vjp.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -793,6 +799,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     }
     // dearest-first patch schedule for the culled kernels
     a.sched = nullptr;
+    a.n_heavy = 0;
+    bool sched_from_history = false;
     if ((!txg || txg_culled) && !(grad_mode && p->strict_nan) && p->max_order >= 2 && c->cw.size() >= 2 && tiles >= c->sched_min_tiles) {
         if ((rc = c->d_sched.ensure((size_t)tiles))) return rc;
         if ((rc = c->d_sched_key.ensure((size_t)tiles))) return rc;
@@ -804,6 +812,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         // cost key: what the patch cost last time, when this context has swept the same grid before (optimisation
         // loops, repeated maps); otherwise a proxy computed from the geometry
         const bool from_history = c->cost_tiles == tiles && c->use_cost_history;
+        sched_from_history = from_history;
         if (!from_history)
             hipLaunchKernelGGL(d2d::patch_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, a, c->d_sched_key.p);
         {
@@ -942,11 +951,34 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     const size_t split_lds = tab_lds + (size_t)(D2D_SPLIT_W - 1) * d2d::SPLIT_LIST * 64 * sizeof(float) +
                              (size_t)((D2D_SPLIT_W - 1) * 65 + D2D_SPLIT_W + 1) * sizeof(int);
     const bool split = p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= 64 * 1024 && tiles <= c->split_max_tiles;
+    // the dearest patches of a bigger launch are cut in four (see power_fwd_kernel); they are only known with a work history
+    dim3 grid_fwd = grid_patches;
+    if (!split && !d_stats && p->max_order == 2 && c->cw.size() >= 2 && a.sched == c->d_sched.p && sched_from_history && c->heavy_split > 0) {
+        const long long H = std::min<long long>(c->heavy_split, tiles / 16);
+        const long long Nc = (long long)c->cw.size();
+        const long long P = d2d::HEAVY_PARTS;
+        const long long cap = ((Nc + P - 1) / P + 2) * Nc + Nc + 2;  // candidates one part can evaluate, generously
+        if (H > 0 && H * P * cap * 64 * (long long)sizeof(float) <= (4ll << 30)) {
+            if ((rc = c->d_heavy_list.ensure((size_t)(H * P * cap * 64)))) return rc;
+            if ((rc = c->d_heavy_cnt.ensure((size_t)(H * P * 64 + H * P)))) return rc;
+            if (c->heavy_done_n < H) {
+                if ((rc = c->d_heavy_done.ensure((size_t)H))) return rc;
+                HIP_TRY(hipMemsetAsync(c->d_heavy_done.p, 0, (size_t)H * sizeof(int), c->stream));  // the kernel re-zeroes it
+                c->heavy_done_n = H;
+            }
+            a.n_heavy = (int)H;
+            a.heavy_cap = (int)cap;
+            a.heavy_list = c->d_heavy_list.p;
+            a.heavy_cnt = c->d_heavy_cnt.p;
+            a.heavy_done = c->d_heavy_done.p;
+            grid_fwd = dim3((unsigned)(tiles + (P - 1) * H));
+        }
+    }
 #define D2D_LAUNCH_FWD(MODE_, STATS_, MAXK_)                                                                              \
     do {                                                                                                                  \
         if (split) hipLaunchKernelGGL((d2d::power_fwd_split_kernel<MODE_, STATS_, MAXK_, D2D_SPLIT_W>),                   \
                                       grid_patches, dim3(64 * D2D_SPLIT_W), split_lds, c->stream, a);     \
-        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, STATS_, MAXK_>), grid_patches, block, tab_lds, c->stream, a);   \
+        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, STATS_, MAXK_>), grid_fwd, block, tab_lds, c->stream, a);       \
     } while (0)
 #define D2D_LAUNCH_FWD_K(MODE_, STATS_)                      \
     do {                                                     \
@@ -1046,6 +1078,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return fail(D2D_ERR_INVALID, "d2d_set_option: NULL argument");
     if (!strcmp(name, "split_max_tiles")) c->split_max_tiles = value;
     else if (!strcmp(name, "sched_min_tiles")) c->sched_min_tiles = value;
+    else if (!strcmp(name, "heavy_split")) c->heavy_split = value;
     else if (!strcmp(name, "time_kernel")) c->time_kernel = value != 0;
     else if (!strcmp(name, "cost_history")) c->use_cost_history = value != 0;
     else if (!strcmp(name, "pair_masks")) c->use_pair_masks = value != 0;
@@ -1070,6 +1103,16 @@ int d2d_debug_set_schedule(d2d_ctx* c, const int32_t* order, int64_t n) {
     HIP_TRY(hipMemcpyAsync(c->d_sched_override.p, order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->sched_override_n = n;
+    return D2D_OK;
+}
+
+int d2d_debug_get_work(d2d_ctx* c, uint32_t* work, int64_t n) {
+    if (!c || !work) return fail(D2D_ERR_INVALID, "NULL argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (!c->d_cost.p || c->cost_tiles != n) return fail(D2D_ERR_STATE, "no work history of %lld patches", (long long)n);
+    HIP_TRY(hipMemcpyAsync(work, c->d_cost.p, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return D2D_OK;
 }
 

@@ -67,6 +67,13 @@ struct SweepArgs {
 
     // patch schedule (patch_cost_kernel / patch_order_kernel): workgroup b takes patch sched[b]; null = identity
     const int* __restrict__ sched;
+    // Dearest patches cut in four (power_fwd_kernel, max_order == 2, needs the schedule): workgroups [0, 4 * n_heavy)
+    // are the quarters of patches sched[0 .. n_heavy), the others take sched[n_heavy ..) one patch each
+    int n_heavy;
+    int heavy_cap;                    // list entries per lane and quarter (>= the candidates a quarter can evaluate)
+    float* __restrict__ heavy_list;   // [n_heavy][4][heavy_cap][64] non-zero contributions in candidate order
+    int* __restrict__ heavy_cnt;      // [n_heavy][4][64] entries per lane, then [n_heavy][4] work of the quarter
+    int* __restrict__ heavy_done;     // [n_heavy] quarters finished (zero between launches)
     unsigned* __restrict__ cost_out;  // [n_patches] work this patch took (feeds the next launch's schedule), or null
 
     unsigned long long* stats; // [D2D_NUM_STATS] executed-work counters (STATS build only), may be null
@@ -970,8 +977,9 @@ struct ListSink {
     float* col;  // this lane's column: entry i at col[i * 64]
     int cnt;
     bool over;
+    int cap = SPLIT_LIST;
     __device__ __forceinline__ void push(float v) {
-        if (cnt < SPLIT_LIST) {
+        if (cnt < cap) {
             col[cnt * 64] = v;
             ++cnt;
         } else {
@@ -1098,6 +1106,42 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
     }
 }
 
+// First-wall positions [lo, hi) of part `part` of `parts`, balanced over the first walls the prefix skip does not kill.
+__device__ __forceinline__ void first_wall_range(const SweepArgs& a, int part, int parts, int& lo, int& hi) {
+    const int lane = threadIdx.x & 63;
+    const int Nc = a.Nc;
+    const bool use_dead = a.shadow && a.shadow_prefix_ok;
+    const int n_chunks = (Nc + 63) >> 6;
+    int A = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int pp = c * 64 + lane;
+        const bool alive = pp < Nc && !(use_dead && a.shadow[a.cw[pp]] == ~0ull);
+        A += __builtin_popcountll(__ballot(alive));
+    }
+    auto boundary = [&](int r) -> int {
+        if (r <= 0) return 0;
+        if (r >= A) return Nc;
+        for (int c = 0; c < n_chunks; ++c) {
+            const int pp = c * 64 + lane;
+            const bool alive = pp < Nc && !(use_dead && a.shadow[a.cw[pp]] == ~0ull);
+            unsigned long long m = __ballot(alive);
+            const int n = __builtin_popcountll(m);
+            if (r < n) {
+                for (; r > 0; --r) m &= m - 1;
+                return c * 64 + __builtin_ctzll(m);
+            }
+            r -= n;
+        }
+        return Nc;
+    };
+    lo = boundary((int)(((long)A * part) / parts));
+    hi = (part == parts - 1) ? Nc : boundary((int)(((long)A * (part + 1)) / parts));
+}
+
+#ifndef D2D_HEAVY_PARTS
+#define D2D_HEAVY_PARTS 4
+#endif
+constexpr int HEAVY_PARTS = D2D_HEAVY_PARTS;  // the dearest patches of a launch are cut into this many parts (power_fwd_kernel)
 constexpr int TILE_W = 8;  // a wave covers an 8 x 8 patch of RX cells: neighbouring cells share skips
 constexpr int TILE_H = 8;
 
@@ -1133,7 +1177,16 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     st.work = 0;
     // One 8 x 8 patch per wave, one wave per workgroup: measured equal or better than persistent waves walking several
     // patches (static striding or an atomic work queue) at 1024^2 .. 4096^2, and it keeps the VGPR count lower.
-    const long tile0 = blockIdx.x;
+    // ... except the dearest patches of a launch with a work history (max_order == 2): a patch can take 4x the mean and a
+    // 1024^2 launch is only ~4 mean patch latencies long, so they are its critical path even though they start first
+    // (scripts/timeline.py: the last 22 % of the launch wait for fewer than 60 of 16 384 patches).  Each of them is cut into
+    // four quarters of first walls, swept by four single-wave workgroups that leave their non-zero contributions as
+    // ordered lists in global memory; the quarter that finishes last adds them up in candidate order (bit for bit the
+    // reference's sum) and writes the cell.  A list cannot overflow: it holds as many entries as the quarter has candidates.
+    const long b0 = blockIdx.x;
+    const bool quarter = !STATS && !GRADK && MAXK == 2 && (b0 < (long)HEAVY_PARTS * a.n_heavy);  // wave-uniform
+    const long tile0 = quarter ? (b0 / HEAVY_PARTS) : (b0 - (long)(HEAVY_PARTS - 1) * a.n_heavy);
+    const int part = quarter ? (int)(b0 % HEAVY_PARTS) : 0;
     const long tile = a.sched ? (long)a.sched[tile0] : tile0;
     const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tcol = (int)(tile % tiles_x), trow = (int)(tile / tiles_x);
@@ -1198,6 +1251,51 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     const float by[4] = {y0, y0, y1, y1};
     unsigned long long tq0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[10] += tq0 - t_start;  // prologue of the patch
+    if (quarter) {
+        const long hq = tile0 * HEAVY_PARTS + part;
+        ListSink sink;
+        sink.col = a.heavy_list + hq * (long)a.heavy_cap * 64 + lane;
+        sink.cnt = 0;
+        sink.over = false;
+        sink.cap = a.heavy_cap;
+        float dummy = 0.0f;
+        if (part == 0) {
+            if (a.min_order <= 0 && a.max_order >= 0) {
+                float t = 0.0f;
+                sweep_order<0, MODE, false, false>(a, a.txx, a.txy, rxx, rxy, lane_bad, t, st, nullptr);
+                if (!(t == 0.0f)) sink.push(t);
+            }
+            if (a.min_order <= 1 && a.max_order >= 1)
+                sweep_order_culled<1, MODE, false, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, 0, 0x7fffffff, &sink);
+        }
+        if (a.min_order <= 2 && a.max_order >= 2) {
+            int lo, hi;
+            first_wall_range(a, part, HEAVY_PARTS, lo, hi);
+            sweep_order_culled<2, MODE, false, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, lo, hi, &sink);
+        }
+        a.heavy_cnt[hq * 64 + lane] = sink.over ? -1 : sink.cnt;
+        if (lane == 0) a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq] = (int)st.work;
+        __threadfence();
+        int old = 0;
+        if (lane == 0) old = atomicAdd(&a.heavy_done[tile0], 1);
+        if (__builtin_amdgcn_readfirstlane(old) != HEAVY_PARTS - 1) return;  // another part will finish the patch
+        __threadfence();
+        unsigned work = 0;
+        for (int q = 0; q < HEAVY_PARTS; ++q) {
+            const long hq2 = tile0 * HEAVY_PARTS + q;
+            const int n = a.heavy_cnt[hq2 * 64 + lane];
+            int nmax = n;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+            const float* col = a.heavy_list + hq2 * (long)a.heavy_cap * 64 + lane;
+            for (int i = 0; i < nmax; ++i)
+                if (i < n) acc = acc + col[i * 64];  // scene.py:1909, in candidate order
+            if (n < 0) acc = __builtin_nanf("");     // cannot happen (heavy_cap covers every candidate); never silently wrong
+            work += (unsigned)a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq2];
+        }
+        st.work = work;
+        if (lane == 0) a.heavy_done[tile0] = 0;  // ready for the next launch
+    } else {
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, GRADK>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, &g);
     unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[11] += tq1 - tq0;      // order 0
@@ -1208,6 +1306,7 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     if (STATS) st.c[13] += __builtin_amdgcn_s_memtime() - tq2;  // order 2
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled<3, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
     if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_culled<4, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
+    }
     if (in_range) {
         if (a.out_mode == D2D_OUT_ADD) {
             a.out[idx] = a.out[idx] + acc;

@@ -221,6 +221,12 @@ class Context:
         L.check(self._lib.d2d_debug_get_schedule(self._ctx, order, key, n_patches))
         return order, key
 
+    def debug_get_work(self, n_patches: int) -> np.ndarray:
+        """Diagnostic: the work (units of ~25 wave-instructions) each patch took in the last culled sweep."""
+        out = np.empty(n_patches, np.uint32)
+        L.check(self._lib.d2d_debug_get_work(self._ctx, out, n_patches))
+        return out
+
     def last_kernel_ms(self) -> float:
         """Duration of the sweep kernel of the last launch (needs ``set_option("time_kernel", 1)``)."""
         ms = C.c_float(0.0)

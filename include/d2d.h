@@ -197,6 +197,8 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
 /* Launch-shape tuning of a context; never changes a result bit (tests sweep these to cover every kernel variant).
  *   "split_max_tiles": launches of at most this many 8 x 8 patches share every patch between 4 waves (default 8192; 0 = never)
  *   "sched_min_tiles": launches of at least this many patches start their dearest patches first (default 2048)
+ *   "heavy_split": with a work history and max_order == 2, this many of the dearest patches of a launch that is too big to
+ *                  share every patch are cut in four parts swept by separate workgroups (default 64; 0 = none)
  *   "cost_history": non-zero (default) = a launch that sweeps the same grid as the previous one orders its patches by the
  *                   work each took then (counted by the kernels); zero = always by the geometric proxy
  *   "pair_masks": zero = do not build / use the wall-to-wall occlusion masks (A/B and tests; same results)
@@ -213,6 +215,9 @@ int d2d_set_option(d2d_ctx* ctx, const char* name, int64_t value);
  * of 0..n-1) instead; n = 0 removes the override. */
 int d2d_debug_set_schedule(d2d_ctx* ctx, const int32_t* order, int64_t n);
 int d2d_debug_get_schedule(d2d_ctx* ctx, int32_t* order, uint8_t* key, int64_t n);
+/* The work history behind the schedule: what each of the n patches took in the last culled sweep (units of ~25
+ * wave-instructions, counted by the kernels). */
+int d2d_debug_get_work(d2d_ctx* ctx, uint32_t* work, int64_t n);
 
 /* Duration of the sweep kernel proper of the last launch on this context -- without the preparation kernels in front
  * of it (shadow masks, patch schedule) and the VJP reduction behind it -- from HIP events recorded on the context's

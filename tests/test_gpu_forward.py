@@ -172,6 +172,13 @@ def test_cfg2_full_size_sampled_cells_and_block_invariance(ctx, approx, function
     want = _oracle(walls, tx, X[ii, jj], Y[ii, jj], **kw)
     assert np.array_equal(got[ii, jj], want)
     assert (want > 0).sum() > 100  # the sample sees plenty of lit cells
+    # repeated sweeps of the same grid (what bench.py times): work-history schedule, dearest patches cut in four
+    from differt2d_amd.engine import make_params
+
+    ctx.set_grid(X, Y)
+    for _ in range(3):
+        ctx.launch(make_params(**kw), tx)
+        assert np.array_equal(ctx.get_map(), got)
     block = ctx.power_map(tx, X[403:446, 617:700], Y[403:446, 617:700], **kw)
     assert np.array_equal(block, got[403:446, 617:700])
 
@@ -207,9 +214,29 @@ def test_repeated_sweeps_reschedule_from_the_work_history(ctx):
         ctx.set_option("cost_history", 0)
         ctx.launch(p, tx)
         assert np.array_equal(ctx.get_map(), maps[0])
+        # with a history, launches too big to share every patch cut their dearest patches in four parts that leave
+        # ordered contribution lists in global memory (power_fwd_kernel): force that path on this small grid
+        ctx.set_option("cost_history", 1)
+        ctx.set_option("split_max_tiles", 0)
+        for heavy in (3, 1000):
+            ctx.set_option("heavy_split", heavy)
+            for t, want in ((tx, maps[0]), (txs[1], maps[1]), (tx, maps[0])):
+                ctx.launch(p, t)
+                ctx.launch(p, t)
+                assert np.array_equal(ctx.get_map(), want)
+        for q in (make_params(max_order=2, approx=False), make_params(min_order=2, max_order=2, approx=True), make_params(min_order=1, max_order=2)):
+            ctx.set_option("heavy_split", 0)
+            ctx.launch(q, tx)
+            ref = ctx.get_map()
+            ctx.set_option("heavy_split", 1000)
+            ctx.launch(q, tx)
+            ctx.launch(q, tx)
+            assert np.array_equal(ctx.get_map(), ref)
     finally:
         ctx.set_option("cost_history", 1)
         ctx.set_option("sched_min_tiles", 2048)
+        ctx.set_option("heavy_split", 64)
+        ctx.set_option("split_max_tiles", 8192)
 
 
 def test_acceleration_masks_do_not_change_results(ctx):
