@@ -1188,6 +1188,9 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     const long tile0 = quarter ? (b0 / HEAVY_PARTS) : (b0 - (long)(HEAVY_PARTS - 1) * a.n_heavy);
     const int part = quarter ? (int)(b0 % HEAVY_PARTS) : 0;
     const long tile = a.sched ? (long)a.sched[tile0] : tile0;
+#ifdef D2D_AB_TIMELINE
+    const unsigned long long t_line0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, common to all XCDs
+#endif
     const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tcol = (int)(tile % tiles_x), trow = (int)(tile / tiles_x);
     const int col = tcol * TILE_W + (lane & (TILE_W - 1));
@@ -1327,7 +1330,12 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
         tby_sum += wave_sum(g.tby);
     }
     if (STATS && lane == 0 && a.wave_cycles) a.wave_cycles[tile] = __builtin_amdgcn_s_memtime() - t_start;
+#ifdef D2D_AB_TIMELINE  // diagnostic build (scripts/timeline.py): start / end stamps of the patch instead of its work
+    if (!STATS && a.cost_out && lane == 0)
+        a.cost_out[tile] = (unsigned)(((t_line0 & 0xffffull) << 16) | (__builtin_amdgcn_s_memrealtime() & 0xffffull));
+#else
     if (!STATS && a.cost_out && lane == 0) a.cost_out[tile] = st.work;
+#endif
     if (scene) {
         __syncthreads();
         // one row per patch: the row order of the fp64 reduction must not depend on the schedule
