@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import workload
 from differt2d_amd.engine import Context, make_params
 g = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+vg = len(sys.argv) > 2 and sys.argv[2] == "vg"  # time the value+grad sweep instead of the forward sweep
 tx, walls, X, Y = workload(grid=g)
 T = (g // 8) ** 2
 with Context(0) as ctx:
@@ -16,7 +17,12 @@ with Context(0) as ctx:
     for approx in (False, True):
         p = make_params(max_order=2, approx=approx)
         ctx.set_option("cost_history", 0)   # the stamps overwrite the work history in this build
-        ctx.launch(p, tx); ctx.launch(p, tx); ctx.synchronize()
+        for _ in range(2):
+            if vg:
+                ctx.launch_vg(p, tx, scene_vjp=True)
+            else:
+                ctx.launch(p, tx)
+        ctx.synchronize()
         w = ctx.debug_get_work(T)
         t0 = (w >> 16).astype(np.int64); t1 = (w & 0xffff).astype(np.int64)
         base = np.min(t0)  # wrap-around handling: stamps are 16 bits of a 10 ns counter (655 us)
