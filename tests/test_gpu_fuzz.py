@@ -45,3 +45,11 @@ def test_culled_and_exhaustive_gradient_kernels_agree_on_random_scenes():
             assert np.abs(a["grad_rx"][fin] - b["grad_rx"][fin]).max(initial=0.0) <= 1e-5 * scale
             assert not (np.isnan(a["grad_rx"]) & fin).any()
             done += 1
+
+
+def test_cut_in_four_handover_is_stable_under_repetition():
+    """scripts/stress_heavy.py: hundreds of launches of the bench workload through the path where four workgroups hand a
+    patch over through global memory -- every map must equal the uncut sweep's bit for bit."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "stress_heavy.py"), "150"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "stress: 0 mismatching maps" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
