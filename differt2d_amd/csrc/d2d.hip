@@ -943,13 +943,14 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
         return D2D_OK;
     }
-    const size_t tab_lds = (size_t)(4 * c->N + 1) * sizeof(float4);
+    const size_t tab_lds = (size_t)(4 * c->N + 1) * sizeof(float4) + 512;  // tables (+ adjoint table) + one culling queue
     if (tab_lds > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~1300)", c->N);
     // Launches that hold only a few patches per SIMD are bound by their dearest patch: share every patch between
     // D2D_SPLIT_W waves there (power_fwd_split_kernel).  Big grids are throughput-bound: one wave per patch.
     constexpr int D2D_SPLIT_W = 4;
-    const size_t split_lds = tab_lds + (size_t)(D2D_SPLIT_W - 1) * d2d::SPLIT_LIST * 64 * sizeof(float) +
-                             (size_t)((D2D_SPLIT_W - 1) * 65 + D2D_SPLIT_W + 1) * sizeof(int);
+    const size_t split_base = ((tab_lds - 512 + (size_t)(D2D_SPLIT_W - 1) * d2d::SPLIT_LIST * 64 * sizeof(float) +
+                                (size_t)((D2D_SPLIT_W - 1) * 65 + D2D_SPLIT_W + 1) * sizeof(int)) + 15) & ~(size_t)15;
+    const size_t split_lds = split_base + (size_t)D2D_SPLIT_W * 512;  // ... + one culling queue per wave
     const bool split = p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= 64 * 1024 && tiles <= c->split_max_tiles;
     // the dearest patches of a bigger launch are cut in four (see power_fwd_kernel); they are only known with a work history
     dim3 grid_fwd = grid_patches;
@@ -974,6 +975,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             grid_fwd = dim3((unsigned)(tiles + (P - 1) * H));
         }
     }
+    a.cullq_off = (int)(split ? split_base : (size_t)(4 * c->N + 1) * sizeof(float4));
 #define D2D_LAUNCH_FWD(MODE_, STATS_, MAXK_)                                                                              \
     do {                                                                                                                  \
         if (split) hipLaunchKernelGGL((d2d::power_fwd_split_kernel<MODE_, STATS_, MAXK_, D2D_SPLIT_W>),                   \

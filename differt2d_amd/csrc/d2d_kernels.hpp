@@ -67,6 +67,7 @@ struct SweepArgs {
 
     // patch schedule (patch_cost_kernel / patch_order_kernel): workgroup b takes patch sched[b]; null = identity
     const int* __restrict__ sched;
+    int cullq_off;  // byte offset, from the start of dynamic LDS, of the culling queues (512 B per wave of the workgroup)
     // Dearest patches cut in four (power_fwd_kernel, max_order == 2, needs the schedule): workgroups [0, 4 * n_heavy)
     // are the quarters of patches sched[0 .. n_heavy), the others take sched[n_heavy ..) one patch each
     int n_heavy;
@@ -1012,6 +1013,66 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
     for (int d = 1; d < K - 1; ++d) pos[d] = (pos[d - 1] == 0) ? 1 : 0;  // no equal neighbours
     if (K - 1 > 0 && (Nc < 2 || p_lo >= p_end)) return;
     if (Nc < 1) return;
+    // Two-stage culling (forward builds, K >= 2).  Stage 1, per prefix and chunk of last walls: only the level next to
+    // the patch (can the last wall's interaction point lie on the wall for any cell?) -- a third of the work at order 2, a
+    // quarter at order 3, and most lanes die there.  The survivors are queued, in candidate order, in LDS; whenever 64 are
+    // waiting, stage 2 runs the full multi-level test (shadow and wall-to-wall masks included) on a FULL wave of them,
+    // and its survivors are evaluated exactly, still in candidate order.
+    constexpr bool QUEUE = !GRAD && K >= 2;
+    unsigned long long* cullq = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(const_cast<float4*>(tab)) + a.cullq_off) +
+                                ((threadIdx.x >> 6) & 3) * 64;  // 64 slots per wave behind the kernel's other LDS data
+    int qn = 0;  // wave-uniform
+    auto flush = [&]() {
+        if (qn == 0) return;
+        __builtin_amdgcn_wave_barrier();
+        bool alive2 = lane < qn;
+        const unsigned long long code = cullq[lane < qn ? lane : 0];
+        {
+            WallC w[K];
+            float Ix[K], Iy[K];
+            float ix = a.txx, iy = a.txy;
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+                const int wd = (int)((code >> (12 * d)) & 0xfffull);
+                const float4 r0 = tab[2 * wd], r1 = tab[2 * wd + 1], fc = tab[2 * a.N + wd];
+                w[d] = make_wallc(r0, r1, fc, wd);
+                image_of(r0, ix, iy, Ix[d], Iy[d]);
+                ix = Ix[d];
+                iy = Iy[d];
+            }
+            const unsigned long long sh0 = a.shadow ? a.shadow[w[0].idx] : 0ull;
+            if (alive2 && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive2 = false;
+        }
+        unsigned long long mask = __ballot(alive2);
+        if (STATS) st.c[9] += K;
+        D2D_WORK(5 * K);
+        const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+        while (mask) {
+            const int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const unsigned long long cb = cullq[b];
+            const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(cb & 0xffffffffull));
+            const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(cb >> 32));
+            const unsigned long long cu = ((unsigned long long)hi32 << 32) | lo32;
+            int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+            float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+                ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
+                image_of(a.refl[2 * ce[d]], d == 0 ? a.txx : ex[d > 0 ? d - 1 : 0], d == 0 ? a.txy : ey[d > 0 ? d - 1 : 0], ex[d], ey[d]);
+            }
+            if (LIST) {
+                float t = 0.0f;
+                eval_candidate<K, MODE, STATS, GRAD, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, lane_bad, t, st, g);
+                if (!(t == 0.0f)) sink->push(t);  // non-zero or NaN
+            } else {
+                eval_candidate<K, MODE, STATS, GRAD, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, g);
+            }
+        }
+        if (STATS) st.c[14] += __builtin_amdgcn_s_memtime() - te0;
+        qn = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
     while (true) {
         // images of the prefix
 #pragma unroll
@@ -1045,6 +1106,31 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
             // ---- lanes = candidates: lane l <-> last wall = cw[chunk * 64 + l]
             const int lp = chunk * 64 + lane;
             bool alive = (lp < Nc) && (lp != last_prefix_pos);
+            if (QUEUE) {
+                const int wl = a.cw[lp < Nc ? lp : 0];
+                const float4 r0 = tab[2 * wl], r1 = tab[2 * wl + 1], fc = tab[2 * a.N + wl];
+                const WallC wlast = make_wallc(r0, r1, fc, wl);
+                float lx, ly;
+                image_of(r0, pIx, pIy, lx, ly);
+                if (alive) {
+                    float smin, smax, M, E;
+                    const bool ok = s_range(bx, by, lx, ly, wlast, smin, smax, M, E);
+                    if (ok && (smax + M < a.on_lo || smin - M > a.on_hi)) alive = false;
+                }
+                const unsigned long long m1 = __ballot(alive);
+                const int cnt = __builtin_popcountll(m1);
+                if (STATS) st.c[9] += 1;
+                D2D_WORK(5);
+                if (qn + cnt > 64) flush();
+                if (alive) {
+                    unsigned long long code = (unsigned long long)wl << (12 * (K - 1));
+#pragma unroll
+                    for (int d = 0; d < K - 1; ++d) code |= (unsigned long long)cand[d] << (12 * d);
+                    cullq[qn + __builtin_popcountll(m1 & ((1ull << lane) - 1ull))] = code;
+                }
+                qn += cnt;
+                continue;
+            }
             {
                 const int wl = a.cw[lp < Nc ? lp : 0];
                 WallC w[K];
@@ -1104,6 +1190,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         for (int e = 1; e < K - 1; ++e)
             if (e > stop) pos[e] = (pos[e - 1] == 0) ? 1 : 0;
     }
+    if (QUEUE) flush();
 }
 
 // First-wall positions [lo, hi) of part `part` of `parts`, balanced over the first walls the prefix skip does not kill.
