@@ -891,8 +891,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         const size_t lds = (size_t)(4 * c->N + 4) * sizeof(float);
         if (!txg && !p->strict_nan) {
             // culled value+grad sweep (default)
-            const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4);
+            const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4) + 512;  // tables, adjoint table, culling queue
             if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+            a.cullq_off = (int)((size_t)(4 * c->N + 1) * sizeof(float4));
 #define D2D_LAUNCH_FWDG(MODE_)                                                                                              \
     do {                                                                                                                    \
         if (p->max_order <= 2) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 2, true>), grid_patches, block, lds2, c->stream, a); \

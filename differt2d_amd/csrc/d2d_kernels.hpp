@@ -1018,7 +1018,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
     // quarter at order 3, and most lanes die there.  The survivors are queued, in candidate order, in LDS; whenever 64 are
     // waiting, stage 2 runs the full multi-level test (shadow and wall-to-wall masks included) on a FULL wave of them,
     // and its survivors are evaluated exactly, still in candidate order.
-    constexpr bool QUEUE = !GRAD && K >= 2;
+    constexpr bool QUEUE = K >= 2;
     unsigned long long* cullq = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(const_cast<float4*>(tab)) + a.cullq_off) +
                                 ((threadIdx.x >> 6) & 3) * 64;  // 64 slots per wave behind the kernel's other LDS data
     int qn = 0;  // wave-uniform
@@ -1041,7 +1041,8 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 iy = Iy[d];
             }
             const unsigned long long sh0 = a.shadow ? a.shadow[w[0].idx] : 0ull;
-            if (alive2 && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive2 = false;
+            const bool bypass = GRAD && ((code >> 60) & 1ull);
+            if (alive2 && !bypass && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive2 = false;
         }
         unsigned long long mask = __ballot(alive2);
         if (STATS) st.c[9] += K;
@@ -1112,7 +1113,11 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 const WallC wlast = make_wallc(r0, r1, fc, wl);
                 float lx, ly;
                 image_of(r0, pIx, pIy, lx, ly);
-                if (alive) {
+                if (GRAD && prefix_dead) {
+                    // value+grad build, first wall wholly in shadow: keep only the candidates whose last-wall pole may
+                    // cross the patch; they bypass stage 2 (nothing may cull them) and are evaluated exactly
+                    alive = alive && pole_possible(bx, by, lx, ly, wlast.nx, wlast.ny);
+                } else if (alive) {
                     float smin, smax, M, E;
                     const bool ok = s_range(bx, by, lx, ly, wlast, smin, smax, M, E);
                     if (ok && (smax + M < a.on_lo || smin - M > a.on_hi)) alive = false;
@@ -1123,7 +1128,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 D2D_WORK(5);
                 if (qn + cnt > 64) flush();
                 if (alive) {
-                    unsigned long long code = (unsigned long long)wl << (12 * (K - 1));
+                    unsigned long long code = ((unsigned long long)wl << (12 * (K - 1))) | ((GRAD && prefix_dead) ? (1ull << 60) : 0ull);
 #pragma unroll
                     for (int d = 0; d < K - 1; ++d) code |= (unsigned long long)cand[d] << (12 * d);
                     cullq[qn + __builtin_popcountll(m1 & ((1ull << lane) - 1ull))] = code;
