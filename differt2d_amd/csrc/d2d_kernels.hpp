@@ -1074,7 +1074,39 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         qn = 0;
         __builtin_amdgcn_wave_barrier();
     };
+    // Order 3, forward builds: the second walls that can follow the current first wall at all (not the same wall, not
+    // mutually invisible with it bin for bin) as a bit mask over positions, one 64-lane test per chunk when the first wall
+    // changes; the odometer then steps from set bit to set bit instead of visiting all N-1 second walls one by one (two
+    // dependent scalar loads each).  Positions beyond 256 walls fall back to plain stepping.
+    const bool use_amask = (K == 3) && !GRAD && Nc <= 256 && a.pair && a.pair_prefix_ok;
+    unsigned long long amask[4] = {0ull, 0ull, 0ull, 0ull};
+    int amask_for = -1;
+    auto next_alive = [&](int from) -> int {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (from < (c + 1) * 64) {
+                const int sh = from > c * 64 ? from - c * 64 : 0;
+                const unsigned long long x = amask[c] & (~0ull << sh);
+                if (x) return c * 64 + __builtin_ctzll(x);
+            }
+        }
+        return Nc;
+    };
     while (true) {
+        bool skip_all = false;
+        if (use_amask && amask_for != pos[0]) {
+            const int w0 = a.cw[pos[0]];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int p1 = c * 64 + lane;
+                const bool ok = p1 < Nc && p1 != pos[0] && a.pair[(size_t)w0 * a.N + a.cw[p1 < Nc ? p1 : 0]] != ~0ull;
+                amask[c] = __ballot(ok);
+            }
+            amask_for = pos[0];
+            pos[1] = next_alive(0);
+        }
+        if (use_amask && pos[1] >= Nc) skip_all = true;  // nothing can follow this first wall
+        if (!skip_all) {
         // images of the prefix
 #pragma unroll
         for (int d = 0; d < K - 1; ++d) {
@@ -1097,6 +1129,12 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         // may cross the patch (a cheap test, few survivors) and evaluates those exactly.  NaN artefacts that only arise
         // deeper in a dead prefix's chain are not reproduced (d2d_params.strict_nan is the exhaustive kernel).
         bool prefix_dead = (K >= 2) && a.shadow && a.shadow_prefix_ok && (a.shadow[cand[0]] == ~0ull);
+        if (K >= 3 && !GRAD && prefix_dead) {
+            // the FIRST wall is dead: so are all (N-1)^(K-2) prefixes that start with it -- leave the inner positions at
+            // their end so that the odometer below moves straight on to the next first wall
+#pragma unroll
+            for (int d = 1; d < K - 1; ++d) pos[d] = Nc;
+        }
         if (K >= 3 && !GRAD && a.pair && a.pair_prefix_ok) {
             // two consecutive walls of the prefix whose windows are mutually invisible bin for bin: whatever follows,
             // the segment between them is occluded (or one of its ends is off its wall)
@@ -1175,6 +1213,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
             }
             if (STATS) st.c[14] += __builtin_amdgcn_s_memtime() - te0;  // exact evaluation of the survivors
         }
+        }  // !skip_all
         // next prefix (lexicographic, no equal neighbours); static indexing keeps pos[] in registers
         if (K == 1) break;
         bool carry = true;
@@ -1182,8 +1221,12 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
 #pragma unroll
         for (int d = K - 2; d >= 0; --d) {
             if (carry) {
-                pos[d] += 1;
-                if (d > 0 && pos[d] == pos[d - 1]) pos[d] += 1;
+                if (use_amask && d == 1) {
+                    pos[d] = (pos[d] >= Nc) ? Nc : next_alive(pos[d] + 1);
+                } else {
+                    pos[d] += 1;
+                    if (d > 0 && pos[d] == pos[d - 1]) pos[d] += 1;
+                }
                 if (pos[d] < (d == 0 ? p_end : Nc)) {
                     carry = false;
                     stop = d;
