@@ -1013,6 +1013,34 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
     for (int d = 1; d < K - 1; ++d) pos[d] = (pos[d - 1] == 0) ? 1 : 0;  // no equal neighbours
     if (K - 1 > 0 && (Nc < 2 || p_lo >= p_end)) return;
     if (Nc < 1) return;
+    // Forward builds: the first walls that are not wholly in the fixed end point's shadow, as a bit mask over positions;
+    // the odometer steps from set bit to set bit (a shadowed first wall costs nothing at all).
+    const bool use_fmask = (K >= 2) && !GRAD && Nc <= 256 && a.shadow && a.shadow_prefix_ok;
+    unsigned long long fmask[4] = {0ull, 0ull, 0ull, 0ull};
+    if (use_fmask) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int p0 = c * 64 + lane;
+            fmask[c] = __ballot(p0 < Nc && a.shadow[a.cw[p0 < Nc ? p0 : 0]] != ~0ull);
+        }
+    }
+    auto next_first = [&](int from) -> int {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (from < (c + 1) * 64) {
+                const int sh = from > c * 64 ? from - c * 64 : 0;
+                const unsigned long long x = fmask[c] & (~0ull << sh);
+                if (x) return c * 64 + __builtin_ctzll(x);
+            }
+        }
+        return Nc;
+    };
+    if (use_fmask) {
+        pos[0] = next_first(p_lo);
+        if (pos[0] >= p_end) return;
+#pragma unroll
+        for (int d = 1; d < K - 1; ++d) pos[d] = (pos[d - 1] == 0) ? 1 : 0;
+    }
     // Two-stage culling (forward builds, K >= 2).  Stage 1, per prefix and chunk of last walls: only the level next to
     // the patch (can the last wall's interaction point lie on the wall for any cell?) -- a third of the work at order 2, a
     // quarter at order 3, and most lanes die there.  The survivors are queued, in candidate order, in LDS; whenever 64 are
@@ -1223,6 +1251,8 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
             if (carry) {
                 if (use_amask && d == 1) {
                     pos[d] = (pos[d] >= Nc) ? Nc : next_alive(pos[d] + 1);
+                } else if (use_fmask && d == 0) {
+                    pos[d] = next_first(pos[d] + 1);
                 } else {
                     pos[d] += 1;
                     if (d > 0 && pos[d] == pos[d - 1]) pos[d] += 1;
