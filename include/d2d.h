@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define D2D_MAX_ORDER 4 /* highest interaction order a sweep accepts */
-#define D2D_ABI_VERSION 2
+#define D2D_ABI_VERSION 3
 
 typedef enum d2d_status {
     D2D_OK = 0,
