@@ -313,3 +313,33 @@ def test_scene_vjp_entry_point_matches_autodiff():
         assert not np.isnan(want[w]).any() and not np.isnan(out[k]).any(), k
         scale = np.abs(want[w]).max()
         assert np.abs(out[k] - want[w]).max() <= 3e-5 * scale, k
+
+
+def test_schedule_diagnostics_roundtrip():
+    """d2d_debug_{get,set}_schedule / d2d_debug_get_work: the built-in schedule is a permutation of the patches, an injected
+    one (here: reversed) changes nothing but the order, and the work history is positive for every patch."""
+    from conftest import random_scene, unit_grid
+    from differt2d_amd.engine import Context, make_params
+
+    tx, walls = random_scene(20, seed=2)
+    X, Y = unit_grid(80, 64)
+    n_patches = 10 * 8
+    with Context(0) as ctx:
+        ctx.set_scene(walls)
+        ctx.set_grid(X, Y)
+        ctx.set_option("sched_min_tiles", 1)
+        p = make_params(max_order=2, approx=True)
+        ctx.launch(p, tx)
+        ref = ctx.get_map()
+        order, key = ctx.debug_get_schedule(n_patches)
+        assert sorted(order.tolist()) == list(range(n_patches)) and key.shape == (n_patches,)
+        work = ctx.debug_get_work(n_patches)
+        assert (work > 0).all()
+        ctx.debug_set_schedule(order[::-1].copy())
+        ctx.launch(p, tx)
+        assert np.array_equal(ctx.get_map(), ref)
+        with pytest.raises(Exception):
+            ctx.debug_set_schedule(np.zeros(n_patches, np.int32))  # not a permutation
+        ctx.debug_set_schedule(None)
+        ctx.launch(p, tx)
+        assert np.array_equal(ctx.get_map(), ref)
