@@ -1837,7 +1837,10 @@ __global__ void __launch_bounds__(64) power_fwd_txg_kernel(SweepArgs a) {
 // patch_cost_kernel: one wave per patch -> key in [0, 63] + histogram;  patch_order_kernel: counting sort, dearest
 // first.  Ties are placed in atomic order: the schedule may differ from run to run, the results cannot.
 constexpr int SCHED_KEYS = 256;  // = blockDim of the two sort passes
-constexpr int SCHED_PER_THREAD = 16;  // patches per thread in the two counting-sort passes (few, aggregated global atomics)
+#ifndef D2D_SCHED_PER_THREAD
+#define D2D_SCHED_PER_THREAD 4
+#endif
+constexpr int SCHED_PER_THREAD = D2D_SCHED_PER_THREAD;  // patches per thread in the two counting-sort passes (16: 4 % slower steps at 1024^2 -- too few blocks)
 __global__ void __launch_bounds__(256) patch_cost_kernel(SweepArgs a, unsigned char* __restrict__ key) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
