@@ -82,7 +82,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(tx, walls, X, Y, max_order, approx, budget_rows=24):
+def cpu_baseline(tx, walls, X, Y, max_order, approx, budget_rows=64):
     """Oracle (C restatement, OpenMP, all usable host cores) timed on a bounded row sample of the same grid."""
     from oracle import c_oracle as CO
 
