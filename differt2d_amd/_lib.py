@@ -14,7 +14,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libd2d.so")
+# D2D_LIB selects another build of the same ABI (A/B variants built aside by scripts/ab_build.sh); the product library is
+# never overwritten by an experiment.
+LIB_PATH = os.environ.get("D2D_LIB") or os.path.join(CSRC, "libd2d.so")
 
 D2D_MAX_ORDER = 4
 D2D_NUM_STATS = 16
@@ -136,7 +138,8 @@ def build(force: bool = False) -> str:
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "d2d.h"))
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "-s", "libd2d.so"] + (["-B"] if force else []))
+        jobs = str(max(1, min(8, len(os.sched_getaffinity(0)))))  # one object per (kernel family, mode): builds in parallel
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j", jobs, "libd2d.so"] + (["-B"] if force else []))
     return LIB_PATH
 
 

@@ -14,10 +14,54 @@
 #include <vector>
 
 #include "../../include/d2d.h"
-#ifndef D2D_KERNELS_HPP
-#define D2D_KERNELS_HPP "d2d_kernels.hpp"
-#endif
-#include D2D_KERNELS_HPP
+#define D2D_AUX_KERNELS 1  // the non-template kernels are defined in this translation unit
+#include "d2d_launch.hpp"
+
+// ---- mode dispatch of the sweep-kernel launchers (d2d_launch.hpp); the per-mode launchers live in the
+// d2d_sweep_tu objects, one per (kernel family, validity mode) ----
+namespace d2d {
+
+template <int MODE> hipError_t launch_fwd_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <int MODE> hipError_t launch_fwd_grad_m(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <int MODE> hipError_t launch_fwd_split_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <int MODE> hipError_t launch_txg_m(bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <int MODE> hipError_t launch_vg_m(bool txg, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+
+#define D2D_DECLARE_MODE(M)                                                                                   \
+    template <> hipError_t launch_fwd_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);           \
+    template <> hipError_t launch_fwd_grad_m<M>(int, dim3, size_t, hipStream_t, const SweepArgs&);            \
+    template <> hipError_t launch_fwd_split_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);     \
+    template <> hipError_t launch_txg_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);           \
+    template <> hipError_t launch_vg_m<M>(bool, bool, dim3, size_t, hipStream_t, const SweepArgs&);
+D2D_DECLARE_MODE(MODE_HARD)
+D2D_DECLARE_MODE(MODE_HSIG)
+D2D_DECLARE_MODE(MODE_SIG)
+#undef D2D_DECLARE_MODE
+
+#define D2D_BY_MODE(fn, ...)                                   \
+    switch (mode) {                                            \
+        case MODE_HARD: return fn<MODE_HARD>(__VA_ARGS__);     \
+        case MODE_HSIG: return fn<MODE_HSIG>(__VA_ARGS__);     \
+        default: return fn<MODE_SIG>(__VA_ARGS__);             \
+    }
+
+hipError_t launch_fwd(int mode, bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    D2D_BY_MODE(launch_fwd_m, stats, max_order, grid, lds, s, a)
+}
+hipError_t launch_fwd_grad(int mode, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    D2D_BY_MODE(launch_fwd_grad_m, max_order, grid, lds, s, a)
+}
+hipError_t launch_fwd_split(int mode, bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    D2D_BY_MODE(launch_fwd_split_m, stats, max_order, grid, lds, s, a)
+}
+hipError_t launch_txg(int mode, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    D2D_BY_MODE(launch_txg_m, grad, max_order, grid, lds, s, a)
+}
+hipError_t launch_vg(int mode, bool txg, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    D2D_BY_MODE(launch_vg_m, txg, grad, grid, lds, s, a)
+}
+
+}  // namespace d2d
 
 namespace {
 
@@ -132,7 +176,8 @@ struct d2d_ctx {
     DevBuf<float> d_grad, d_cot, d_partial;
     DevBuf<double> d_vjp;
     bool have_cot = false;
-    bool have_vjp = false;
+    bool have_vjp = false;   // d_vjp holds the scene VJP of a sweep of the CURRENT scene (4 N + 2 values)
+    bool have_grad = false;  // d_grad holds the per-cell gradient map of a sweep of the CURRENT grid (2 m n values)
     bool want_wave_cycles = false;
     long long split_max_tiles = 8192;   // launches up to this many patches share every patch between 4 waves
     long long heavy_split = 64;        // bigger launches with a work history: this many of the dearest patches are cut in four
@@ -457,25 +502,34 @@ int d2d_synchronize(d2d_ctx* c) {
 
 int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float* phi, int32_t n_objects) {
     if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
-    c->cost_tiles = 0;  // the patch-cost history describes another sweep
+    // validate everything before touching the context: a rejected call leaves the previous scene in place
     if (n_objects < 0 || (n_objects > 0 && !xys)) return fail(D2D_ERR_INVALID, "bad scene arguments");
-    int rc = set_device(c);
-    if (rc) return rc;
     for (size_t i = 0; i < 4 * (size_t)n_objects; ++i)
         if (!(std::fabs(xys[i]) < 1e18f)) return fail(D2D_ERR_INVALID, "object coordinate %zu is not finite (or >= 1e18)", i);
+    if (kind)
+        for (int j = 0; j < n_objects; ++j)
+            if (kind[j] > D2D_VERTEX) return fail(D2D_ERR_INVALID, "object %d has unknown kind %d", j, (int)kind[j]);
+    if (phi)
+        for (int j = 0; j < n_objects; ++j)
+            if (!std::isfinite(phi[j])) return fail(D2D_ERR_INVALID, "phi[%d] is not finite", j);
+    int rc = set_device(c);
+    if (rc) return rc;
+    // from here on the old scene is gone: a failed upload leaves the context without a scene, never with half of one
+    c->have_scene = false;
+    c->have_vjp = false;          // d_vjp was sized for (and computed from) the previous scene
+    c->have_kernel_time = false;
+    c->cost_tiles = 0;            // the patch-cost history describes another sweep
+    c->pair_valid = false;
+    c->occl_patch = NAN;
     c->N = n_objects;
     c->xys.assign(xys, xys + 4 * (size_t)n_objects);
     c->scene_absmax = 0.0f;
     for (size_t i = 0; i < 4 * (size_t)n_objects; ++i) c->scene_absmax = std::fmax(c->scene_absmax, std::fabs(xys[i]));
     c->kind.assign((size_t)n_objects, (uint8_t)D2D_WALL);
     if (kind) c->kind.assign(kind, kind + n_objects);
-    for (int j = 0; j < n_objects; ++j)
-        if (c->kind[j] > D2D_VERTEX) return fail(D2D_ERR_INVALID, "object %d has unknown kind %d", j, (int)c->kind[j]);
     c->phi.assign((size_t)n_objects, 0.78539816339744830962f);
     if (phi) c->phi.assign(phi, phi + n_objects);
     c->allowed.assign((size_t)n_objects, (uint8_t)1);
-    c->occl_patch = NAN;
-    c->pair_valid = false;
     rc = upload_refl(c);
     if (rc) return rc;
     rc = upload_mask(c);
@@ -588,6 +642,8 @@ int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t 
     c->have_grid = true;
     c->have_cot = false;
     c->have_vjp = false;
+    c->have_grad = false;  // d_grad (if any) was sized for the previous grid
+    c->gathered = 0;
     return D2D_OK;
 }
 
@@ -661,6 +717,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     if (rc) return rc;
     if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come before a sweep");
     if (!c->have_grid) return fail(D2D_ERR_STATE, "d2d_set_grid must come before a sweep");
+    c->have_kernel_time = false;  // whatever this launch turns out to be, the previous launch's kernel time is stale
     if (p->solver == D2D_SOLVER_MINPATH || p->solver == D2D_SOLVER_FERMAT) {
         if (d_stats || grad_mode) return fail(D2D_ERR_UNSUPPORTED, "the optimiser-based solvers have no stats / gradient kernels");
         return opt_sweep_launch(c, p, tx);
@@ -734,7 +791,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     const int tiles_y = (c->m + d2d::TILE_H - 1) / d2d::TILE_H;
     const long long tiles = (long long)tiles_x * tiles_y;
     if (tiles > 0x7fffffffLL) return fail(D2D_ERR_INVALID, "grid too large: %lld tiles", tiles);
-    dim3 grid((unsigned)tiles), block(64);
+    dim3 grid((unsigned)tiles);
     dim3 grid_patches((unsigned)tiles);  // one single-wave workgroup per 8 x 8 patch
     const bool txg = p->grid_role == D2D_GRID_TX;
     // first-segment shadow coverage (RX grids: the fixed end point is the transmitter)
@@ -847,18 +904,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         const size_t lds_t = (size_t)(3 * c->N + 1) * sizeof(float4);
         if (lds_t > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
         a.grad = nullptr; a.cot = nullptr; a.partial = nullptr;
-#define D2D_LAUNCH_TXG(MODE_)                                                                                            \
-    do {                                                                                                                \
-        if (p->max_order <= 2) hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 2>), grid, block, lds_t, c->stream, a); \
-        else if (p->max_order == 3) hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 3>), grid, block, lds_t, c->stream, a); \
-        else hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 4>), grid, block, lds_t, c->stream, a);                \
-    } while (0)
-        switch (mode) {
-            case d2d::MODE_HARD: D2D_LAUNCH_TXG(d2d::MODE_HARD); break;
-            case d2d::MODE_HSIG: D2D_LAUNCH_TXG(d2d::MODE_HSIG); break;
-            default: D2D_LAUNCH_TXG(d2d::MODE_SIG); break;
-        }
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(d2d::launch_txg(mode, false, p->max_order, grid, lds_t, c->stream, a));
         D2D_KERNEL_DONE();
         return D2D_OK;
     }
@@ -866,18 +912,15 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         // TX grid, values only, exhaustive ("txg_exhaustive" option): the per-lane-image code path without the adjoint
         const size_t lds0 = (size_t)(4 * c->N + 4) * sizeof(float);
         a.grad = nullptr; a.cot = nullptr; a.partial = nullptr;
-        switch (mode) {
-            case d2d::MODE_HARD: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_HARD, true, false>), grid, block, lds0, c->stream, a); break;
-            case d2d::MODE_HSIG: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_HSIG, true, false>), grid, block, lds0, c->stream, a); break;
-            default: hipLaunchKernelGGL((d2d::power_vg_kernel<d2d::MODE_SIG, true, false>), grid, block, lds0, c->stream, a); break;
-        }
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(d2d::launch_vg(mode, true, false, grid, lds0, c->stream, a));
         D2D_KERNEL_DONE();
         return D2D_OK;
     }
     if (grad_mode) {
         const size_t cells = (size_t)c->m * c->n;
+        if (p->out_mode == D2D_OUT_ADD && !c->have_grad) return fail(D2D_ERR_STATE, "D2D_OUT_ADD needs a previous value+grad sweep on this grid");
         if ((rc = c->d_grad.ensure(2 * cells))) return rc;
+        c->have_grad = true;
         a.grad = c->d_grad.p;
         a.cot = c->have_cot ? c->d_cot.p : nullptr;
         a.partial = nullptr;
@@ -894,46 +937,15 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4) + 512;  // tables, adjoint table, culling queue
             if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
             a.cullq_off = (int)((size_t)(4 * c->N + 1) * sizeof(float4));
-#define D2D_LAUNCH_FWDG(MODE_)                                                                                              \
-    do {                                                                                                                    \
-        if (p->max_order <= 2) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 2, true>), grid_patches, block, lds2, c->stream, a); \
-        else if (p->max_order == 3) hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 3, true>), grid_patches, block, lds2, c->stream, a); \
-        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, false, 4, true>), grid_patches, block, lds2, c->stream, a);            \
-    } while (0)
-            switch (mode) {
-                case d2d::MODE_HARD: D2D_LAUNCH_FWDG(d2d::MODE_HARD); break;
-                case d2d::MODE_HSIG: D2D_LAUNCH_FWDG(d2d::MODE_HSIG); break;
-                default: D2D_LAUNCH_FWDG(d2d::MODE_SIG); break;
-            }
+            HIP_TRY(d2d::launch_fwd_grad(mode, p->max_order, grid_patches, lds2, c->stream, a));
         } else if (txg_culled) {
             // TX grid, culled value+grad sweep
             const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4);
             if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
-#define D2D_LAUNCH_TXGG(MODE_)                                                                                              \
-    do {                                                                                                                    \
-        if (p->max_order <= 2) hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 2, true>), grid_patches, block, lds2, c->stream, a); \
-        else if (p->max_order == 3) hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 3, true>), grid_patches, block, lds2, c->stream, a); \
-        else hipLaunchKernelGGL((d2d::power_fwd_txg_kernel<MODE_, 4, true>), grid_patches, block, lds2, c->stream, a);            \
-    } while (0)
-            switch (mode) {
-                case d2d::MODE_HARD: D2D_LAUNCH_TXGG(d2d::MODE_HARD); break;
-                case d2d::MODE_HSIG: D2D_LAUNCH_TXGG(d2d::MODE_HSIG); break;
-                default: D2D_LAUNCH_TXGG(d2d::MODE_SIG); break;
-            }
-        } else
-        {
-#define D2D_LAUNCH_VG(MODE_)                                                                                             \
-    do {                                                                                                                \
-        if (txg) hipLaunchKernelGGL((d2d::power_vg_kernel<MODE_, true, true>), grid, block, lds, c->stream, a);         \
-        else hipLaunchKernelGGL((d2d::power_vg_kernel<MODE_, false, true>), grid, block, lds, c->stream, a);            \
-    } while (0)
-        switch (mode) {
-            case d2d::MODE_HARD: D2D_LAUNCH_VG(d2d::MODE_HARD); break;
-            case d2d::MODE_HSIG: D2D_LAUNCH_VG(d2d::MODE_HSIG); break;
-            default: D2D_LAUNCH_VG(d2d::MODE_SIG); break;
+            HIP_TRY(d2d::launch_txg(mode, true, p->max_order, grid_patches, lds2, c->stream, a));
+        } else {
+            HIP_TRY(d2d::launch_vg(mode, txg, true, grid, lds, c->stream, a));
         }
-        }
-        HIP_TRY(hipGetLastError());
         D2D_KERNEL_DONE();
         if (grad_mode == 2) {
             const long rows = (long)tiles;  // one row of partials per patch
@@ -948,7 +960,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     if (tab_lds > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~1300)", c->N);
     // Launches that hold only a few patches per SIMD are bound by their dearest patch: share every patch between
     // D2D_SPLIT_W waves there (power_fwd_split_kernel).  Big grids are throughput-bound: one wave per patch.
-    constexpr int D2D_SPLIT_W = 4;
+    constexpr int D2D_SPLIT_W = d2d::SPLIT_W;
     const size_t split_base = ((tab_lds - 512 + (size_t)(D2D_SPLIT_W - 1) * d2d::SPLIT_LIST * 64 * sizeof(float) +
                                 (size_t)((D2D_SPLIT_W - 1) * 65 + D2D_SPLIT_W + 1) * sizeof(int)) + 15) & ~(size_t)15;
     const size_t split_lds = split_base + (size_t)D2D_SPLIT_W * 512;  // ... + one culling queue per wave
@@ -977,32 +989,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
     }
     a.cullq_off = (int)(split ? split_base : (size_t)(4 * c->N + 1) * sizeof(float4));
-#define D2D_LAUNCH_FWD(MODE_, STATS_, MAXK_)                                                                              \
-    do {                                                                                                                  \
-        if (split) hipLaunchKernelGGL((d2d::power_fwd_split_kernel<MODE_, STATS_, MAXK_, D2D_SPLIT_W>),                   \
-                                      grid_patches, dim3(64 * D2D_SPLIT_W), split_lds, c->stream, a);     \
-        else hipLaunchKernelGGL((d2d::power_fwd_kernel<MODE_, STATS_, MAXK_>), grid_fwd, block, tab_lds, c->stream, a);       \
-    } while (0)
-#define D2D_LAUNCH_FWD_K(MODE_, STATS_)                      \
-    do {                                                     \
-        if (p->max_order <= 2) D2D_LAUNCH_FWD(MODE_, STATS_, 2); \
-        else if (p->max_order == 3) D2D_LAUNCH_FWD(MODE_, STATS_, 3); \
-        else D2D_LAUNCH_FWD(MODE_, STATS_, 4);                \
-    } while (0)
-    if (d_stats) {
-        switch (mode) {
-            case d2d::MODE_HARD: D2D_LAUNCH_FWD_K(d2d::MODE_HARD, true); break;
-            case d2d::MODE_HSIG: D2D_LAUNCH_FWD_K(d2d::MODE_HSIG, true); break;
-            default: D2D_LAUNCH_FWD_K(d2d::MODE_SIG, true); break;
-        }
-    } else {
-        switch (mode) {
-            case d2d::MODE_HARD: D2D_LAUNCH_FWD_K(d2d::MODE_HARD, false); break;
-            case d2d::MODE_HSIG: D2D_LAUNCH_FWD_K(d2d::MODE_HSIG, false); break;
-            default: D2D_LAUNCH_FWD_K(d2d::MODE_SIG, false); break;
-        }
-    }
-    HIP_TRY(hipGetLastError());
+    if (split) HIP_TRY(d2d::launch_fwd_split(mode, d_stats != nullptr, p->max_order, grid_patches, split_lds, c->stream, a));
+    else HIP_TRY(d2d::launch_fwd(mode, d_stats != nullptr, p->max_order, grid_fwd, tab_lds, c->stream, a));
     D2D_KERNEL_DONE();
     return D2D_OK;
 }
@@ -1032,7 +1020,7 @@ int d2d_power_map_vg_launch(d2d_ctx* c, const d2d_params* p, const float* tx, in
 
 int d2d_get_grad_rx(d2d_ctx* c, float* out) {
     if (!c || !out) return fail(D2D_ERR_INVALID, "NULL argument");
-    if (!c->have_grid || !c->d_grad.p) return fail(D2D_ERR_STATE, "no value+grad sweep has run on this grid");
+    if (!c->have_grid || !c->have_grad) return fail(D2D_ERR_STATE, "no value+grad sweep has run on this grid");
     int rc = set_device(c);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->d_grad.p, 2 * (size_t)c->m * c->n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -1284,7 +1272,10 @@ int d2d_power_map(d2d_ctx* c, const d2d_params* p, const float* tx, const float*
 
 int d2d_comm_unique_id(uint8_t* id) {
     if (!id) return fail(D2D_ERR_INVALID, "id is NULL");
-    if (!rccl().ok) return fail(D2D_ERR_COMM, "librccl could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+    if (!rccl().ok) {
+        const char* why = dlerror();  // (a second call would return NULL: dlerror clears its state)
+        return fail(D2D_ERR_COMM, "librccl could not be loaded: %s", why ? why : "missing symbols");
+    }
     ncclUniqueId u;
     RCCL_TRY(rccl().GetUniqueId(&u));
     static_assert(sizeof(u) == D2D_COMM_ID_BYTES, "ncclUniqueId size");
@@ -1337,7 +1328,7 @@ int d2d_comm_allgather_map(d2d_ctx* c, int32_t what) {
     if (!c->comm) return fail(D2D_ERR_STATE, "d2d_comm_init must come first");
     if (!c->have_grid) return fail(D2D_ERR_STATE, "no grid set");
     if (what != 0 && what != 1) return fail(D2D_ERR_INVALID, "what must be 0 (value map) or 1 (grad_rx map)");
-    if (what == 1 && !c->d_grad.p) return fail(D2D_ERR_STATE, "no value+grad sweep has run");
+    if (what == 1 && !c->have_grad) return fail(D2D_ERR_STATE, "no value+grad sweep has run on this grid");
     int rc = set_device(c);
     if (rc) return rc;
     const size_t per_rank = (size_t)c->m * c->n * (what ? 2 : 1);

@@ -1334,8 +1334,6 @@ template <int MODE, bool STATS, int MAXK, bool GRADK = false>
 __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
-    const int tiles_y = (a.m + TILE_H - 1) / TILE_H;
-    const long n_tiles = (long)tiles_x * tiles_y;
     // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index), staged once per wave
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
     for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
@@ -1852,6 +1850,7 @@ constexpr int SCHED_KEYS = 256;  // = blockDim of the two sort passes
 #define D2D_SCHED_PER_THREAD 4
 #endif
 constexpr int SCHED_PER_THREAD = D2D_SCHED_PER_THREAD;  // patches per thread in the two counting-sort passes (16: 4 % slower steps at 1024^2 -- too few blocks)
+#ifdef D2D_AUX_KERNELS  // non-template kernels: defined once, in d2d.hip
 __global__ void __launch_bounds__(256) patch_cost_kernel(SweepArgs a, unsigned char* __restrict__ key) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
@@ -2071,6 +2070,8 @@ __global__ void __launch_bounds__(256) pair_shadow_kernel(const float4* __restri
     if (bits && lane == 0) atomicOr(&pair[(size_t)we * N + wl], bits);
 }
 
+#endif  // D2D_AUX_KERNELS
+
 // Value + gradient sweep: same forward arithmetic as power_fwd_kernel (bit-identical values), plus the
 // hand-derived adjoint of every contributing candidate.  One wave per block; the wave's partial sums of
 // the scene-parameter VJP live in LDS and are written to `partial` (reduced in fixed order afterwards,
@@ -2141,6 +2142,7 @@ __global__ void __launch_bounds__(64) power_vg_kernel(SweepArgs a) {
     }
 }
 
+#ifdef D2D_AUX_KERNELS  // non-template kernels: defined once, in d2d.hip
 // Fixed-order reduction of the per-wave partials: out[e] (+)= sum_w partial[w][e], accumulated in fp64.
 __global__ void __launch_bounds__(256) vjp_reduce_kernel(const float* __restrict__ partial, long n_waves, int n_elem,
                                                          double* __restrict__ out, int accumulate) {
@@ -2156,6 +2158,8 @@ __global__ void __launch_bounds__(256) vjp_reduce_kernel(const float* __restrict
     }
     if (threadIdx.x == 0) out[e] = (accumulate ? out[e] : 0.0) + sm[0];
 }
+
+#endif  // D2D_AUX_KERNELS
 
 }  // namespace d2d
 
@@ -2556,6 +2560,7 @@ struct TraceArgs {
     float alpha, tol, seg_lo, seg_hi;
 };
 
+#ifdef D2D_AUX_KERNELS  // non-template kernels: defined once, in d2d.hip
 // One thread per (tx/rx pair, candidate).  Serves Scene.all_paths / all_valid_paths / accumulate_over_paths
 // (scene.py:1156-1334), {Image,Min,Fermat}Path.from_tx_objects_rx and Path.is_valid / on_objects /
 // intersects_with_objects (geometry.py:821-963) of the host mirror.
@@ -2600,6 +2605,8 @@ __global__ void __launch_bounds__(64) trace_kernel(TraceArgs a) {
     if (a.hit) a.hit[tid] = hit;
     if (a.length) a.length[tid] = r;
 }
+
+#endif  // D2D_AUX_KERNELS
 
 // Grid sweep for the optimiser-based solvers: one RX cell per lane, candidates walked in the reference's order
 // (scene.py:1892-1918); theta0 is per candidate and shared by every cell, as in the reference (scene.py:1887-1890).
@@ -2652,6 +2659,7 @@ __device__ __forceinline__ float opt_contribution(const OptSweepArgs& a, int c, 
     return valid * f;
 }
 
+#ifdef D2D_AUX_KERNELS
 // One cell per lane, the candidates one after the other (any number of candidates).
 __global__ void __launch_bounds__(64) power_opt_kernel(OptSweepArgs a) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2687,5 +2695,7 @@ __global__ void __launch_bounds__(256) opt_reduce_kernel(const float* __restrict
     if (out_mode == D2D_OUT_ADD) out[idx] = out[idx] + acc;
     else out[idx] = acc;
 }
+
+#endif  // D2D_AUX_KERNELS
 
 }  // namespace d2d

@@ -1,0 +1,86 @@
+// One translation unit per (kernel family, validity mode): instantiates the sweep kernels of that pair and defines the
+// per-mode launcher that d2d_launch.cpp's dispatchers call.  Compiled several times by the Makefile with
+//   -DD2D_TU_FAMILY={0 fwd, 1 fwd_grad, 2 fwd_split, 3 txg, 4 vg}  -DD2D_TU_MODE={0 hard, 1 hard_sigmoid, 2 sigmoid}
+#include "d2d_launch.hpp"
+
+#ifndef D2D_TU_FAMILY
+#error "compile with -DD2D_TU_FAMILY=<0..4> -DD2D_TU_MODE=<0..2>"
+#endif
+
+namespace d2d {
+
+constexpr int TU_MODE = D2D_TU_MODE;
+
+#if D2D_TU_FAMILY == 0
+template <int MODE> hipError_t launch_fwd_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <>
+hipError_t launch_fwd_m<TU_MODE>(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    const dim3 block(64);
+    if (stats) {
+        if (max_order <= 2) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, true, 2>), grid, block, lds, s, a);
+        else if (max_order == 3) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, true, 3>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, true, 4>), grid, block, lds, s, a);
+    } else {
+        if (max_order <= 2) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 2>), grid, block, lds, s, a);
+        else if (max_order == 3) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 3>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 4>), grid, block, lds, s, a);
+    }
+    return hipGetLastError();
+}
+#elif D2D_TU_FAMILY == 1
+template <int MODE> hipError_t launch_fwd_grad_m(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <>
+hipError_t launch_fwd_grad_m<TU_MODE>(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    const dim3 block(64);
+    if (max_order <= 2) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 2, true>), grid, block, lds, s, a);
+    else if (max_order == 3) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 3, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 4, true>), grid, block, lds, s, a);
+    return hipGetLastError();
+}
+#elif D2D_TU_FAMILY == 2
+template <int MODE> hipError_t launch_fwd_split_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <>
+hipError_t launch_fwd_split_m<TU_MODE>(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    const dim3 block(64 * SPLIT_W);
+    if (stats) {
+        if (max_order <= 2) hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, true, 2, SPLIT_W>), grid, block, lds, s, a);
+        else if (max_order == 3) hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, true, 3, SPLIT_W>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, true, 4, SPLIT_W>), grid, block, lds, s, a);
+    } else {
+        if (max_order <= 2) hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, false, 2, SPLIT_W>), grid, block, lds, s, a);
+        else if (max_order == 3) hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, false, 3, SPLIT_W>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, false, 4, SPLIT_W>), grid, block, lds, s, a);
+    }
+    return hipGetLastError();
+}
+#elif D2D_TU_FAMILY == 3
+template <int MODE> hipError_t launch_txg_m(bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <>
+hipError_t launch_txg_m<TU_MODE>(bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    const dim3 block(64);
+    if (grad) {
+        if (max_order <= 2) hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 2, true>), grid, block, lds, s, a);
+        else if (max_order == 3) hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 3, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 4, true>), grid, block, lds, s, a);
+    } else {
+        if (max_order <= 2) hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 2>), grid, block, lds, s, a);
+        else if (max_order == 3) hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 3>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 4>), grid, block, lds, s, a);
+    }
+    return hipGetLastError();
+}
+#elif D2D_TU_FAMILY == 4
+template <int MODE> hipError_t launch_vg_m(bool txg, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <>
+hipError_t launch_vg_m<TU_MODE>(bool txg, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    const dim3 block(64);
+    if (txg && grad) hipLaunchKernelGGL((power_vg_kernel<TU_MODE, true, true>), grid, block, lds, s, a);
+    else if (txg) hipLaunchKernelGGL((power_vg_kernel<TU_MODE, true, false>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((power_vg_kernel<TU_MODE, false, true>), grid, block, lds, s, a);  // (RX grid, values only: launch_fwd)
+    return hipGetLastError();
+}
+#else
+#error "unknown D2D_TU_FAMILY"
+#endif
+
+}  // namespace d2d

@@ -307,6 +307,10 @@ class Context:
             loss_in = np.ascontiguousarray(loss_in, dtype=np.float32).reshape(P, Cn)
         th = None
         if theta0 is not None:
+            # the library reads C * max(1, many) rows from this pointer: a shorter array would be a host out-of-bounds read
+            need = Cn * max(1, int(params.many))
+            if params.solver != L.SOLVER_IMAGE and xys_in is None and len(theta0) != need:
+                raise ValueError(f"theta0 must have {need} rows (candidates x max(1, many)), got {len(theta0)}")
             th = np.zeros((max(len(theta0), 1), L.D2D_MAX_ORDER), np.float32)
             for i, row in enumerate(theta0):
                 row = np.asarray(row, np.float32).reshape(-1)

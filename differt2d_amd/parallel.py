@@ -56,6 +56,20 @@ class RowShards:
         idx[len(rows):] = rows[-1] if len(rows) else 0
         return np.ascontiguousarray(A[idx])
 
+    def cotangent_mask(self, rank: int, n_cols: int, cotangent: Optional[np.ndarray] = None) -> np.ndarray:
+        """Cotangent of ``rank``'s padded shard: the rows of ``cotangent`` (``[m, n_cols]``, default ones) it owns and ZERO
+        on the padding rows.  The padding repeats a real row, so without this mask a scene VJP summed over ranks
+        (``d2d_comm_allreduce_vjp``) would count that row once per repetition."""
+        rows = self._rows[rank]
+        out = np.zeros((self.pad_rows, int(n_cols)), np.float32)
+        if len(rows):
+            out[: len(rows)] = 1.0 if cotangent is None else np.asarray(cotangent, np.float32)[rows]
+        return out
+
+    def padded(self, rank: int) -> bool:
+        """Does ``rank``'s shard carry padding rows?"""
+        return len(self._rows[rank]) < self.pad_rows
+
     def assemble(self, gathered: np.ndarray) -> np.ndarray:
         """``gathered[world, pad_rows, ...]`` -> ``[m, ...]`` (drops padding, undoes the interleave)."""
         if gathered.shape[0] != self.world or gathered.shape[1] != self.pad_rows:

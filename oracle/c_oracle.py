@@ -62,6 +62,8 @@ def lib():
         L.orc_num_candidates.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_power_map.restype = C.c_int
         L.orc_power_map.argtypes = [fp, C.c_int, C.c_void_p, C.POINTER(OrcParams), fp, fp, fp, C.c_long, fp, C.c_int]
+        L.orc_power_map_ex.restype = C.c_int
+        L.orc_power_map_ex.argtypes = [fp, C.c_int, C.c_void_p, C.POINTER(OrcParams), fp, fp, fp, C.c_long, fp, fp, C.c_int]
         L.orc_eval_candidates.restype = C.c_int
         L.orc_eval_candidates.argtypes = [fp, C.c_int, C.c_void_p, C.POINTER(OrcParams), fp, fp, fp, fp,
                                           np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]
@@ -106,6 +108,22 @@ def power_map(walls, tx, X, Y, allowed=None, nthreads=0, **kw):
     if rc != 0:
         raise RuntimeError(f"orc_power_map failed: {rc}")
     return out
+
+
+def power_and_count_maps(walls, tx, X, Y, allowed=None, nthreads=0, **kw):
+    """One pass of the C oracle that returns (map of `fun`, map of valid-path counts = the same sweep with fun = 1)."""
+    walls = np.ascontiguousarray(walls, dtype=np.float32).reshape(-1, 2, 2)
+    Xc = np.ascontiguousarray(X, dtype=np.float32)
+    Yc = np.ascontiguousarray(Y, dtype=np.float32)
+    out, cnt = np.empty(Xc.shape, dtype=np.float32), np.empty(Xc.shape, dtype=np.float32)
+    p = make_params(**kw)
+    keep, ptr = _allowed_ptr(allowed)
+    rc = lib().orc_power_map_ex(walls.reshape(-1) if walls.size else np.zeros(1, np.float32), walls.shape[0], ptr,
+                                C.byref(p), np.ascontiguousarray(tx, dtype=np.float32), Xc.reshape(-1), Yc.reshape(-1),
+                                Xc.size, out.reshape(-1), cnt.reshape(-1), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"orc_power_map_ex failed: {rc}")
+    return out, cnt
 
 
 def eval_candidates(walls, tx, rx, allowed=None, **kw):

@@ -264,8 +264,8 @@ long orc_num_candidates(int N, const uint8_t* allowed, int min_order, int max_or
  * Power map for one transmitter.  walls: [N][2][2]; allowed: [N] or NULL (filter_objects);
  * X, Y: [ncell]; out: [ncell].  Returns 0, or <0 on bad arguments.
  */
-int orc_power_map(const float* walls, int N, const uint8_t* allowed, const orc_params* p, const float* tx,
-                  const float* X, const float* Y, long ncell, float* out, int nthreads) {
+int orc_power_map_ex(const float* walls, int N, const uint8_t* allowed, const orc_params* p, const float* tx,
+                     const float* X, const float* Y, long ncell, float* out, float* out_count, int nthreads) {
     if (N < 0 || p->max_order > ORC_MAX_ORDER || p->min_order < 0) return -1;
     wall_t* W = (wall_t*)malloc(sizeof(wall_t) * (N > 0 ? N : 1));
     for (int j = 0; j < N; ++j) make_wall(&W[j], walls + 4 * j, p->patch);
@@ -279,6 +279,7 @@ int orc_power_map(const float* walls, int N, const uint8_t* allowed, const orc_p
 #pragma omp parallel for schedule(dynamic, 64)
     for (long c = 0; c < ncell; ++c) {
         float acc = 0.0f;
+        float cnt = 0.0f; /* the same sweep with fun = 1.0: the map of (soft) valid-path counts */
         for (long ci = 0; ci < total; ++ci) {
             float valid, f;
             if (!p->grid_is_tx) {
@@ -298,12 +299,19 @@ int orc_power_map(const float* walls, int N, const uint8_t* allowed, const orc_p
                 eval_candidate(W, N, C[ci].idx, C[ci].k, img, X[c], Y[c], tx[0], tx[1], p, &valid, &f);
             }
             acc = acc + valid * f;
+            cnt = cnt + valid * 1.0f;
         }
         out[c] = acc;
+        if (out_count) out_count[c] = cnt;
     }
     free(C);
     free(W);
     return 0;
+}
+
+int orc_power_map(const float* walls, int N, const uint8_t* allowed, const orc_params* p, const float* tx,
+                  const float* X, const float* Y, long ncell, float* out, int nthreads) {
+    return orc_power_map_ex(walls, N, allowed, p, tx, X, Y, ncell, out, NULL, nthreads);
 }
 
 /* Per-candidate dump for a single RX (debug / known-answer tests): valid[C], fun[C]. */

@@ -898,3 +898,123 @@ def power_map_value_and_grads(walls, tx, Xg, Yg, cotangent=None, dtype="float32"
         "tx_bar": z(gt, t),
         "walls_bar": z(gw, w),
     }
+
+
+# --------------------------------------------------------------------------------------
+# The same sweep with the candidates of one order evaluated side by side (a leading candidate
+# axis that broadcasts through every function above, exactly as the cells' axis does).  Same op
+# chain per (cell, candidate); only the Python loop over candidates is gone, which makes reverse
+# mode over scenes of 50+ walls tractable (tests/golden/cfg3_grad_*.npz).  tests/test_oracle_batched.py
+# checks it against the candidate-by-candidate functions above.
+# --------------------------------------------------------------------------------------
+
+
+def intersects_with_objects_batched(scene_objs, cands, pts, patch, approx, xp=NUMPY, **kw):
+    """geometry.py:856-906 for a batch of candidates ``cands[Ck, k]``: ``ignore`` is now an array, applied with
+    ``where(ignore, intersects, or(intersects, hit))`` exactly as the reference writes it (:892-904)."""
+    Ck, k = cands.shape
+    idx = np.concatenate([np.full((Ck, 1), -1), cands, np.full((Ck, 1), -1)], axis=1)
+    intersects = false_value(approx, xp)
+    for i in range(k + 1):
+        for j, o in enumerate(scene_objs):
+            ignore = (idx[:, i] == j) | (idx[:, i + 1] == j)
+            if ignore.all():
+                continue  # where(True, intersects, ...) == intersects
+            hit = o.intersects(pts[i], pts[i + 1], patch, approx, xp=xp, **kw)
+            new = logical_or(intersects, hit, approx, xp=xp)
+            if not ignore.any():
+                intersects = new
+            elif xp.name == "torch":
+                intersects = xp.torch.where(xp.torch.as_tensor(ignore[:, None]), intersects, new)
+            else:
+                intersects = np.where(ignore[:, None], intersects, new)  # keeps bool (hard) / float (approx) dtype
+    return intersects
+
+
+def facc_batched(tx, walls, cands_by_order, rx, fun="received_power", fun_kwargs=None, approx=False, xp=NUMPY,
+                 grid_role="rx", sequential_sum=True, **kw):
+    """scene.py:1892-1918 with the candidates of each order side by side.  ``walls``: (N, 2, 2) array / tensor;
+    ``cands_by_order``: list of (k, int array [Ck, k]); ``rx``: (cells, 2) -- the grid cells (receivers, or transmitters
+    with grid_role="tx"); ``tx``: (2,) the fixed end point.  The contributions are added in candidate order (fp32 sum)."""
+    fun_kwargs = fun_kwargs or {}
+    patch = kw.pop("patch", DEFAULT_PATCH)
+    tol = kw.pop("tol", DEFAULT_TOL)
+    f = FUNS[fun] if isinstance(fun, str) else fun
+    N = walls.shape[0]
+    scene_objs = [Obj(WALL, walls[j]) for j in range(N)]
+    acc = xp.c(0.0) * X(rx)
+    for k, cands in cands_by_order:
+        if k == 0:
+            a, b = (tx, rx) if grid_role == "rx" else (rx, tx)
+            valid, val, _, _ = accumulate_candidate(a, scene_objs, cands[0], b, fun, fun_kwargs, "image", approx, xp,
+                                                    patch=patch, tol=tol, **kw)
+            acc = acc + xp.to_float(valid) * val
+            continue
+        inter = [Obj(WALL, walls[cands[:, i]][:, None]) for i in range(k)]  # xys: (Ck, 1, 2, 2)
+        a, b = (tx, rx) if grid_role == "rx" else (rx, tx)
+        pts, loss = image_path(a, inter, b, xp)
+        on = on_objects(inter, pts, approx, xp=xp, **kw)
+        hit = intersects_with_objects_batched(scene_objs, cands, pts, patch, approx, xp=xp, **kw)
+        ok = less(loss, xp.c(tol), approx, xp=xp, **kw)
+        valid = xp.nan_to_num(logical_all([on, logical_not(hit, approx, xp=xp), ok], approx, xp=xp))
+        contrib = xp.to_float(valid) * f(pts, xp=xp, **fun_kwargs)  # (Ck, cells)
+        if sequential_sum:
+            for c in range(contrib.shape[0]):
+                acc = acc + contrib[c]
+        else:
+            acc = acc + contrib.sum(0)
+    return acc
+
+
+def candidates_by_order(num_nodes, min_order=0, max_order=1, order=None, filter_nodes=None):
+    if order is not None:
+        min_order = max_order = order
+    out = []
+    for k in range(min_order, max_order + 1):
+        c = all_path_candidates(num_nodes, k, k, None, filter_nodes)
+        out.append((k, np.stack(c).astype(np.int64).reshape(len(c), k) if c else np.zeros((0, k), np.int64)))
+    return [(k, c) for k, c in out if len(c)]
+
+
+def power_map_batched(walls, tx, Xg, Yg, min_order=0, max_order=1, order=None, filter_nodes=None, xp=NUMPY, **kw):
+    """power_map() through facc_batched: same values bit for bit (fp32 NumPy backend)."""
+    w = xp.asarray(walls)
+    shape = np.shape(Xg)
+    cells = vec(xp.asarray(Xg).reshape(-1), xp.asarray(Yg).reshape(-1), xp)
+    cb = candidates_by_order(w.shape[0], min_order, max_order, order, filter_nodes)
+    return facc_batched(xp.asarray(tx), w, cb, cells, xp=xp, **kw).reshape(shape)
+
+
+def power_map_value_and_grads_batched(walls, tx, Xg, Yg, cotangent=None, dtype="float32", chunk=128, min_order=0,
+                                      max_order=1, order=None, filter_nodes=None, **kwargs):
+    """power_map_value_and_grads() with the candidates side by side and the cells in chunks of ``chunk`` (bounds the
+    autograd tape: ~3750 saved tensors of Ck x chunk elements at 50 walls, order 2).  Same dict of results."""
+    import torch
+
+    tb = TorchBackend(dtype)
+    shape = np.shape(Xg)
+    Xf, Yf = np.asarray(Xg).reshape(-1), np.asarray(Yg).reshape(-1)
+    ct_all = np.ones(Xf.shape, np.float64) if cotangent is None else np.asarray(cotangent, np.float64).reshape(-1)
+    walls = np.asarray(walls)
+    cb = candidates_by_order(walls.shape[0], min_order, max_order, order, filter_nodes)
+    value = np.zeros(Xf.shape, np.float64)
+    grad = np.zeros((*Xf.shape, 2), np.float64)
+    tx_bar = np.zeros(2, np.float64)
+    walls_bar = np.zeros(walls.shape, np.float64)
+    for lo in range(0, Xf.size, chunk):
+        sl = slice(lo, min(lo + chunk, Xf.size))
+        w = tb.asarray(walls).clone().requires_grad_(True)
+        t = tb.asarray(np.asarray(tx)).clone().requires_grad_(True)
+        cells = tb.asarray(np.stack([Xf[sl], Yf[sl]], -1)).clone().requires_grad_(True)
+        Z = facc_batched(t, w, cb, cells, xp=tb, sequential_sum=False, **kwargs)
+        ct = tb.asarray(ct_all[sl])
+        gw, gt = torch.autograd.grad((Z * ct).sum(), [w, t], retain_graph=True, allow_unused=True)
+        (gc,) = torch.autograd.grad(Z.sum(), [cells], allow_unused=True)
+        value[sl] = Z.detach().numpy()
+        if gc is not None:
+            grad[sl] = gc.detach().numpy()
+        if gt is not None:
+            tx_bar += gt.detach().numpy()
+        if gw is not None:
+            walls_bar += gw.detach().numpy()
+    return {"value": value.reshape(shape), "grad_rx": grad.reshape(*shape, 2), "tx_bar": tx_bar, "walls_bar": walls_bar}

@@ -20,16 +20,20 @@ from conftest import random_scene  # noqa: E402
 from oracle import c_oracle  # noqa: E402
 
 F = np.float32
-n_cells = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+n_cells = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 tx, walls = random_scene(200, seed=1234)
 x = np.linspace(0.0, 1.0, 2048).astype(F)
 rng = np.random.default_rng(4)
-# half of the cells near the transmitter (where high-order paths survive), half anywhere
+# an eighth of the cells in the 8 x 8 patches around the transmitter (the patch holding it and its neighbours), three
+# eighths within 60 cells of it (where high-order paths survive), half anywhere
 itx, jtx = int(round(float(tx[1]) * 2047)), int(round(float(tx[0]) * 2047))
-near = np.stack([np.clip(itx + rng.integers(-60, 61, n_cells // 2), 0, 2047),
-                 np.clip(jtx + rng.integers(-60, 61, n_cells // 2), 0, 2047)], 1)
-far = rng.integers(0, 2048, (n_cells - n_cells // 2, 2))
-ij = np.concatenate([near, far]).astype(np.int32)
+n_adj, n_near = n_cells // 8, 3 * n_cells // 8
+adj = np.stack([np.clip(itx + rng.integers(-12, 13, n_adj), 0, 2047),
+                np.clip(jtx + rng.integers(-12, 13, n_adj), 0, 2047)], 1)
+near = np.stack([np.clip(itx + rng.integers(-60, 61, n_near), 0, 2047),
+                 np.clip(jtx + rng.integers(-60, 61, n_near), 0, 2047)], 1)
+far = rng.integers(0, 2048, (n_cells - n_adj - n_near, 2))
+ij = np.concatenate([adj, near, far]).astype(np.int32)
 X, Y = x[ij[:, 1]], x[ij[:, 0]]
 for name, mode in (("hard", dict(approx=False)), ("hsig", dict(approx=True, function="hard_sigmoid"))):
     t = time.time()

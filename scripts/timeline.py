@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Residency timeline of the sweep kernel (needs a -DD2D_AB_TIMELINE build: scripts/ab_run.sh): how many patches are in
+"""Residency timeline of the sweep kernel (needs a -DD2D_AB_TIMELINE build: AB_CMD="python scripts/timeline.py" scripts/ab_build.sh "tl:-DD2D_AB_TIMELINE"): how many patches are in
 flight over the launch, from per-patch start/end stamps of the 100 MHz real-time counter."""
 import os, sys
 import numpy as np

@@ -10,7 +10,7 @@ from oracle import c_oracle as CO
 from oracle import ref as R
 
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-                if not os.path.basename(p).startswith("cfg4_samples"))  # those: test_gpu_forward.py (full-size configs[3])
+                if not os.path.basename(p).startswith("cfg"))  # cfg2_fullmap / cfg3_grad / cfg4_samples: full-size fixtures, own tests
 
 
 def test_fixtures_exist():
@@ -58,3 +58,25 @@ def test_cfg4_sample_fixtures_are_consistent():
         for k in range(3):
             got = c_oracle.power_map(walls, tx, X, Y, min_order=k, max_order=k, prune=True, **kw)
             assert np.array_equal(got, z["per_order"][k][sel])
+
+
+def test_cfg2_fullmap_fixture_rows_recompute():
+    """Full-size configs[1] fixture (scripts/make_golden_fullmap.py: one CRC-32 per row of the oracle's 1024^2 maps):
+    a few rows recomputed here give the same CRCs, for both grid roles and both bit-comparable validity modes."""
+    import zlib
+
+    from conftest import random_scene
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg2_fullmap_crc.npz"))
+    assert int(z["grid"]) == 1024
+    tx, walls = random_scene(50, seed=1234)
+    x = np.linspace(0.0, 1.0, 1024).astype(np.float32)
+    X, Y = np.meshgrid(x, x)
+    rows = [0, 517, 1023]
+    for role in ("rx", "tx"):
+        for mode, kw in (("hard", dict(approx=False)), ("hsig", dict(approx=True, function="hard_sigmoid"))):
+            p, c = CO.power_and_count_maps(walls, tx, X[rows], Y[rows], min_order=0, max_order=2, prune=True, grid_role=role, **kw)
+            for what, a in (("power", p), ("count", c)):
+                crc = z[f"{role}_{mode}_{what}_crc"]
+                assert crc.shape == (1024,) and crc.dtype == np.uint32
+                assert [zlib.crc32(a[i].tobytes()) for i in range(len(rows))] == [int(crc[r]) for r in rows], (role, mode, what)

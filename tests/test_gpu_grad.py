@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 F = np.float32
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-                if not os.path.basename(p).startswith("cfg4_samples"))  # those: test_gpu_forward.py (full-size configs[3])
+                if not os.path.basename(p).startswith("cfg"))  # cfg2_fullmap / cfg3_grad / cfg4_samples: full-size fixtures, own tests
 
 
 @pytest.fixture(scope="module", params=["identity_order", "dearest_first"])
