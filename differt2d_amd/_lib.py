@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("D2D_LIB") or os.path.join(CSRC, "libd2d.so")
 D2D_MAX_ORDER = 4
 D2D_NUM_STATS = 16
 D2D_COMM_ID_BYTES = 128
-D2D_ABI_VERSION = 3
+D2D_ABI_VERSION = 4
 
 D2D_WALL, D2D_RIS, D2D_VERTEX = 0, 1, 2
 SOLVER_IMAGE, SOLVER_MINPATH, SOLVER_FERMAT = 0, 1, 2
@@ -101,7 +101,7 @@ SYMBOLS = [
     ("d2d_set_cotangent", C.c_int, [_ctx, C.c_void_p]),
     ("d2d_power_map_vg_launch", C.c_int, [_ctx, C.POINTER(Params), _f32p, C.c_int32]),
     ("d2d_get_grad_rx", C.c_int, [_ctx, _f32p]),
-    ("d2d_get_scene_vjp", C.c_int, [_ctx, _f32p, C.c_void_p]),
+    ("d2d_get_scene_vjp", C.c_int, [_ctx, _f32p, C.c_void_p, C.c_void_p]),
     ("d2d_power_map_stats", C.c_int, [_ctx, C.POINTER(Params), _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]),
     ("d2d_set_option", C.c_int, [_ctx, C.c_char_p, C.c_int64]),
     ("d2d_debug_set_schedule", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), C.c_int64]),
@@ -115,13 +115,15 @@ SYMBOLS = [
     ("d2d_get_map", C.c_int, [_ctx, _f32p]),
     ("d2d_power_map", C.c_int, [_ctx, C.POINTER(Params), _f32p, _f32p, _f32p, C.c_int32, C.c_int32, _f32p]),
     ("d2d_trace_paths", C.c_int, [_ctx, C.POINTER(Params), _f32p, _f32p, C.c_int32, _i32p, _i32p, C.c_int32,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _f32p, _f32p, _f32p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     ("d2d_set_theta0", C.c_int, [_ctx, C.c_void_p, C.c_int64]),
     ("d2d_comm_unique_id", C.c_int, [C.c_void_p]),
     ("d2d_comm_init", C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32]),
     ("d2d_comm_destroy", C.c_int, [_ctx]),
     ("d2d_comm_allgather_map", C.c_int, [_ctx, C.c_int32]),
-    ("d2d_comm_get_gathered", C.c_int, [_ctx, _f32p, C.c_int64]),
+    ("d2d_comm_gather_map", C.c_int, [_ctx, C.c_int32, C.c_int32]),
+    ("d2d_comm_get_gathered", C.c_int, [_ctx, C.c_int32, _f32p, C.c_int64]),
     ("d2d_comm_allreduce_vjp", C.c_int, [_ctx]),
     ("d2d_comm_allreduce_host", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_int32, C.c_int32]),
     ("d2d_timer_begin", C.c_int, [_ctx]),

@@ -177,6 +177,7 @@ struct d2d_ctx {
     DevBuf<double> d_vjp;
     bool have_cot = false;
     bool have_vjp = false;   // d_vjp holds the scene VJP of a sweep of the CURRENT scene (4 N + 2 values)
+    bool vjp_has_phi = false;  // d_vjp[4N+2 .. 5N+2) holds d/d phi (optimiser-based sweeps); image sweeps: identically 0
     bool have_grad = false;  // d_grad holds the per-cell gradient map of a sweep of the CURRENT grid (2 m n values)
     bool want_wave_cycles = false;
     long long split_max_tiles = 8192;   // launches up to this many patches share every patch between 4 waves
@@ -187,13 +188,15 @@ struct d2d_ctx {
     // RCCL (one communicator per ctx, collectives run on the ctx stream)
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
-    DevBuf<float> d_gather, d_send;
+    DevBuf<float> d_gather[2], d_send[2];  // [0] value map, [1] gradient map: gathered shards / staging copy of the local shard
     // the all-gather of step k runs on its own stream, overlapped with the sweep of step k+1
     hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-    bool gather_inflight = false;
+    // every collective runs on comm_stream behind a "ready" event of the main stream; [0] value-map gather, [1] gradient-map
+    // gather, [2] scene-VJP all-reduce; the main stream waits for ev_done[i] only where it reuses what collective i touches
+    hipEvent_t ev_ready = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};
+    bool inflight[3] = {false, false, false};
     DevBuf<double> d_hostred;
-    size_t gathered = 0;  // floats per rank in d_gather
+    size_t gathered[2] = {0, 0};  // floats per rank in d_gather[what] (0: nothing gathered on this rank)
 };
 
 namespace {
@@ -353,6 +356,10 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok = false;
@@ -372,9 +379,14 @@ Rccl& rccl() {
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+    r.Send = (decltype(r.Send))dlsym(r.h, "ncclSend");
+    r.Recv = (decltype(r.Recv))dlsym(r.h, "ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(r.h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.h, "ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
     r.GetVersion = (decltype(r.GetVersion))dlsym(r.h, "ncclGetVersion");
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.GetErrorString;
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.GetErrorString && r.Send &&
+           r.Recv && r.GroupStart && r.GroupEnd;
     return r;
 }
 
@@ -383,6 +395,37 @@ Rccl& rccl() {
         ncclResult_t r_ = (expr);                                                                          \
         if (r_ != ncclSuccess) return fail(D2D_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString(r_)); \
     } while (0)
+
+}  // namespace
+
+namespace {
+
+// All collectives of a context run on its communication stream, in issue order (one communicator).  The main stream
+// waits for collective `which` ([0] value-map gather, [1] gradient-map gather, [2] scene-VJP all-reduce) only where it is
+// about to reuse the buffers that collective reads or writes.
+int join_comm(d2d_ctx* c, int which) {
+    if (c->inflight[which]) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done[which], 0));
+    return D2D_OK;
+}
+int join_all_comm(d2d_ctx* c) {
+    for (int w = 0; w < 3; ++w)
+        if (int rc = join_comm(c, w)) return rc;
+    return D2D_OK;
+}
+int ensure_comm_stream(d2d_ctx* c) {
+    if (c->comm_stream) return D2D_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    for (int w = 0; w < 3; ++w) HIP_TRY(hipEventCreateWithFlags(&c->ev_done[w], hipEventDisableTiming));
+    return D2D_OK;
+}
+// main stream -> communication stream hand-over: everything enqueued on the main stream so far happens before what is
+// enqueued on the communication stream from now on
+int comm_after_main(d2d_ctx* c) {
+    HIP_TRY(hipEventRecord(c->ev_ready, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
+    return D2D_OK;
+}
 
 }  // namespace
 
@@ -451,8 +494,10 @@ void d2d_destroy(d2d_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
-    c->d_gather.release();
-    c->d_send.release();
+    for (int w = 0; w < 2; ++w) {
+        c->d_gather[w].release();
+        c->d_send[w].release();
+    }
     c->d_hostred.release();
     c->d_occl.release();
     c->d_refl.release();
@@ -480,7 +525,8 @@ void d2d_destroy(d2d_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    for (int w = 0; w < 3; ++w)
+        if (c->ev_done[w]) (void)hipEventDestroy(c->ev_done[w]);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->evk0) (void)hipEventDestroy(c->evk0);
     if (c->evk1) (void)hipEventDestroy(c->evk1);
@@ -493,10 +539,11 @@ int d2d_synchronize(d2d_ctx* c) {
     int rc = set_device(c);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->gather_inflight) {
-        HIP_TRY(hipEventSynchronize(c->ev_done));
-        c->gather_inflight = false;
-    }
+    for (int w = 0; w < 3; ++w)
+        if (c->inflight[w]) {
+            HIP_TRY(hipEventSynchronize(c->ev_done[w]));
+            c->inflight[w] = false;
+        }
     return D2D_OK;
 }
 
@@ -643,7 +690,7 @@ int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t 
     c->have_cot = false;
     c->have_vjp = false;
     c->have_grad = false;  // d_grad (if any) was sized for the previous grid
-    c->gathered = 0;
+    c->gathered[0] = c->gathered[1] = 0;
     return D2D_OK;
 }
 
@@ -927,7 +974,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         const int n_elem = 4 * c->N + 2;
         if (grad_mode == 2) {
             if ((rc = c->d_partial.ensure((size_t)tiles * n_elem))) return rc;
-            if ((rc = c->d_vjp.ensure((size_t)n_elem))) return rc;
+            if ((rc = c->d_vjp.ensure((size_t)n_elem + (size_t)c->N))) return rc;  // [4N] end points, [2] fixed point, [N] phi
             a.partial = c->d_partial.p;
         }
         if (p->out_mode == D2D_OUT_OVERWRITE) c->have_vjp = false;
@@ -949,6 +996,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         D2D_KERNEL_DONE();
         if (grad_mode == 2) {
             const long rows = (long)tiles;  // one row of partials per patch
+            if ((rc = join_comm(c, 2))) return rc;  // the previous step's all-reduce has finished with d_vjp
+            c->vjp_has_phi = false;
             hipLaunchKernelGGL(d2d::vjp_reduce_kernel, dim3((unsigned)n_elem), dim3(256), 0, c->stream, c->d_partial.p,
                                rows, n_elem, c->d_vjp.p, (p->out_mode == D2D_OUT_ADD && c->have_vjp) ? 1 : 0);
             HIP_TRY(hipGetLastError());
@@ -1028,19 +1077,31 @@ int d2d_get_grad_rx(d2d_ctx* c, float* out) {
     return D2D_OK;
 }
 
-int d2d_get_scene_vjp(d2d_ctx* c, float* tx_bar, float* xys_bar) {
+int d2d_get_scene_vjp(d2d_ctx* c, float* tx_bar, float* xys_bar, float* phi_bar) {
     if (!c || !tx_bar) return fail(D2D_ERR_INVALID, "NULL argument");
     if (!c->have_vjp) return fail(D2D_ERR_STATE, "no scene-VJP sweep has run");
     int rc = set_device(c);
     if (rc) return rc;
     const int n_elem = 4 * c->N + 2;
     std::vector<double> h((size_t)n_elem);
+    if ((rc = join_comm(c, 2))) return rc;  // an all-reduce of the VJP in flight lands first
     HIP_TRY(hipMemcpyAsync(h.data(), c->d_vjp.p, (size_t)n_elem * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (xys_bar)
         for (int i = 0; i < 4 * c->N; ++i) xys_bar[i] = (float)h[(size_t)i];
     tx_bar[0] = (float)h[(size_t)4 * c->N];
     tx_bar[1] = (float)h[(size_t)4 * c->N + 1];
+    if (phi_bar) {
+        // ImagePath sweeps interact with Wall objects only (RIS / Vertex objects need MinPath / FermatPath): the map does not
+        // depend on any phi
+        for (int j = 0; j < c->N; ++j) phi_bar[j] = 0.0f;
+        if (c->vjp_has_phi) {
+            std::vector<double> hp((size_t)c->N);
+            HIP_TRY(hipMemcpyAsync(hp.data(), c->d_vjp.p + n_elem, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (int j = 0; j < c->N; ++j) phi_bar[j] = (float)hp[(size_t)j];
+        }
+    }
     return D2D_OK;
 }
 
@@ -1159,14 +1220,17 @@ int d2d_set_theta0(d2d_ctx* c, const float* theta0, int64_t n_rows) {
 }
 
 int d2d_trace_paths(d2d_ctx* c, const d2d_params* p, const float* tx, const float* rx, int32_t P, const int32_t* cand,
-                    const int32_t* order, int32_t C, const float* theta0, const float* xys_in, const float* loss_in, float* xys,
-                    float* loss, float* valid, float* on, float* hit, float* length) {
+                    const int32_t* order, int32_t C, const float* theta0, int64_t theta0_rows, const float* xys_in,
+                    const float* loss_in, float* xys, float* loss, float* valid, float* on, float* hit, float* length) {
     if (!c || !tx || !rx || !cand || !order || !xys || !loss || !valid) return fail(D2D_ERR_INVALID, "NULL argument");
     int rc = check_params(p);
     if (rc) return rc;
     if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
     if (P < 0 || C < 0) return fail(D2D_ERR_INVALID, "negative sizes");
     const bool opt = (p->solver == D2D_SOLVER_MINPATH || p->solver == D2D_SOLVER_FERMAT) && !xys_in;
+    if (opt && theta0 && theta0_rows != (int64_t)C * (p->many > 1 ? p->many : 1))
+        return fail(D2D_ERR_INVALID, "theta0 must hold %lld rows (candidates x max(1, many)), got %lld",
+                    (long long)C * (p->many > 1 ? p->many : 1), (long long)theta0_rows);
     if (p->solver < D2D_SOLVER_IMAGE || p->solver > D2D_SOLVER_FERMAT) return fail(D2D_ERR_INVALID, "unknown solver %d", p->solver);
     for (int i = 0; i < C; ++i) {
         if (order[i] < 0 || order[i] > D2D_MAX_ORDER) return fail(D2D_ERR_INVALID, "candidate %d has order %d", i, order[i]);
@@ -1283,13 +1347,6 @@ int d2d_comm_unique_id(uint8_t* id) {
     return D2D_OK;
 }
 
-// Every later operation on the context's main stream that touches the communicator or the gathered map first waits for
-// the all-gather in flight on the communication stream.
-static int join_gather(d2d_ctx* c) {
-    if (c->gather_inflight) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
-    return D2D_OK;
-}
-
 int d2d_comm_init(d2d_ctx* c, const uint8_t* id, int32_t rank, int32_t world) {
     if (!c || !id) return fail(D2D_ERR_INVALID, "NULL argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(D2D_ERR_INVALID, "bad rank %d of %d", rank, world);
@@ -1314,7 +1371,7 @@ int d2d_comm_destroy(d2d_ctx* c) {
         (void)set_device(c);
         (void)hipStreamSynchronize(c->stream);
         if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
-        c->gather_inflight = false;
+        c->inflight[0] = c->inflight[1] = c->inflight[2] = false;
         rccl().CommDestroy(c->comm);
         c->comm = nullptr;
     }
@@ -1323,44 +1380,68 @@ int d2d_comm_destroy(d2d_ctx* c) {
     return D2D_OK;
 }
 
-int d2d_comm_allgather_map(d2d_ctx* c, int32_t what) {
+// Common part of the two map collectives.  root < 0: all-gather (every rank receives the whole map); root >= 0: gather
+// to that rank only -- what a single-process caller of the reference gets (one assembled array, scene.py:1927-1953):
+// ncclSend from every other rank, world - 1 ncclRecv on the root inside one group, N x fewer bytes on the wire than the
+// all-gather and nothing to receive on the other ranks.
+static int gather_map(d2d_ctx* c, int32_t what, int32_t root) {
     if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
     if (!c->comm) return fail(D2D_ERR_STATE, "d2d_comm_init must come first");
     if (!c->have_grid) return fail(D2D_ERR_STATE, "no grid set");
-    if (what != 0 && what != 1) return fail(D2D_ERR_INVALID, "what must be 0 (value map) or 1 (grad_rx map)");
+    if (what != 0 && what != 1) return fail(D2D_ERR_INVALID, "what must be 0 (value map) or 1 (grad map)");
     if (what == 1 && !c->have_grad) return fail(D2D_ERR_STATE, "no value+grad sweep has run on this grid");
+    if (root >= c->world) return fail(D2D_ERR_INVALID, "root %d is not a rank of this communicator (world %d)", root, c->world);
     int rc = set_device(c);
     if (rc) return rc;
     const size_t per_rank = (size_t)c->m * c->n * (what ? 2 : 1);
-    if ((rc = c->d_gather.ensure(per_rank * (size_t)c->world))) return rc;
-    if ((rc = c->d_send.ensure(per_rank))) return rc;
-    if (!c->comm_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    const bool receives = root < 0 || root == c->rank;
+    DevBuf<float>& gbuf = c->d_gather[what];
+    DevBuf<float>& sbuf = c->d_send[what];
+    if (receives && (rc = gbuf.ensure(per_rank * (size_t)c->world))) return rc;
+    if ((rc = sbuf.ensure(per_rank))) return rc;
+    if ((rc = ensure_comm_stream(c))) return rc;
+    // main stream: (the previous gather of this map has finished reading the staging copy) -> copy this step's shard;
+    // communication stream: -> collective -> done.  The next sweep on the main stream does not wait for `done`.
+    if ((rc = join_comm(c, what))) return rc;
+    HIP_TRY(hipMemcpyAsync(sbuf.p, what ? c->d_grad.p : c->d_out.p, per_rank * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = comm_after_main(c))) return rc;
+    if (root < 0) {
+        RCCL_TRY(rccl().AllGather(sbuf.p, gbuf.p, per_rank, ncclFloat32, c->comm, c->comm_stream));
+    } else if (root == c->rank) {
+        RCCL_TRY(rccl().GroupStart());
+        for (int r = 0; r < c->world; ++r)
+            if (r != root) RCCL_TRY(rccl().Recv(gbuf.p + (size_t)r * per_rank, per_rank, ncclFloat32, r, c->comm, c->comm_stream));
+        RCCL_TRY(rccl().GroupEnd());
+        HIP_TRY(hipMemcpyAsync(gbuf.p + (size_t)root * per_rank, sbuf.p, per_rank * sizeof(float), hipMemcpyDeviceToDevice, c->comm_stream));
+    } else {
+        RCCL_TRY(rccl().Send(sbuf.p, per_rank, ncclFloat32, root, c->comm, c->comm_stream));
     }
-    // main stream: (previous gather has finished reading the staging copy) -> copy this step's shard -> ready;
-    // communication stream: ready -> all-gather -> done.  The next sweep does not wait for `done`.
-    if ((rc = join_gather(c))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->d_send.p, what ? c->d_grad.p : c->d_out.p, per_rank * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->ev_ready, c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
-    RCCL_TRY(rccl().AllGather(c->d_send.p, c->d_gather.p, per_rank, ncclFloat32, c->comm, c->comm_stream));
-    HIP_TRY(hipEventRecord(c->ev_done, c->comm_stream));
-    c->gather_inflight = true;
-    c->gathered = per_rank;
+    HIP_TRY(hipEventRecord(c->ev_done[what], c->comm_stream));
+    c->inflight[what] = true;
+    c->gathered[what] = receives ? per_rank : 0;
     return D2D_OK;
 }
 
-int d2d_comm_get_gathered(d2d_ctx* c, float* out, int64_t capacity) {
+int d2d_comm_allgather_map(d2d_ctx* c, int32_t what) { return gather_map(c, what, -1); }
+
+int d2d_comm_gather_map(d2d_ctx* c, int32_t what, int32_t root) {
+    if (root < 0) return fail(D2D_ERR_INVALID, "root must be a rank (>= 0)");
+    return gather_map(c, what, root);
+}
+
+int d2d_comm_get_gathered(d2d_ctx* c, int32_t what, float* out, int64_t capacity) {
     if (!c || !out) return fail(D2D_ERR_INVALID, "NULL argument");
-    if (!c->gathered) return fail(D2D_ERR_STATE, "nothing has been gathered");
-    if (capacity != (int64_t)(c->gathered * (size_t)c->world))
-        return fail(D2D_ERR_INVALID, "the last all-gather holds %lld floats (%d ranks), the buffer %lld", (long long)(c->gathered * (size_t)c->world), c->world, (long long)capacity);
+    if (what != 0 && what != 1) return fail(D2D_ERR_INVALID, "what must be 0 (value map) or 1 (grad map)");
+    if (!c->gathered[what])
+        return fail(D2D_ERR_STATE, "no %s map has been gathered on this rank (after d2d_comm_gather_map only the root holds it)",
+                    what ? "gradient" : "value");
+    const size_t total = c->gathered[what] * (size_t)c->world;
+    if (capacity != (int64_t)total)
+        return fail(D2D_ERR_INVALID, "the gathered map holds %lld floats (%d ranks), the buffer %lld", (long long)total, c->world, (long long)capacity);
     int rc = set_device(c);
     if (rc) return rc;
-    if ((rc = join_gather(c))) return rc;
-    HIP_TRY(hipMemcpyAsync(out, c->d_gather.p, c->gathered * (size_t)c->world * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = join_comm(c, what))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->d_gather[what].p, total * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return D2D_OK;
 }
@@ -1371,8 +1452,14 @@ int d2d_comm_allreduce_vjp(d2d_ctx* c) {
     if (!c->have_vjp) return fail(D2D_ERR_STATE, "no scene-VJP sweep has run");
     int rc = set_device(c);
     if (rc) return rc;
-    if ((rc = join_gather(c))) return rc;  // collectives of one communicator execute in issue order
-    RCCL_TRY(rccl().AllReduce(c->d_vjp.p, c->d_vjp.p, (size_t)(4 * c->N + 2), ncclFloat64, ncclSum, c->comm, c->stream));
+    if ((rc = ensure_comm_stream(c))) return rc;
+    // on the communication stream like the gathers (collectives of one communicator execute in issue order), behind the
+    // reduction kernel that produced d_vjp; d2d_get_scene_vjp and the next sweep's reduction wait for it
+    if ((rc = comm_after_main(c))) return rc;
+    const size_t n = (size_t)(4 * c->N + 2) + (c->vjp_has_phi ? (size_t)c->N : 0);
+    RCCL_TRY(rccl().AllReduce(c->d_vjp.p, c->d_vjp.p, n, ncclFloat64, ncclSum, c->comm, c->comm_stream));
+    HIP_TRY(hipEventRecord(c->ev_done[2], c->comm_stream));
+    c->inflight[2] = true;
     return D2D_OK;
 }
 
@@ -1384,7 +1471,7 @@ int d2d_comm_allreduce_host(d2d_ctx* c, double* values, int32_t n, int32_t op) {
     int rc = set_device(c);
     if (rc) return rc;
     if ((rc = c->d_hostred.ensure((size_t)n))) return rc;
-    if ((rc = join_gather(c))) return rc;
+    if ((rc = join_all_comm(c))) return rc;  // this one runs on the main stream: behind every collective in flight
     HIP_TRY(hipMemcpyAsync(c->d_hostred.p, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     RCCL_TRY(rccl().AllReduce(c->d_hostred.p, c->d_hostred.p, (size_t)n, ncclFloat64, op ? ncclMax : ncclSum, c->comm, c->stream));
     HIP_TRY(hipMemcpyAsync(values, c->d_hostred.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1414,7 +1501,7 @@ int d2d_timer_end(d2d_ctx* c, float* ms) {
     if (!c || !ms) return fail(D2D_ERR_INVALID, "NULL argument");
     int rc = set_device(c);
     if (rc) return rc;
-    if ((rc = join_gather(c))) return rc;  // the timed region ends when the last all-gather has landed
+    if ((rc = join_all_comm(c))) return rc;  // the timed region ends when the last collective has landed
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));

@@ -180,11 +180,15 @@ class Context:
         L.check(self._lib.d2d_get_grad_rx(self._ctx, out.reshape(-1)))
         return out
 
-    def get_scene_vjp(self):
-        """Returns (tx_bar[2], xys_bar[N,2,2])."""
+    def get_scene_vjp(self, with_phi: bool = False):
+        """Returns (tx_bar[2], xys_bar[N,2,2]) -- and phi_bar[N] (RIS angles) with ``with_phi``."""
         tx_bar = np.zeros(2, np.float32)
         xys_bar = np.zeros((max(self.n_objects, 1), 2, 2), np.float32)
-        L.check(self._lib.d2d_get_scene_vjp(self._ctx, tx_bar, xys_bar.ctypes.data_as(C.c_void_p)))
+        phi_bar = np.zeros(max(self.n_objects, 1), np.float32)
+        L.check(self._lib.d2d_get_scene_vjp(self._ctx, tx_bar, xys_bar.ctypes.data_as(C.c_void_p),
+                                            phi_bar.ctypes.data_as(C.c_void_p) if with_phi else None))
+        if with_phi:
+            return tx_bar, xys_bar[: self.n_objects], phi_bar[: self.n_objects]
         return tx_bar, xys_bar[: self.n_objects]
 
     def value_and_grads(self, tx, X, Y, cotangent=None, **kw):
@@ -317,7 +321,8 @@ class Context:
                 th[i, : row.size] = row
         L.check(
             self._lib.d2d_trace_paths(
-                self._ctx, C.byref(params), tx, rx, P, cand, order, Cn, vp(th), vp(xys_in), vp(loss_in),
+                self._ctx, C.byref(params), tx, rx, P, cand, order, Cn, vp(th), 0 if theta0 is None else len(theta0),
+                vp(xys_in), vp(loss_in),
                 out["xys"].reshape(-1), out["loss"].reshape(-1), out["valid"].reshape(-1),
                 vp(out["on"]), vp(out["hit"]), vp(out["length"]),
             )
@@ -345,10 +350,14 @@ class Context:
     def comm_allgather_map(self, grad: bool = False):
         L.check(self._lib.d2d_comm_allgather_map(self._ctx, 1 if grad else 0))
 
+    def comm_gather_map(self, root: int = 0, grad: bool = False):
+        """Gathers the resident map to ``root`` only (ncclSend / ncclRecv): only ``root`` may fetch it afterwards."""
+        L.check(self._lib.d2d_comm_gather_map(self._ctx, 1 if grad else 0, int(root)))
+
     def comm_get_gathered(self, world: int, grad: bool = False) -> np.ndarray:
         shape = (world, *self.shape, 2) if grad else (world, *self.shape)
         out = np.empty(shape, np.float32)
-        L.check(self._lib.d2d_comm_get_gathered(self._ctx, out.reshape(-1), out.size))
+        L.check(self._lib.d2d_comm_get_gathered(self._ctx, 1 if grad else 0, out.reshape(-1), out.size))
         return out
 
     def comm_allreduce_vjp(self):

@@ -1,5 +1,6 @@
 """
-Multi-GPU sweep: one process per GPU, RX rows sharded over ranks, maps assembled with ONE all-gather.
+Multi-GPU sweep: one process per GPU, RX rows sharded over ranks, maps assembled with ONE all-gather (or one gather to
+a root rank) per map and the scene VJP with one all-reduce.
 
 The reference has no multi-device code (its only batching is ``jax.vmap`` over the grid,
 scene.py:1927-1932).  Every RX cell is independent, so the partition needs no data-path exchange other
@@ -192,6 +193,13 @@ class GlooHostComm:
         self.dist.all_gather(outs, t)
         return np.stack([o.numpy() for o in outs])
 
+    def gather(self, local: np.ndarray, root: int = 0) -> Optional[np.ndarray]:
+        """``[world, ...]`` on ``root``, ``None`` elsewhere."""
+        t = self.torch.from_numpy(np.ascontiguousarray(local))
+        outs = [self.torch.empty_like(t) for _ in range(self.world)] if self.rank == root else None
+        self.dist.gather(t, outs, dst=root)
+        return np.stack([o.numpy() for o in outs]) if self.rank == root else None
+
     def allreduce_sum(self, local: np.ndarray) -> np.ndarray:
         t = self.torch.from_numpy(np.array(local, dtype=np.float64))
         self.dist.all_reduce(t)
@@ -213,31 +221,75 @@ def sharded_map(X: np.ndarray, Y: np.ndarray, compute_shard: Callable[[np.ndarra
 class ShardedSweep:
     """Resident multi-GPU power-map sweep on top of one :class:`~differt2d_amd.engine.Context` per rank.
 
-    ``setup`` uploads this rank's row shard once; ``step`` = fused kernel + RCCL all-gather, both
-    asynchronous on the context's stream; ``result`` downloads and assembles the full map."""
+    ``setup`` uploads this rank's row shard (and its cotangent, zero on padding rows) once; ``step`` = fused kernel +
+    collectives, all asynchronous: the value map (and, with ``grad``, the per-cell gradient map) is gathered either to
+    every rank (``gather="all"``, one ``ncclAllGather`` per map) or to ``root`` only (``gather="root"``,
+    ``ncclSend``/``ncclRecv`` -- what the reference's single-process result needs, scene.py:1927-1953), and the scene
+    VJP is summed over ranks with one ``ncclAllReduce`` in the same step; ``result`` / ``grad_result`` download and
+    assemble the full maps on the ranks that hold them (``None`` elsewhere), ``scene_vjp`` returns the reduced VJP.
+
+    ``ctx`` is duck-typed (the CPU tests drive this class with an oracle-backed stand-in over gloo)."""
 
     def __init__(self, ctx, rank: int, world: int, unique_id: Optional[bytes] = None):
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         if unique_id is not None:
             ctx.comm_init(unique_id, rank, world)
         self.shards = None
+        self._gathered = None  # (mode, root, grad) of the last step
 
-    def setup(self, walls, X, Y, kind=None, phi=None):
+    def setup(self, walls, X, Y, kind=None, phi=None, cotangent=None):
         self.shards = RowShards(X.shape[0], self.world)
         self.ctx.set_scene(walls, kind, phi)
         self.ctx.set_grid(self.shards.take(X, self.rank), self.shards.take(Y, self.rank))
+        if self.world > 1 or cotangent is not None:
+            # padding rows repeat a real row: their cotangent is zero, or the all-reduced VJP would count that row twice
+            self.ctx.set_cotangent(self.shards.cotangent_mask(self.rank, X.shape[1], cotangent))
 
-    def step(self, params, tx, grad: bool = False, gather: bool = True):
-        if grad:
-            self.ctx.launch_vg(params, tx, scene_vjp=False)
+    def step(self, params, tx, grad: bool = False, scene_vjp: bool = False, gather: Optional[str] = "all", root: int = 0):
+        if gather not in (None, "all", "root"):
+            raise ValueError("gather must be None, 'all' or 'root'")
+        if grad or scene_vjp:
+            self.ctx.launch_vg(params, tx, scene_vjp=scene_vjp)
         else:
             self.ctx.launch(params, tx)
-        if gather and self.world > 1:
-            self.ctx.comm_allgather_map(grad=False)
-            if grad:
-                raise NotImplementedError("gather of the gradient map: call comm_allgather_map(grad=True) after fetching the value map")
+        self._gathered = None
+        if self.world > 1:
+            for g in ([False, True] if grad else [False]):
+                if gather == "all":
+                    self.ctx.comm_allgather_map(grad=g)
+                elif gather == "root":
+                    self.ctx.comm_gather_map(root=root, grad=g)
+            if scene_vjp:
+                self.ctx.comm_allreduce_vjp()
+            if gather:
+                self._gathered = (gather, int(root), bool(grad))
 
-    def result(self) -> np.ndarray:
+    def _holds_result(self) -> bool:
+        if self.world == 1:
+            return True
+        if self._gathered is None:
+            raise RuntimeError("the last step gathered nothing: call step(..., gather='all' or 'root')")
+        mode, root, _ = self._gathered
+        return mode == "all" or root == self.rank
+
+    def result(self) -> Optional[np.ndarray]:
+        """The assembled value map ``[m, n]`` on the ranks that hold it, ``None`` on the others."""
         if self.world == 1:
             return self.shards.assemble(self.ctx.get_map()[None])
+        if not self._holds_result():
+            return None
         return self.shards.assemble(self.ctx.comm_get_gathered(self.world))
+
+    def grad_result(self) -> Optional[np.ndarray]:
+        """The assembled per-cell gradient map ``[m, n, 2]`` (a step with ``grad=True``)."""
+        if self.world == 1:
+            return self.shards.assemble(self.ctx.get_grad_rx()[None])
+        if not self._holds_result():
+            return None
+        if not self._gathered[2]:
+            raise RuntimeError("the last step did not gather the gradient map: call step(..., grad=True)")
+        return self.shards.assemble(self.ctx.comm_get_gathered(self.world, grad=True))
+
+    def scene_vjp(self):
+        """(tx_bar, xys_bar) summed over all ranks' cells (a step with ``scene_vjp=True``)."""
+        return self.ctx.get_scene_vjp()

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define D2D_MAX_ORDER 4 /* highest interaction order a sweep accepts */
-#define D2D_ABI_VERSION 3
+#define D2D_ABI_VERSION 4
 
 typedef enum d2d_status {
     D2D_OK = 0,
@@ -174,8 +174,10 @@ int d2d_power_map_vg_launch(d2d_ctx* ctx, const d2d_params* params, const float*
 /* Synchronises and copies the per-cell gradient map to out[m*n*2] (last axis d/dx, d/dy). */
 int d2d_get_grad_rx(d2d_ctx* ctx, float* out);
 
-/* Synchronises and copies the scene-parameter VJP: tx_bar[2] and xys_bar[N][2][2] (may be NULL). */
-int d2d_get_scene_vjp(d2d_ctx* ctx, float* tx_bar, float* xys_bar);
+/* Synchronises and copies the scene-parameter VJP: tx_bar[2] (the fixed end point), xys_bar[N][2][2] (object end points;
+ * may be NULL) and phi_bar[N] (RIS angles, differt2d/geometry.py:683-721; may be NULL; identically 0 after an ImagePath
+ * sweep, whose candidates hold Wall objects only). */
+int d2d_get_scene_vjp(d2d_ctx* ctx, float* tx_bar, float* xys_bar, float* phi_bar);
 
 /* Same sweep through the instrumented build of the kernel (same results, not for timing): fills
  * stats[D2D_NUM_STATS] with executed-work counters summed over waves (one count = one 64-lane wave):
@@ -247,10 +249,12 @@ int d2d_power_map(d2d_ctx* ctx, const d2d_params* params, const float* tx, const
  * loss, valid (is_valid after nan_to_num; 0/1 in hard mode), and optionally on (on_objects),
  * hit (intersects_with_objects) and length (path_length). theta0[C * max(1, many)][D2D_MAX_ORDER] = initial parametric
  * coordinates of the optimiser-based solvers (MinPath geometry.py:1207-1288, FermatPath :1117-1204; the reference
- * draws them from a per-candidate PRNG key shared by all pairs, scene.py:1887-1890); NULL for ImagePath. Synchronous. */
+ * draws them from a per-candidate PRNG key shared by all pairs, scene.py:1887-1890), theta0_rows = the number of rows the
+ * caller provides (checked against C * max(1, many)); NULL / 0 for ImagePath. Synchronous. */
 int d2d_trace_paths(d2d_ctx* ctx, const d2d_params* params, const float* tx, const float* rx, int32_t P,
-                    const int32_t* cand, const int32_t* order, int32_t C, const float* theta0, const float* xys_in,
-                    const float* loss_in, float* xys, float* loss, float* valid, float* on, float* hit, float* length);
+                    const int32_t* cand, const int32_t* order, int32_t C, const float* theta0, int64_t theta0_rows,
+                    const float* xys_in, const float* loss_in, float* xys, float* loss, float* valid, float* on, float* hit,
+                    float* length);
 
 /* ---- multi-GPU (one process per GPU; the reference has no multi-device code: its only batching is jax.vmap
  *      over the grid, differt2d/scene.py:1927-1932; RX rows are sharded over ranks and maps are assembled with one
@@ -265,12 +269,19 @@ int d2d_comm_destroy(d2d_ctx* ctx);
 /* Collective, asynchronous: all-gathers this rank's resident map (what = 0: value map, m*n floats; what = 1:
  * grad_rx map, m*n*2 floats; every rank must hold the same m, n) into a resident buffer [world][...]. The map is
  * first copied aside on the ctx stream and the all-gather runs on a second stream behind that copy, so the NEXT sweep
- * on this ctx overlaps with it; d2d_synchronize, d2d_timer_end, d2d_comm_get_gathered and the other collectives wait
- * for the all-gather in flight. */
+ * on this ctx overlaps with it; d2d_synchronize, d2d_timer_end, d2d_comm_get_gathered and d2d_comm_allreduce_host wait
+ * for the collectives in flight. */
 int d2d_comm_allgather_map(d2d_ctx* ctx, int32_t what);
-/* Synchronises and copies the gathered buffer to out[world * per_rank]; capacity (in floats) must be exactly that. */
-int d2d_comm_get_gathered(d2d_ctx* ctx, float* out, int64_t capacity);
-/* Collective, asynchronous: sums the resident scene VJP (fp64, 4N+2 values) over ranks in place. */
+/* Collective, asynchronous: the same maps gathered to ONE rank -- what the reference's single-process caller receives
+ * (one assembled m x n (x 2) array, differt2d/scene.py:1927-1953): ncclSend from every other rank, world - 1 ncclRecv on
+ * `root` (xGMI is point to point: 7 direct links into the root, 1/world of the all-gather's bytes per GPU).  Same staging
+ * copy, second stream and overlap as the all-gather; only `root` may call d2d_comm_get_gathered afterwards. */
+int d2d_comm_gather_map(d2d_ctx* ctx, int32_t what, int32_t root);
+/* Synchronises and copies the gathered map (what = 0 / 1 as above; the two are kept in separate buffers, so a step may
+ * gather both) to out[world * per_rank]; capacity (in floats) must be exactly that. */
+int d2d_comm_get_gathered(d2d_ctx* ctx, int32_t what, float* out, int64_t capacity);
+/* Collective, asynchronous: sums the resident scene VJP (fp64, 4N+2 values, + N for phi) over ranks in place, on the
+ * communication stream behind the reduction that produced it; d2d_get_scene_vjp waits for it. */
 int d2d_comm_allreduce_vjp(d2d_ctx* ctx);
 
 /* Collective, synchronous: all-reduces n host doubles over ranks through the GPUs (op 0 = sum, 1 = max).

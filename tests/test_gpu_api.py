@@ -343,3 +343,56 @@ def test_schedule_diagnostics_roundtrip():
         ctx.debug_set_schedule(None)
         ctx.launch(p, tx)
         assert np.array_equal(ctx.get_map(), ref)
+
+
+def test_resident_results_are_invalidated_with_what_they_were_computed_for():
+    """include/d2d.h promises D2D_ERR_STATE, not stale or out-of-bounds reads: the per-cell gradient map belongs to the
+    grid it was swept on, the scene VJP to the scene; a rejected d2d_set_scene leaves the previous scene in place."""
+    from conftest import random_scene, unit_grid
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import Context, make_params
+
+    tx, walls = random_scene(6, seed=2)
+    X, Y = unit_grid(16, 8)
+    with Context(0) as ctx:
+        ctx.set_scene(walls)
+        ctx.set_grid(X, Y)
+        p = make_params(max_order=2, approx=True)
+        ctx.launch_vg(p, tx, scene_vjp=True)
+        assert ctx.get_grad_rx().shape == (8, 16, 2)
+        X2, Y2 = unit_grid(64, 64)
+        ctx.set_grid(X2, Y2)  # 32x the cells: the old gradient buffer must not be read as if it covered them
+        with pytest.raises(L.D2DError, match="D2D_ERR_STATE"):
+            ctx.get_grad_rx()
+        with pytest.raises(L.D2DError, match="D2D_ERR_STATE"):  # accumulate into a gradient map that does not exist
+            ctx.launch_vg(make_params(max_order=2, approx=True, out_mode=L.OUT_ADD), tx)
+        ctx.launch_vg(p, tx, scene_vjp=True)
+        ref_map = ctx.get_map()
+        _, wb = ctx.get_scene_vjp()
+        assert wb.shape == (6, 2, 2)
+        # a rejected scene (unknown kind) changes nothing: same map afterwards
+        tx2, walls2 = random_scene(40, seed=3)
+        with pytest.raises(L.D2DError, match="D2D_ERR_INVALID"):
+            ctx.set_scene(walls2, kind=np.full(40, 7, np.uint8))
+        ctx.launch(p, tx)
+        assert np.array_equal(ctx.get_map(), ref_map)
+        # a new, larger scene: the VJP of the old one (4 * 6 + 2 values) must not be handed out as 4 * 40 + 2
+        ctx.set_scene(walls2)
+        with pytest.raises(L.D2DError, match="D2D_ERR_STATE"):
+            ctx.get_scene_vjp()
+        tb, wb, pb = (ctx.launch_vg(p, tx, scene_vjp=True), ctx.get_scene_vjp(with_phi=True))[1]
+        assert wb.shape == (40, 2, 2) and pb.shape == (40,) and not pb.any()  # ImagePath sweeps do not depend on phi
+
+
+def test_trace_paths_checks_the_number_of_theta0_rows():
+    from differt2d_amd.engine import Context, make_params
+    from oracle import ref as R
+
+    with Context(0) as ctx:
+        ctx.set_scene(R.square_scene_walls())
+        cands = [np.array([0], np.int32), np.array([1], np.int32), np.array([2], np.int32)]
+        p = make_params(order=1, solver="min", steps=10)
+        with pytest.raises(ValueError, match="theta0 must have 3 rows"):
+            ctx.trace_paths(p, [[0.2, 0.2]], [[0.8, 0.6]], cands, theta0=[[0.5], [0.5]])
+        out = ctx.trace_paths(p, [[0.2, 0.2]], [[0.8, 0.6]], cands, theta0=[[0.5], [0.5], [0.5]])
+        assert out["xys"].shape[:2] == (1, 3)

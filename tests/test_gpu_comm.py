@@ -69,8 +69,34 @@ def _roundtrip():
             ctx.launch(p, t)
             ctx.comm_allgather_map()
         ctx.synchronize()
-        with pytest.raises(Exception):            # a buffer of the wrong size is refused, not overrun
-            ctx.comm_get_gathered(1, grad=True)
         assert np.array_equal(ctx.comm_get_gathered(1)[0], maps[-1])
+        # the value and the gradient map are gathered into separate buffers: the gradient gathered earlier is still there
+        assert np.array_equal(ctx.comm_get_gathered(1, grad=True)[0], g[0])
+        with pytest.raises(Exception):            # a buffer of the wrong size is refused, not overrun
+            ctx._lib.d2d_comm_get_gathered  # noqa: B018
+            bad = np.empty(7, np.float32)
+            from differt2d_amd import _lib as L
+            L.check(ctx._lib.d2d_comm_get_gathered(ctx._ctx, 0, bad, bad.size))
+        # one step through ShardedSweep: value + gradient gathered to the root, scene VJP all-reduced, all asynchronous
+        sweep.step(p, tx, grad=True, scene_vjp=True, gather="root", root=0)
+        Z, G = sweep.result(), sweep.grad_result()
+        tb, wb = sweep.scene_vjp()
+        ref = ctx.value_and_grads(tx, X, Y, max_order=2, approx=True)
+        assert np.array_equal(Z, ref["value"]) and np.array_equal(G, ref["grad_rx"], equal_nan=True)
+        assert np.array_equal(tb, ref["tx_bar"]) and np.array_equal(wb, ref["walls_bar"])
+        ctx.comm_gather_map(root=0)               # the ncclSend / ncclRecv path itself, at world size 1: a local copy
+        ctx.comm_gather_map(root=0, grad=True)
+        assert np.array_equal(ctx.comm_get_gathered(1)[0], ref["value"])
+        assert np.array_equal(ctx.comm_get_gathered(1, grad=True)[0], ref["grad_rx"], equal_nan=True)
+        with pytest.raises(Exception):            # gather to a rank that does not exist
+            ctx.comm_gather_map(root=1)
+        # a new grid invalidates what was gathered for the old one (and the gradient map itself)
+        ctx.set_grid(X[:8], Y[:8])
+        with pytest.raises(Exception):
+            ctx.comm_get_gathered(1)
+        with pytest.raises(Exception):
+            ctx.comm_allgather_map(grad=True)
+        with pytest.raises(Exception):
+            ctx.get_grad_rx()
         assert ctx.comm_allreduce_host([3.0], "max")[0] == 3.0
         ctx.comm_destroy()

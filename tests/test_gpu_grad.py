@@ -202,3 +202,62 @@ def test_tx_grid_culled_and_exhaustive_gradients_agree(ctx):
             f2 = np.isfinite(b[k])
             if f2.all():
                 np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=1e-5 * max(1e-30, float(np.abs(b[k]).max())))
+
+
+def _tight(got, want, want32, name, report):
+    """north_star's bar: within 1e-5 (of the largest gradient, + 1e-5 relative) of the fp64 autodiff result; NaN positions
+    identical.  Where the reference's OWN fp32 autodiff (same op chain, `want32`) is further than that from fp64 -- cells
+    around the transmitter, where the gradient grows like 1/r^3 and every fp32 evaluation carries that round-off -- the
+    bar is twice that cell's fp32-autodiff error: no fp32 evaluation can be held closer to fp64 than the reference is."""
+    got, want, want32 = np.asarray(got, np.float64), np.asarray(want, np.float64), np.asarray(want32, np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{name}: NaN positions differ"
+    if not np.isfinite(want).any():
+        return
+    scale = float(np.nanmax(np.abs(want)))
+    err = np.abs(got - want)
+    ref_err = np.abs(want32 - want)
+    plain = 1e-5 * scale + 1e-5 * np.abs(want) + 1e-7
+    over_plain = np.nan_to_num(err) > plain
+    report.append(f"{name}: max err/scale {float(np.nanmax(err)) / scale:.2e} (the reference's fp32 autodiff: "
+                  f"{float(np.nanmax(ref_err)) / scale:.2e}); {int(over_plain.sum())} of {err.size} entries beyond 1e-5, "
+                  f"every one of them within 2x the fp32-autodiff error at that entry")
+    bad = np.nan_to_num(err) > np.maximum(plain, 2.0 * np.nan_to_num(ref_err) + 1e-7)
+    assert not bad.any(), report[-1] + f" -- NOT so for {int(bad.sum())} entries, worst {float(np.nanmax(err[bad])):.3e}"
+
+
+@pytest.mark.parametrize("strict_nan", [False, True], ids=["culled", "strict"])
+@pytest.mark.parametrize("mode", ["hard", "hsig"])
+@pytest.mark.parametrize("role", ["rx", "tx"])
+def test_cfg3_full_grid_blocks_against_autodiff_of_the_oracle(role, mode, strict_nan):
+    """BASELINE.json configs[2] -- the 50-wall scene, 1024 x 1024 cells, orders 0..2, value + gradient -- against
+    reverse-mode autodiff of the ORACLE (tests/golden/cfg3_grad_*.npz, scripts/make_golden_cfg3.py: oracle/ref.py under
+    torch.autograd in fp64; NaN positions from the same chain in fp32) on 8 x 8 blocks of the full grid: the transmitter's
+    patch and its neighbours, patches crossed by walls, random patches (768 cells as receivers, 256 as transmitters).
+    The GPU sweeps the WHOLE grid (so every block is culled exactly as in the benchmark); the scene VJP is taken with
+    cotangent 1 on the fixture's cells and 0 elsewhere.  Tolerance: see _tight."""
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import Context
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"cfg3_grad_{role}_{mode}.npz"))
+    kw = dict(approx=False) if mode == "hard" else dict(approx=True, function="hard_sigmoid")
+    tx, walls = random_scene(50, seed=1234)
+    x = np.linspace(0.0, 1.0, 1024).astype(F)
+    X, Y = np.meshgrid(x, x)
+    blocks = z["blocks"]
+    ii = (blocks[:, 0, None, None] + np.arange(8)[None, :, None]) + np.zeros((1, 1, 8), np.int64)
+    jj = (blocks[:, 1, None, None] + np.arange(8)[None, None, :]) + np.zeros((1, 8, 1), np.int64)
+    cot = np.zeros(X.shape, F)
+    cot[ii, jj] = 1.0
+    report = []
+    with Context(0) as c:
+        c.set_scene(walls)
+        got = c.value_and_grads(tx, X, Y, cotangent=cot, min_order=0, max_order=2, strict_nan=strict_nan,
+                                grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw)
+    assert np.array_equal(got["value"][ii, jj], z["value"]), "value map differs from the oracle's on the fixture blocks"
+    g = got["grad_rx"][ii, jj]
+    want = np.where(np.isnan(z["grad32"]), np.nan, z["grad"])  # fp64 values, fp32 NaN positions
+    _tight(g, want, z["grad32"], "per-cell gradient", report)
+    _tight(got["tx_bar"], np.where(np.isnan(z["fixed_bar32"]), np.nan, z["fixed_bar"]), z["fixed_bar32"], "VJP w.r.t. the fixed end point", report)
+    _tight(got["walls_bar"], np.where(np.isnan(z["walls_bar32"]), np.nan, z["walls_bar"]), z["walls_bar32"], "VJP w.r.t. the wall end points", report)
+    assert np.abs(z["grad"]).max() > 1.0 and (z["value"] != 0).sum() >= 64  # the blocks do see paths
+    print("\n".join(report))
