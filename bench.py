@@ -3,27 +3,41 @@
 bench.py -- ray-path candidates/s of the fused power-map sweep (BASELINE.json metric) on N MI355X.
 
 Step      = one forward power map of the workload, inputs resident in HBM:
-            50 random walls (NumPy seed 1234), 1 TX, 1024 x 1024 RX grid over the unit square, orders 0..2
-            (C = 2501 candidates per cell) = BASELINE.json configs[1]; hard (reference default) validity.
-N > 1     = launched by torch.distributed.run, one process per GPU.  Weak scaling: the grid becomes
-            (1024 N) x 1024 cells over the same unit square, rows dealt to ranks in 8-row blocks round-robin
-            (differt2d_amd/parallel.py), so every rank sweeps 1024 x 1024 cells; each step ends with ONE RCCL
-            all-gather of the value map, on a second stream so that it overlaps the next step's sweep.  Control plane (rendezvous, barrier, max over
-            ranks): RCCL too (d2d_comm_allreduce_host); rendezvous through a file in /tmp; torch is never imported.
+            --workload cfg2 (default): 50 random walls (NumPy seed 1234), 1 TX, 1024 x 1024 RX grid over the unit square,
+            orders 0..2 (C = 2501 candidates per cell) = BASELINE.json configs[1]; hard (reference default) validity.
+            --workload cfg4: 200 walls, 2048 x 2048 grid, orders 0..3 (C = 7 960 201) = configs[3].
+N > 1     = launched by torch.distributed.run, one process per GPU (torch is never imported: rendezvous through a file in
+            /tmp, data plane, barrier and max-over-ranks through RCCL).  Rows are dealt to ranks in 8-row blocks
+            round-robin (differt2d_amd/parallel.py).  cfg2: WEAK scaling, the grid becomes (1024 N) x 1024 cells over the
+            same unit square, 1024 x 1024 per rank.  cfg4: STRONG scaling, the 2048 x 2048 grid is split over the ranks.
+            Each step ends with ONE RCCL gather of the value map to rank 0 (--gather root, ncclSend/ncclRecv; or --gather
+            all, ncclAllGather), on a second stream so that it overlaps the next step's sweep.  If the communicator cannot
+            be created the run FAILS (exit code 3): a number without the gather is not the configured workload.
 value     = all cells of all ranks x C / wall time of the K timed steps (max over ranks).
-roofline  = the kernel is FP32-VALU bound (~1e6 FLOP per HBM byte, no MFMA-shaped work).
-            `achieved` prices the work the kernel actually executed (counters of its instrumented build, see
-            include/d2d.h) with SURVEY.md's per-unit FLOP figures; `peak` is the 157.3 TFLOP/s FP32 vector peak.
+roofline  = the kernel is FP32-VALU bound (~1e6 FLOP per HBM byte, no MFMA-shaped work).  Three
+            labelled fractions of the 157.3 TFLOP/s FP32 vector peak, all over the sweep kernel's own duration (HIP
+            events around it, on its stream):
+              executed_with_culling   every unit the kernel executed (counters of its instrumented build, include/d2d.h)
+                                      priced with SURVEY.md's per-unit FLOP figures, the conservative culling itself at
+                                      120 FLOP per lane and level (this repository's own pricing, not a SURVEY figure)
+              reference_work_only     the same without the culling: only work the reference's algorithm also does
+              unpruned_equivalent     SURVEY.md's unpruned count / time: a statement of pruning, not of utilisation
+            `frac` / `achieved` are executed_with_culling (as in round 1).  `traffic` is null: HBM bytes are not measured
+            inside this run (rocprofv3 PMC passes: profiles/, scripts/profile_gpu.sh).
+extras    = (N = 1, outside the timed region, skipped by --no-extras) the same map in hard_sigmoid and sigmoid validity, a
+            moving-TX sequence (a different transmitter every step: the schedule's work history is then always one step
+            stale), the first launch after set_grid, value+grad in both strict_nan modes, and `parity`: mismatch counts
+            of the timed configuration's map against the oracle (committed full-map row CRCs + the cpu_baseline's rows).
 cpu_baseline = the oracle's C/OpenMP restatement on a bounded row sample of the same grid (rank 0, N = 1).
 Prints ONE JSON line on rank 0.
 """
 
 import argparse
-import glob
 import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -32,6 +46,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_VECTOR_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBPS = 8000.0
+WORKLOADS = {
+    # name: (walls, grid, max_order, BASELINE.json config, scaling at N > 1)
+    "cfg2": (50, 1024, 2, "configs[1]", "weak"),
+    "cfg4": (200, 2048, 3, "configs[3]", "strong"),
+}
 
 
 def workload(n_walls=50, grid=1024, seed=1234, rows=None):
@@ -62,12 +81,13 @@ def unpruned_flop_per_rx(n_walls, min_order, max_order, approx):
 def executed_flop(stats, approx):
     """Prices the executed-work counters (d2d_power_map_stats; one count = one 64-lane wave) with SURVEY.md
     section 8(d)'s per-unit figures: solver 16k + on_objects 20k per evaluated candidate, loss 29k,
-    F_seg per evaluated segment/wall test, length/power/validity 9k + 23."""
+    F_seg per evaluated segment/wall test, length/power/validity 9k + 23.  Returns (reference work, culling work):
+    the culling -- per level 4 vertex evaluations of ~30 FLOP in each of the 64 lanes -- is work the reference does not
+    have; its price is this repository's own."""
     f_seg = 41 if approx else 17
     s = [int(v) for v in stats]
     per_wave = s[6] * 36 + s[7] * 29 + s[4] * f_seg + (s[8] - s[3]) * 9 + s[3] * 23
-    per_wave += s[9] * 120  # tile culling: per level 4 vertex evaluations of ~30 FLOP in each of the 64 lanes
-    return per_wave * 64
+    return per_wave * 64, s[9] * 120 * 64
 
 
 def usable_cores():
@@ -83,7 +103,8 @@ def usable_cores():
 
 
 def cpu_baseline(tx, walls, X, Y, max_order, approx, budget_rows=64):
-    """Oracle (C restatement, OpenMP, all usable host cores) timed on a bounded row sample of the same grid."""
+    """Oracle (C restatement, OpenMP, all usable host cores) timed on a bounded row sample of the same grid.
+    Returns (the cpu_baseline object, the sampled row indices, the oracle's map on those rows)."""
     from oracle import c_oracle as CO
 
     CO.build()
@@ -91,7 +112,7 @@ def cpu_baseline(tx, walls, X, Y, max_order, approx, budget_rows=64):
     rows = np.linspace(0, X.shape[0] - 1, budget_rows).astype(int)
     Xs, Ys = np.ascontiguousarray(X[rows]), np.ascontiguousarray(Y[rows])
     t0 = time.perf_counter()
-    CO.power_map(walls, tx, Xs, Ys, min_order=0, max_order=max_order, approx=approx, prune=False, nthreads=cores)
+    ref = CO.power_map(walls, tx, Xs, Ys, min_order=0, max_order=max_order, approx=approx, prune=False, nthreads=cores)
     dt = time.perf_counter() - t0
     cands = Xs.size * num_candidates(walls.shape[0], 0, max_order)
     return {
@@ -102,34 +123,47 @@ def cpu_baseline(tx, walls, X, Y, max_order, approx, budget_rows=64):
         "sample": f"{budget_rows} of {X.shape[0]} grid rows x {X.shape[1]} columns ({Xs.size} RX cells, "
                   f"{cands:.3g} candidates, every candidate fully evaluated), C/OpenMP restatement of DiffeRT2d v0.4.0 "
                   f"(the JAX reference cannot be installed here), {dt:.1f} s",
-    }
+    }, rows, ref
 
 
-def measured_traffic_bytes(approx):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc.json: FETCH_SIZE + WRITE_SIZE,
-    KiB; 4-byte-per-lane accesses, for which the guide's x2 wide-read correction does not apply)."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_a{int(approx)}_pmc.json")))
-    if not files:
-        return None
-    try:
-        pmc = json.load(open(files[-1]))
-        return (pmc["FETCH_SIZE"]["mean_per_dispatch"] + pmc["WRITE_SIZE"]["mean_per_dispatch"]) * 1024.0
-    except (KeyError, ValueError):
-        return None
+def row_crcs(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return np.array([zlib.crc32(a[i].tobytes()) for i in range(a.shape[0])], dtype=np.uint32)
+
+
+def moving_transmitters(tx, n, step=0.01, seed=7):
+    """A transmitter that moves a little every step (an optimisation loop's caller, examples/plot_power_optimize.py:78-93):
+    random walk inside [0.05, 0.95]^2 starting at the workload's transmitter."""
+    rng = np.random.default_rng(seed)
+    out, p = [], np.asarray(tx, np.float64).copy()
+    for _ in range(n):
+        p = np.clip(p + rng.normal(0.0, step, 2), 0.05, 0.95)
+        out.append(p.astype(np.float32))
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", type=int, default=1024)
-    ap.add_argument("--walls", type=int, default=50)
-    ap.add_argument("--max-order", type=int, default=2)
-    ap.add_argument("--approx", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for cfg2, 5 for cfg4)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 5 for cfg2, 1 for cfg4)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    ap.add_argument("--grid", type=int, default=None, help="override the workload's grid size (cells per side and per GPU)")
+    ap.add_argument("--walls", type=int, default=None)
+    ap.add_argument("--max-order", type=int, default=None)
+    ap.add_argument("--approx", type=int, default=0, help="validity of the TIMED map: 0 hard (reference default), 1 hard_sigmoid")
+    ap.add_argument("--gather", choices=["root", "all"], default="root", help="N > 1: gather the map to rank 0, or all-gather it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-grad", action="store_true", help="skip the value+grad (BASELINE.json configs[2]) timing")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other modes / moving-TX / value+grad / parity legs")
     args = ap.parse_args()
+
+    wl_walls, wl_grid, wl_order, wl_cfg, wl_scaling = WORKLOADS[args.workload]
+    n_walls = args.walls or wl_walls
+    grid = args.grid or wl_grid
+    max_order = wl_order if args.max_order is None else args.max_order
+    steps = args.steps if args.steps is not None else (200 if args.workload == "cfg2" else 5)
+    warmup = args.warmup if args.warmup is not None else (5 if args.workload == "cfg2" else 1)
+    default_shape = (n_walls, grid, max_order) == (wl_walls, wl_grid, wl_order)
 
     from differt2d_amd import _lib as L
     from differt2d_amd.engine import Context, make_params
@@ -146,125 +180,181 @@ def main():
 
     n_dev = max(1, L.device_count())
     ctx = Context(local_rank % n_dev)  # one GPU per rank; ranks only share a device on a box with fewer GPUs than ranks
-    rccl_note = None
-    host_comm = None  # control plane: RCCL (d2d_comm_allreduce_host) unless the communicator cannot be created
     if distributed:
         # torch.distributed.run is only the launcher: rendezvous through /tmp, everything else through RCCL
-        from differt2d_amd.parallel import FileHostComm, file_rendezvous, file_rendezvous_cleanup
+        from differt2d_amd.parallel import file_rendezvous, file_rendezvous_cleanup
 
         try:
             ctx.comm_init(file_rendezvous(rank, world, Context.comm_unique_id), rank, world)
             ctx.comm_barrier()
-        except Exception as e:  # noqa: BLE001 -- keep the sharded sweep measurable without the gather
-            rccl_note = f"RCCL communicator unavailable ({str(e)[:200]}): shards timed without the all-gather, file barrier"
-            print(f"[bench rank {rank}] {rccl_note}", file=sys.stderr, flush=True)
-            host_comm = FileHostComm(rank, world)
-            host_comm.barrier()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench rank {rank}] RCCL communicator unavailable: {e}\n[bench rank {rank}] the configured workload ends every "
+                  f"step with an RCCL gather; refusing to print a number without it", file=sys.stderr, flush=True)
+            sys.exit(3)
         file_rendezvous_cleanup(rank)
 
-    tx, walls, X, Y = workload(args.walls, args.grid, rows=args.grid * world)
+    weak = wl_scaling == "weak"
+    tx, walls, X, Y = workload(n_walls, grid, rows=grid * world if weak else grid)
     shards = RowShards(X.shape[0], world)
     Xl, Yl = shards.take(X, rank), shards.take(Y, rank)
-    C = num_candidates(args.walls, 0, args.max_order)
-    params = make_params(min_order=0, max_order=args.max_order, approx=bool(args.approx))
+    C = num_candidates(n_walls, 0, max_order)
+    mode_kw = {"hard": dict(approx=False), "hard_sigmoid": dict(approx=True, function="hard_sigmoid"),
+               "sigmoid": dict(approx=True, function="sigmoid")}
+    timed_mode = "hard_sigmoid" if args.approx else "hard"
+    params = make_params(min_order=0, max_order=max_order, **mode_kw[timed_mode])
     ctx.set_scene(walls)
     ctx.set_grid(Xl, Yl)
-
-    gather = world > 1 and host_comm is None
+    gather = world > 1
 
     def barrier():
         ctx.synchronize()
-        if host_comm is not None:
-            host_comm.barrier()
-        elif distributed:
+        if distributed:
             ctx.comm_barrier()
 
     def allreduce_max(v):
-        return float((host_comm.allreduce([v], "max") if host_comm is not None else ctx.comm_allreduce_host([v], "max"))[0])
+        return float(ctx.comm_allreduce_host([v], "max")[0])
+
+    def do_gather(grad=False):
+        if args.gather == "root":
+            ctx.comm_gather_map(root=0, grad=grad)  # on its own stream, overlapped with the next step's sweep
+        else:
+            ctx.comm_allgather_map(grad=grad)
 
     def step():
         ctx.launch(params, tx)
         if gather:
-            ctx.comm_allgather_map()  # on its own stream, overlapped with the next step's sweep
+            do_gather()
 
-    def timed(fn, steps, warmup):
-        for _ in range(warmup):
+    def timed(fn, n_steps, n_warmup):
+        for _ in range(n_warmup):
             fn()
         barrier()
         t0 = time.perf_counter()
         ctx.timer_begin()
-        for _ in range(steps):
+        for _ in range(n_steps):
             fn()
         stream_ms = ctx.timer_end()  # HIP events on the stream the kernels are launched on
         barrier()
         wall = time.perf_counter() - t0
         if distributed:
             wall = allreduce_max(wall)
-        return wall, stream_ms / steps
+        return wall, stream_ms / n_steps
 
-    # Setup, like set_scene / set_grid: one launch allocates the library's device buffers and builds the scene-only
-    # wall-to-wall masks (the W warmup steps that follow are the contract's; with --warmup 0 the timed steps would
-    # otherwise include hipMalloc calls).
-    step()
+    def kernel_ms_of(p, the_tx, n):
+        """The sweep kernel on its own (HIP events around it, on the stream it runs on), averaged over n launches."""
+        ctx.set_option("time_kernel", 1)
+        ks = []
+        for _ in range(n):
+            ctx.launch(p, the_tx)
+            ks.append(ctx.last_kernel_ms())
+        ctx.set_option("time_kernel", 0)
+        return float(np.mean(ks))
+
+    # First launch after set_grid: allocates the library's device buffers, builds the scene-only wall-to-wall masks and
+    # schedules the patches by the geometric proxy (no work history yet).  Setup, like set_scene / set_grid; reported.
     barrier()
-    wall, sequence_ms = timed(step, args.steps, args.warmup)
-    ms_per_step = wall * 1e3 / args.steps
-    # the dominant kernel on its own (HIP events around it, on the stream it runs on), outside the timed region
-    ctx.set_option("time_kernel", 1)
-    ks = []
-    for _ in range(args.steps):
-        ctx.launch(params, tx)
-        ks.append(ctx.last_kernel_ms())
-    ctx.set_option("time_kernel", 0)
-    kernel_ms = float(np.mean(ks))
+    t0 = time.perf_counter()
+    step()
+    ctx.synchronize()
+    first_launch_ms = (time.perf_counter() - t0) * 1e3
+    barrier()
+
+    wall, sequence_ms = timed(step, steps, warmup)
+    ms_per_step = wall * 1e3 / steps
+    kernel_ms = kernel_ms_of(params, tx, min(steps, 50))
     cells_total = X.size
     cells_local = Xl.size
+    small = (Xl.shape[0] + 7) // 8 * ((Xl.shape[1] + 7) // 8) <= 8192
 
-    grad_info = None
-    if not args.no_grad:
+    extras = {}
+    if not args.no_extras and world == 1:
+        n_x = max(10, min(steps, 100))
+        # ---- the same map in every validity mode (the timed one included, for a like-for-like column)
+        modes = {}
+        for name, kw in mode_kw.items():
+            p = make_params(min_order=0, max_order=max_order, **kw)
+            n = n_x if name != "sigmoid" else max(3, n_x // 10)
+            w, _ = timed(lambda p=p: ctx.launch(p, tx), n, 2)
+            modes[name] = {"ms_per_step": w * 1e3 / n, "kernel_ms": kernel_ms_of(p, tx, min(n, 10)), "steps": n,
+                           "candidates_per_s": cells_total * C / (w / n)}
+        extras["modes"] = modes
+        # ---- a different transmitter every step: the work history behind the patch schedule is one step stale
+        txs = moving_transmitters(tx, n_x + 5)
+        it = iter(txs)
+        w, _ = timed(lambda: ctx.launch(params, next(it)), n_x, 5)
+        extras["moving_tx"] = {"ms_per_step": w * 1e3 / n_x, "steps": n_x, "mode": timed_mode,
+                               "what": "random walk of the transmitter (sigma 0.01 per step), a different position every step; "
+                                       "shadow masks and schedule rebuilt per launch as always, work history from the previous position"}
+        # ---- a launch right after set_grid with everything allocated: geometric-proxy schedule, no cut-in-four
+        cold = []
+        for _ in range(5):
+            ctx.set_grid(Xl, Yl)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.launch(params, tx)
+            ctx.synchronize()
+            cold.append((time.perf_counter() - t0) * 1e3)
+        extras["first_launch"] = {"ms_incl_allocation_and_scene_masks": first_launch_ms, "ms_cold_schedule": float(np.median(cold)),
+                                  "what": "wall time launch -> synchronize of one map; the first figure is the very first launch of "
+                                          "the process's context, the second a launch after set_grid with buffers and masks in place "
+                                          "(no work history: geometric-proxy schedule)"}
+        # ---- value + gradient (BASELINE.json configs[2]), both NaN-parity modes, in the timed validity mode
+        vg = {}
+        for label, strict in (("culled", False), ("strict_nan", True)):
+            p = make_params(min_order=0, max_order=max_order, strict_nan=strict, **mode_kw[timed_mode])
+            n = max(3, n_x // 2) if not strict else 5
+            w, _ = timed(lambda p=p: ctx.launch_vg(p, tx, scene_vjp=True), n, 1)
+            vg[label] = {"ms_per_step": w * 1e3 / n, "steps": n, "candidates_per_s": cells_total * C / (w / n)}
+        vg["what"] = ("value + per-cell d/d rx + VJP w.r.t. TX position and wall end points (hand-derived reverse mode). "
+                      "`culled` (default): NaN where the reference's autodiff NaN artefacts come from an evaluated candidate or a "
+                      "cell on a wall's line; `strict_nan`: every candidate evaluated, NaN positions identical to the reference's "
+                      "in all cases (DESIGN.md 'NaN parity')")
+        extras["value_and_grad"] = vg
+    elif not args.no_extras:
         def step_vg():
             ctx.launch_vg(params, tx, scene_vjp=True)
             if gather:
-                ctx.comm_allgather_map()
+                do_gather()
+                do_gather(grad=True)
                 ctx.comm_allreduce_vjp()
 
-        gwall, gkernel_ms = timed(step_vg, max(3, args.steps // 2), 1)
-        gsteps = max(3, args.steps // 2)
-        grad_info = {
-            "what": "value + per-cell d/d rx + VJP w.r.t. TX position and wall end points (reverse-mode kernel), "
-                    "BASELINE.json configs[2]",
-            "ms_per_step": gwall * 1e3 / gsteps,
-            "stream_ms_per_step": gkernel_ms,
-            "candidates_per_s": cells_total * C / (gwall / gsteps),
-        }
+        n = max(3, steps // 4)
+        w, _ = timed(step_vg, n, 1)
+        extras["value_and_grad"] = {"culled": {"ms_per_step": w * 1e3 / n, "steps": n, "candidates_per_s": cells_total * C / (w / n)},
+                                    "what": "value + gradient maps gathered, scene VJP all-reduced, every step"}
 
     if rank == 0:
+        approx = timed_mode != "hard"
+        ctx.launch(params, tx)
+        final_map = ctx.get_map()  # rank 0's shard of the timed configuration (N = 1: the whole map)
         stats = ctx.launch_stats(params, tx)  # instrumented build, outside the timed region (deterministic counts)
-        flop_exec = executed_flop(stats, bool(args.approx))
-        flop_unpruned = unpruned_flop_per_rx(args.walls, 0, args.max_order, bool(args.approx)) * cells_local
-        achieved = flop_exec / (kernel_ms * 1e-3) / 1e12
+        flop_ref, flop_cull = executed_flop(stats, approx)
+        flop_unpruned = unpruned_flop_per_rx(n_walls, 0, max_order, approx) * cells_local
+        per_s = 1.0 / (kernel_ms * 1e-3) / 1e12
+        achieved = (flop_ref + flop_cull) * per_s
+        parity = None
         line = {
             "metric": "ray-path candidates/s",
             "value": cells_total * C / (ms_per_step * 1e-3),
             "unit": "candidates/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": steps,
+            "warmup": warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": wl_scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.walls} random walls (NumPy seed 1234), 1 TX, {X.shape[0]}x{X.shape[1]} RX grid over the "
-                            f"unit square ({args.grid}x{args.grid} per GPU), orders 0..{args.max_order} (C={C} candidates per "
-                            f"cell), {'approx hard_sigmoid alpha=100' if args.approx else 'hard'} validity, received_power; "
-                            f"BASELINE.json configs[1]",
-                "setup": "scene and grid resident in HBM; 1 untimed launch (buffer allocation, scene-only masks) before the warmup steps",
+                "workload": f"{n_walls} random walls (NumPy seed 1234), 1 TX, {X.shape[0]}x{X.shape[1]} RX grid over the "
+                            f"unit square ({Xl.shape[0]}x{Xl.shape[1]} per GPU), orders 0..{max_order} (C={C} candidates per "
+                            f"cell), {timed_mode} validity, received_power; BASELINE.json {wl_cfg}",
+                "setup": "scene and grid resident in HBM; 1 untimed launch (buffer allocation, scene-only masks) before the warmup "
+                         "steps; every timed step sweeps the same transmitter (see moving_tx for a different one every step)",
                 "sharding": f"{world} rank(s), 8-row blocks round-robin"
-                            + ("; 1 RCCL all-gather of the value map per step, overlapped with the next step's sweep" if gather else "")
-                            + (f"; {rccl_note}" if rccl_note else ""),
+                            + (f"; 1 RCCL {'gather to rank 0 (ncclSend/ncclRecv)' if args.gather == 'root' else 'all-gather'} of the "
+                               f"value map per step, overlapped with the next step's sweep" if gather else ""),
             },
             "roofline": {
                 "bound": "valu_fp32",
@@ -272,14 +362,22 @@ def main():
                 "peak": PEAK_FP32_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
-                "traffic": measured_traffic_bytes(args.approx),
-                "kernel": "d2d::power_fwd_split_kernel" if (Xl.shape[0] + 7) // 8 * ((Xl.shape[1] + 7) // 8) <= 8192
-                          else "d2d::power_fwd_kernel",
+                "fracs": {
+                    "executed_with_culling": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                    "reference_work_only": flop_ref * per_s / PEAK_FP32_VECTOR_TFLOPS,
+                    "unpruned_equivalent": flop_unpruned * per_s / PEAK_FP32_VECTOR_TFLOPS,
+                    "pmc_lane_ops": None,
+                    "note": "all over kernel_ms; frac = executed_with_culling; pmc_lane_ops (64 x SQ_INSTS_VALU / time / peak) needs "
+                            "rocprofv3 PMC passes and is not measured inside this run: see profiles/*_summary.md",
+                },
+                "traffic": None,
+                "kernel": "d2d::power_fwd_split_kernel" if small else "d2d::power_fwd_kernel",
                 "kernel_ms": kernel_ms,
                 "launch_sequence_ms": sequence_ms,  # + shadow masks, patch schedule (4 small kernels, 2 memsets)
-                "algorithmic_flop_per_launch": flop_exec,
+                "algorithmic_flop_per_launch": flop_ref + flop_cull,
+                "reference_work_flop_per_launch": flop_ref,
+                "culling_flop_per_launch": flop_cull,
                 "unpruned_flop_per_launch": flop_unpruned,
-                "unpruned_equiv_TFLOPs": flop_unpruned / (kernel_ms * 1e-3) / 1e12,
                 "executed_lane_units": {
                     "cull_levels": int(stats[9]) * 64, "candidates_exact": int(stats[0]) * 64, "reached_loss": int(stats[1]) * 64,
                     "reached_occlusion": int(stats[2]) * 64, "reached_fun": int(stats[3]) * 64,
@@ -290,16 +388,31 @@ def main():
                 "hbm_peak_GBps": PEAK_HBM_GBPS,
             },
         }
-        if grad_info:
-            line["value_and_grad"] = grad_info
+        line.update(extras)
+        if world == 1 and not args.no_extras:
+            parity = {"what": "cells / rows of the timed configuration's map that differ from the oracle's (expected 0)"}
+            gold_path = os.path.join(ROOT, "tests", "golden", "cfg2_fullmap_crc.npz")
+            if args.workload == "cfg2" and default_shape and os.path.exists(gold_path):
+                gold = np.load(gold_path)
+                key = f"rx_{'hsig' if approx else 'hard'}_power_crc"
+                parity["full_map_rows_compared"] = int(final_map.shape[0])
+                parity["full_map_rows_mismatching"] = int((row_crcs(final_map) != gold[key]).sum())
+                parity["full_map_reference"] = "tests/golden/cfg2_fullmap_crc.npz (C oracle, every cell, one CRC-32 per row)"
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(tx, walls, X, Y, args.max_order, bool(args.approx))
+            base, rows, ref = cpu_baseline(tx, walls, X, Y, max_order, approx)
+            line["cpu_baseline"] = base
+            if parity is not None:
+                got = final_map[rows]
+                parity["sampled_cells_compared"] = int(ref.size)
+                parity["sampled_cells_mismatching"] = int((~((got == ref) | (np.isnan(got) & np.isnan(ref)))).sum())
+                parity["sampled_reference"] = "the cpu_baseline's own output (C oracle, every candidate fully evaluated)"
+        if parity is not None:
+            line["parity"] = parity
         print(json.dumps(line), flush=True)
 
     if distributed:
         barrier()
-        if host_comm is None:
-            ctx.comm_destroy()
+        ctx.comm_destroy()
     ctx.close()
 
 

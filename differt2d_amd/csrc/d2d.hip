@@ -16,6 +16,7 @@
 #include "../../include/d2d.h"
 #define D2D_AUX_KERNELS 1  // the non-template kernels are defined in this translation unit
 #include "d2d_launch.hpp"
+#include "d2d_host.hpp"
 
 // ---- mode dispatch of the sweep-kernel launchers (d2d_launch.hpp); the per-mode launchers live in the
 // d2d_sweep_tu objects, one per (kernel family, validity mode) ----
@@ -104,21 +105,7 @@ struct DevBuf {
     }
 };
 
-// lax.integer_pow lowering (square and multiply), fp32
-float integer_pow(float x, int n) {
-    if (n == 0) return 1.0f;
-    float acc = 0.0f;
-    bool have = false;
-    while (n > 0) {
-        if (n & 1) {
-            acc = have ? acc * x : x;
-            have = true;
-        }
-        n >>= 1;
-        if (n > 0) x = x * x;
-    }
-    return acc;
-}
+using d2d_host::integer_pow;
 
 }  // namespace
 
@@ -322,26 +309,10 @@ int adam_cfg(d2d_ctx* c, const d2d_params* p, d2d::AdamCfg* A) {
     return D2D_OK;
 }
 
-int64_t count_order(int64_t nc, int k) {
-    if (k == 0) return 1;
-    if (nc <= 0) return 0;
-    int64_t c = nc;
-    for (int i = 1; i < k; ++i) c *= (nc - 1);
-    return c;
-}
-
 int check_params(const d2d_params* p) {
-    if (!p) return fail(D2D_ERR_INVALID, "params is NULL");
-    if (p->min_order < 0 || p->max_order > D2D_MAX_ORDER)
-        return fail(D2D_ERR_INVALID, "orders must lie in [0, %d], got [%d, %d]", D2D_MAX_ORDER, p->min_order, p->max_order);
-    if (p->approx && !(p->alpha > 0.0f)) return fail(D2D_ERR_INVALID, "alpha must be > 0 in approx mode, got %g", (double)p->alpha);
-    if (p->approx && p->act != D2D_ACT_HARD_SIGMOID && p->act != D2D_ACT_SIGMOID)
-        return fail(D2D_ERR_UNSUPPORTED, "activation %d is not one of the native activations", p->act);
-    if (p->fun_id < 0 || p->fun_id > D2D_FUN_ONE) return fail(D2D_ERR_UNSUPPORTED, "fun_id %d is not a native path function", p->fun_id);
-    if (p->out_mode != D2D_OUT_OVERWRITE && p->out_mode != D2D_OUT_ADD) return fail(D2D_ERR_INVALID, "bad out_mode %d", p->out_mode);
-    if (p->grid_role != D2D_GRID_RX && p->grid_role != D2D_GRID_TX) return fail(D2D_ERR_INVALID, "bad grid_role %d", p->grid_role);
-    if (!(p->seg_tol >= 0.0f)) return fail(D2D_ERR_INVALID, "seg_tol must be >= 0");
-    return D2D_OK;
+    std::string err;
+    const int rc = d2d_host::check_params(p, err);
+    return rc ? fail(rc, "%s", err.c_str()) : D2D_OK;
 }
 
 }  // namespace
@@ -597,59 +568,16 @@ int d2d_set_candidate_mask(d2d_ctx* c, const uint8_t* allowed) {
 }
 
 int d2d_count_candidates(int32_t n_objects, const uint8_t* allowed, int32_t min_order, int32_t max_order, int64_t* count) {
-    if (!count) return fail(D2D_ERR_INVALID, "count is NULL");
-    if (n_objects < 0 || min_order < 0) return fail(D2D_ERR_INVALID, "negative argument");
-    int64_t nc = 0;
-    for (int j = 0; j < n_objects; ++j) nc += (!allowed || allowed[j]) ? 1 : 0;
-    int64_t total = 0;
-    for (int k = min_order; k <= max_order; ++k) total += count_order(nc, k);
-    *count = total;
-    return D2D_OK;
+    std::string err;
+    const int rc = d2d_host::count_candidates(n_objects, allowed, min_order, max_order, count, err);
+    return rc ? fail(rc, "%s", err.c_str()) : D2D_OK;
 }
 
 int d2d_enumerate_candidates(int32_t n_objects, const uint8_t* allowed, int32_t min_order, int32_t max_order, int32_t* cand,
                              int32_t* order, int64_t capacity) {
-    if (min_order < 0 || max_order > D2D_MAX_ORDER) return fail(D2D_ERR_INVALID, "orders must lie in [0, %d]", D2D_MAX_ORDER);
-    int64_t total = 0;
-    int rc = d2d_count_candidates(n_objects, allowed, min_order, max_order, &total);
-    if (rc) return rc;
-    if (capacity < total) return fail(D2D_ERR_INVALID, "capacity %lld < %lld candidates", (long long)capacity, (long long)total);
-    std::vector<int> cw;
-    for (int j = 0; j < n_objects; ++j)
-        if (!allowed || allowed[j]) cw.push_back(j);
-    const int nc = (int)cw.size();
-    int64_t at = 0;
-    for (int k = min_order; k <= max_order; ++k) {
-        if (k == 0) {
-            if (cand) for (int i = 0; i < D2D_MAX_ORDER; ++i) cand[at * D2D_MAX_ORDER + i] = -1;
-            if (order) order[at] = 0;
-            ++at;
-            continue;
-        }
-        // odometer over positions in the compact list: lexicographic, no equal neighbours
-        int pos[D2D_MAX_ORDER];
-        int depth = 0;
-        pos[0] = -1;
-        while (depth >= 0) {
-            int p = pos[depth] + 1;
-            if (depth > 0 && p == pos[depth - 1]) ++p;
-            if (p >= nc) {
-                --depth;
-                continue;
-            }
-            pos[depth] = p;
-            if (depth == k - 1) {
-                if (cand)
-                    for (int i = 0; i < D2D_MAX_ORDER; ++i) cand[at * D2D_MAX_ORDER + i] = (i < k) ? cw[pos[i]] : -1;
-                if (order) order[at] = k;
-                ++at;
-            } else {
-                ++depth;
-                pos[depth] = -1;
-            }
-        }
-    }
-    return D2D_OK;
+    std::string err;
+    const int rc = d2d_host::enumerate_candidates(n_objects, allowed, min_order, max_order, cand, order, capacity, err);
+    return rc ? fail(rc, "%s", err.c_str()) : D2D_OK;
 }
 
 int d2d_num_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int64_t* count) {
@@ -1005,25 +933,23 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
         return D2D_OK;
     }
-    const size_t tab_lds = (size_t)(4 * c->N + 1) * sizeof(float4) + 512;  // tables (+ adjoint table) + one culling queue
-    if (tab_lds > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~1300)", c->N);
+    const size_t tab_lds = d2d_host::tab_lds_bytes(c->N);  // tables (+ adjoint table) + one culling queue
+    if (tab_lds > d2d_host::LDS_LIMIT) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~1300)", c->N);
     // Launches that hold only a few patches per SIMD are bound by their dearest patch: share every patch between
     // D2D_SPLIT_W waves there (power_fwd_split_kernel).  Big grids are throughput-bound: one wave per patch.
     constexpr int D2D_SPLIT_W = d2d::SPLIT_W;
-    const size_t split_base = ((tab_lds - 512 + (size_t)(D2D_SPLIT_W - 1) * d2d::SPLIT_LIST * 64 * sizeof(float) +
-                                (size_t)((D2D_SPLIT_W - 1) * 65 + D2D_SPLIT_W + 1) * sizeof(int)) + 15) & ~(size_t)15;
-    const size_t split_lds = split_base + (size_t)D2D_SPLIT_W * 512;  // ... + one culling queue per wave
-    const bool split = p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= 64 * 1024 && tiles <= c->split_max_tiles;
+    const d2d_host::SplitLds sl = d2d_host::split_lds_bytes(c->N, D2D_SPLIT_W, d2d::SPLIT_LIST);
+    const size_t split_base = sl.base, split_lds = sl.total;  // ... + one culling queue per wave
+    const bool split = p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= d2d_host::LDS_LIMIT && tiles <= c->split_max_tiles;
     // the dearest patches of a bigger launch are cut in four (see power_fwd_kernel); they are only known with a work history
     dim3 grid_fwd = grid_patches;
     if (!split && !d_stats && p->max_order == 2 && c->cw.size() >= 2 && a.sched == c->d_sched.p && sched_from_history && c->heavy_split > 0) {
-        const long long H = std::min<long long>(c->heavy_split, tiles / 16);
-        const long long Nc = (long long)c->cw.size();
         const long long P = d2d::HEAVY_PARTS;
-        const long long cap = ((Nc + P - 1) / P + 2) * Nc + Nc + 2;  // candidates one part can evaluate, generously
-        if (H > 0 && H * P * cap * 64 * (long long)sizeof(float) <= (4ll << 30)) {
-            if ((rc = c->d_heavy_list.ensure((size_t)(H * P * cap * 64)))) return rc;
-            if ((rc = c->d_heavy_cnt.ensure((size_t)(H * P * 64 + H * P)))) return rc;
+        const d2d_host::HeavyPlan hp = d2d_host::heavy_plan(tiles, (long long)c->cw.size(), c->heavy_split, P);
+        const long long H = hp.H, cap = hp.cap;
+        if (H > 0) {
+            if ((rc = c->d_heavy_list.ensure((size_t)hp.list_floats))) return rc;
+            if ((rc = c->d_heavy_cnt.ensure((size_t)hp.cnt_ints))) return rc;
             if (c->heavy_done_n < H) {
                 if ((rc = c->d_heavy_done.ensure((size_t)H))) return rc;
                 HIP_TRY(hipMemsetAsync(c->d_heavy_done.p, 0, (size_t)H * sizeof(int), c->stream));  // the kernel re-zeroes it

@@ -1,0 +1,170 @@
+// Host-only logic of libd2d.so that needs neither a device nor the HIP headers: candidate enumeration (the stand-in for
+// differt-core's Rust graph iterator, differt2d/scene.py:153-175), parameter validation, lax.integer_pow, and the
+// buffer-size arithmetic of the sweep launches (LDS tables, the contribution lists of the patches cut in four and their
+// 4 GiB guard).  d2d.hip uses these functions as they are; tests/native/d2d_host_san.cpp compiles the same header with
+// g++ -fsanitize=address,undefined and tests/test_host_sanitizers.py drives it (sanitizers run on the CPU build only).
+#pragma once
+#include <stdint.h>
+
+#include <cmath>
+#include <cstddef>
+#include <string>
+#include <vector>
+
+#include "../../include/d2d.h"
+
+namespace d2d_host {
+
+// lax.integer_pow lowering (square and multiply), fp32
+inline float integer_pow(float x, int n) {
+    if (n == 0) return 1.0f;
+    float acc = 0.0f;
+    bool have = false;
+    while (n > 0) {
+        if (n & 1) {
+            acc = have ? acc * x : x;
+            have = true;
+        }
+        n >>= 1;
+        if (n > 0) x = x * x;
+    }
+    return acc;
+}
+
+// candidates of order k over nc allowed objects: nc (nc - 1)^(k-1), 1 for k = 0; saturates at INT64_MAX
+inline int64_t count_order(int64_t nc, int k) {
+    if (k == 0) return 1;
+    if (nc <= 0) return 0;
+    int64_t c = nc;
+    for (int i = 1; i < k; ++i) {
+        if (nc - 1 != 0 && c > INT64_MAX / (nc - 1)) return INT64_MAX;
+        c *= (nc - 1);
+    }
+    return c;
+}
+
+// status (D2D_OK or negative) + message
+inline int count_candidates(int32_t n_objects, const uint8_t* allowed, int32_t min_order, int32_t max_order, int64_t* count,
+                            std::string& err) {
+    if (!count) return err = "count is NULL", D2D_ERR_INVALID;
+    if (n_objects < 0 || min_order < 0) return err = "negative argument", D2D_ERR_INVALID;
+    int64_t nc = 0;
+    for (int j = 0; j < n_objects; ++j) nc += (!allowed || allowed[j]) ? 1 : 0;
+    int64_t total = 0;
+    for (int k = min_order; k <= max_order; ++k) {
+        const int64_t ck = count_order(nc, k);
+        if (ck > INT64_MAX - total) return err = "the number of candidates overflows int64", D2D_ERR_INVALID;
+        total += ck;
+    }
+    *count = total;
+    return D2D_OK;
+}
+
+// For each order k ascending, every tuple of k allowed object indices with no two equal neighbours, lexicographic
+// (recorded order: docs/source/notebooks/cost20120_helsinki_model.ipynb cell 20).  cand: [count][D2D_MAX_ORDER], -1 padded.
+inline int enumerate_candidates(int32_t n_objects, const uint8_t* allowed, int32_t min_order, int32_t max_order, int32_t* cand,
+                                int32_t* order, int64_t capacity, std::string& err) {
+    if (min_order < 0 || max_order > D2D_MAX_ORDER) return err = "orders must lie in [0, " + std::to_string(D2D_MAX_ORDER) + "]", D2D_ERR_INVALID;
+    int64_t total = 0;
+    int rc = count_candidates(n_objects, allowed, min_order, max_order, &total, err);
+    if (rc) return rc;
+    if (capacity < total) return err = "capacity " + std::to_string(capacity) + " < " + std::to_string(total) + " candidates", D2D_ERR_INVALID;
+    std::vector<int> cw;
+    for (int j = 0; j < n_objects; ++j)
+        if (!allowed || allowed[j]) cw.push_back(j);
+    const int nc = (int)cw.size();
+    int64_t at = 0;
+    for (int k = min_order; k <= max_order; ++k) {
+        if (k == 0) {
+            if (cand) for (int i = 0; i < D2D_MAX_ORDER; ++i) cand[at * D2D_MAX_ORDER + i] = -1;
+            if (order) order[at] = 0;
+            ++at;
+            continue;
+        }
+        // odometer over positions in the compact list: lexicographic, no equal neighbours
+        int pos[D2D_MAX_ORDER];
+        int depth = 0;
+        pos[0] = -1;
+        while (depth >= 0) {
+            int p = pos[depth] + 1;
+            if (depth > 0 && p == pos[depth - 1]) ++p;
+            if (p >= nc) {
+                --depth;
+                continue;
+            }
+            pos[depth] = p;
+            if (depth == k - 1) {
+                if (cand)
+                    for (int i = 0; i < D2D_MAX_ORDER; ++i) cand[at * D2D_MAX_ORDER + i] = (i < k) ? cw[pos[i]] : -1;
+                if (order) order[at] = k;
+                ++at;
+            } else {
+                ++depth;
+                pos[depth] = -1;
+            }
+        }
+    }
+    return D2D_OK;
+}
+
+inline int check_params(const d2d_params* p, std::string& err) {
+    if (!p) return err = "params is NULL", D2D_ERR_INVALID;
+    if (p->min_order < 0 || p->max_order > D2D_MAX_ORDER)
+        return err = "orders must lie in [0, " + std::to_string(D2D_MAX_ORDER) + "], got [" + std::to_string(p->min_order) + ", " +
+                     std::to_string(p->max_order) + "]", D2D_ERR_INVALID;
+    if (p->approx && !(p->alpha > 0.0f)) return err = "alpha must be > 0 in approx mode", D2D_ERR_INVALID;
+    if (p->approx && p->act != D2D_ACT_HARD_SIGMOID && p->act != D2D_ACT_SIGMOID)
+        return err = "activation " + std::to_string(p->act) + " is not one of the native activations", D2D_ERR_UNSUPPORTED;
+    if (p->fun_id < 0 || p->fun_id > D2D_FUN_ONE) return err = "fun_id " + std::to_string(p->fun_id) + " is not a native path function", D2D_ERR_UNSUPPORTED;
+    if (p->out_mode != D2D_OUT_OVERWRITE && p->out_mode != D2D_OUT_ADD) return err = "bad out_mode " + std::to_string(p->out_mode), D2D_ERR_INVALID;
+    if (p->grid_role != D2D_GRID_RX && p->grid_role != D2D_GRID_TX) return err = "bad grid_role " + std::to_string(p->grid_role), D2D_ERR_INVALID;
+    if (!(p->seg_tol >= 0.0f)) return err = "seg_tol must be >= 0", D2D_ERR_INVALID;
+    return D2D_OK;
+}
+
+// ---- buffer sizes of the forward sweep ----------------------------------------------------------------------------
+constexpr size_t LDS_LIMIT = 64 * 1024;  // dynamic LDS a launch may ask for (of the CU's 160 KB: several workgroups stay resident)
+constexpr size_t F4 = 16;                // sizeof(float4)
+
+// one-wave-per-patch kernels: [2N] refl + [N] flt + [N] adjoint table (float4 each) + 1 spare + one 512-byte culling queue
+inline size_t tab_lds_bytes(int n_objects) { return (size_t)(4 * (size_t)n_objects + 1) * F4 + 512; }
+
+struct SplitLds {
+    size_t base;   // byte offset of the culling queues (16-byte aligned)
+    size_t total;  // dynamic LDS of power_fwd_split_kernel
+};
+// shared-patch kernel (W waves): tables, (W - 1) contribution lists of list_len x 64 floats, their bookkeeping, W queues
+inline SplitLds split_lds_bytes(int n_objects, int W, int list_len) {
+    SplitLds s;
+    s.base = ((tab_lds_bytes(n_objects) - 512 + (size_t)(W - 1) * (size_t)list_len * 64 * sizeof(float) +
+               (size_t)((W - 1) * 65 + W + 1) * sizeof(int)) + 15) & ~(size_t)15;
+    s.total = s.base + (size_t)W * 512;
+    return s;
+}
+
+struct HeavyPlan {
+    long long H = 0;           // patches cut in `parts` (0: none)
+    long long cap = 0;         // list entries per lane and part
+    long long list_floats = 0; // heavy_list elements
+    long long cnt_ints = 0;    // heavy_cnt elements
+};
+// The dearest `heavy_split` patches of a launch of `tiles` patches (at most a sixteenth of them) are cut in `parts`; a
+// part's list holds as many entries as it has candidates at most (orders 0..2 over Nc allowed walls), and the lists of
+// all parts together must stay below 4 GiB, else nothing is cut.
+inline HeavyPlan heavy_plan(long long tiles, long long Nc, long long heavy_split, long long parts) {
+    HeavyPlan hp;
+    if (tiles <= 0 || Nc < 2 || heavy_split <= 0 || parts <= 0) return hp;
+    const long long H = heavy_split < tiles / 16 ? heavy_split : tiles / 16;
+    if (H <= 0) return hp;
+    const long long cap = ((Nc + parts - 1) / parts + 2) * Nc + Nc + 2;
+    // H * parts * cap * 64 * 4 bytes <= 4 GiB, evaluated without overflow
+    const long long limit = (4ll << 30) / (64 * (long long)sizeof(float));
+    if (cap <= 0 || H > limit / parts || H * parts > limit / cap) return hp;
+    hp.H = H;
+    hp.cap = cap;
+    hp.list_floats = H * parts * cap * 64;
+    hp.cnt_ints = H * parts * 64 + H * parts;
+    return hp;
+}
+
+}  // namespace d2d_host
