@@ -17,6 +17,7 @@
 #define D2D_AUX_KERNELS 1  // the non-template kernels are defined in this translation unit
 #include "d2d_launch.hpp"
 #include "d2d_host.hpp"
+#include "d2d_optgrad.hpp"
 
 // ---- mode dispatch of the sweep-kernel launchers (d2d_launch.hpp); the per-mode launchers live in the
 // d2d_sweep_tu objects, one per (kernel family, validity mode) ----
@@ -134,8 +135,9 @@ struct d2d_ctx {
     DevBuf<int> d_cw;
     DevBuf<unsigned char> d_kind;
     DevBuf<float2> d_sincos;
+    DevBuf<float4> d_xys;  // raw end points {origin, dest} (gradient sweeps of the optimiser-based solvers)
     // optimiser-based solvers
-    DevBuf<float> d_bc1, d_bc2, d_theta0, d_contrib;
+    DevBuf<float> d_bc1, d_bc2, d_theta0, d_contrib, d_gcontrib;
     bool opt_parallel = true;  // optimiser-based sweeps: candidates side by side (same results as one after the other)
     int bc_steps = -1;
     std::vector<float> theta0;  // [C][D2D_MAX_ORDER] as set by d2d_set_theta0
@@ -221,6 +223,8 @@ int upload_refl(d2d_ctx* c) {
     HIP_TRY(hipMemcpyAsync(c->d_flt.p, flt.data(), flt.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     if ((rc = c->d_kind.ensure((size_t)c->N + 1))) return rc;
     if ((rc = c->d_sincos.ensure((size_t)c->N + 1))) return rc;
+    if ((rc = c->d_xys.ensure((size_t)c->N + 1))) return rc;
+    if (c->N > 0) HIP_TRY(hipMemcpyAsync(c->d_xys.p, c->xys.data(), (size_t)c->N * sizeof(float4), hipMemcpyHostToDevice, c->stream));
     std::vector<float2> sc((size_t)c->N + 1);
     for (int j = 0; j < c->N; ++j) sc[(size_t)j] = make_float2(sinf(c->phi[j]), cosf(c->phi[j]));  // geometry.py:709-710
     HIP_TRY(hipMemcpyAsync(c->d_refl.p, refl.data(), refl.size() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
@@ -272,6 +276,7 @@ d2d::ObjTables obj_tables(d2d_ctx* c) {
     T.refl = c->d_refl.p;
     T.kind = c->d_kind.p;
     T.sincos = c->d_sincos.p;
+    T.xys = c->d_xys.p;
     T.N = c->N;
     return T;
 }
@@ -476,6 +481,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_cw.release();
     c->d_kind.release();
     c->d_sincos.release();
+    c->d_xys.release(); c->d_gcontrib.release();
     c->d_bc1.release(); c->d_bc2.release(); c->d_theta0.release(); c->d_contrib.release(); c->d_scand.release(); c->d_sorder.release();
     c->d_tcand.release(); c->d_torder.release(); c->d_ttx.release(); c->d_trx.release();
     c->d_txys_in.release(); c->d_tloss_in.release(); c->d_txys.release(); c->d_tloss.release();
@@ -623,7 +629,8 @@ int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t 
 }
 
 // MinPath / FermatPath sweep: explicit candidate list (these sweeps have few candidates), theta0 per candidate.
-static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx) {
+// grad_mode: 0 values; 1 + per-cell gradient; 2 + scene VJP (d2d_optgrad.hpp: tangents carried through the Adam loop).
+static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, int grad_mode) {
     int rc;
     if ((rc = set_device(c))) return rc;
     if ((rc = upload_occl(c, p->patch))) return rc;
@@ -672,6 +679,53 @@ static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx) {
     a.fun_id = p->fun_id;
     a.out_mode = p->out_mode;
     const unsigned blocks = (unsigned)((a.cells + 63) / 64);
+    if (grad_mode) {
+        // one (cell, candidate) per lane, the candidates side by side; value, per-cell gradient and VJP partial sums go
+        // through per-candidate scratch and are reduced in candidate order
+        if (C < 1 || C > 65535 || (long long)C * a.cells > (1ll << 28))
+            return fail(D2D_ERR_UNSUPPORTED, "%lld candidates x %lld cells exceed the gradient sweep's scratch (2^28 contributions)",
+                        (long long)C, (long long)a.cells);
+        const int n_elem = 5 * c->N + 2;  // [4N] object end points, [2] fixed end point, [N] phi
+        if (p->out_mode == D2D_OUT_ADD && !c->have_grad) return fail(D2D_ERR_STATE, "D2D_OUT_ADD needs a previous value+grad sweep on this grid");
+        if ((rc = c->d_contrib.ensure((size_t)C * (size_t)a.cells))) return rc;
+        if ((rc = c->d_gcontrib.ensure(2 * (size_t)C * (size_t)a.cells))) return rc;
+        if ((rc = c->d_grad.ensure(2 * (size_t)a.cells))) return rc;
+        d2d::OptGradArgs g;
+        memset(&g, 0, sizeof g);
+        g.s = a;
+        g.patch = p->patch;
+        g.cot = c->have_cot ? c->d_cot.p : nullptr;
+        g.contrib = c->d_contrib.p;
+        g.gcontrib = c->d_gcontrib.p;
+        g.partial = nullptr;
+        const size_t rows = (size_t)C * blocks;
+        if (grad_mode == 2) {
+            if ((rc = c->d_partial.ensure(rows * (size_t)n_elem))) return rc;
+            if ((rc = c->d_vjp.ensure((size_t)n_elem))) return rc;
+            g.partial = c->d_partial.p;
+            if (p->out_mode == D2D_OUT_OVERWRITE) c->have_vjp = false;
+        }
+        c->have_grad = true;
+        if (c->time_kernel) HIP_TRY(hipEventRecord(c->evk0, c->stream));
+        HIP_TRY(d2d::launch_opt_grad(g, dim3(blocks, (unsigned)C), (size_t)n_elem * sizeof(float), c->stream));
+        if (c->time_kernel) {
+            HIP_TRY(hipEventRecord(c->evk1, c->stream));
+            c->have_kernel_time = true;
+        }
+        HIP_TRY(d2d::launch_opt_grad_reduce(c->d_contrib.p, c->d_gcontrib.p, (int)C, a.cells, c->d_out.p, c->d_grad.p, p->out_mode, c->stream));
+        if (grad_mode == 2) {
+            if ((rc = join_comm(c, 2))) return rc;  // the previous step's all-reduce has finished with d_vjp
+            // a VJP accumulated over several transmitters (D2D_OUT_ADD) must come from sweeps of one kind: the image-method
+            // sweeps leave the phi part untouched
+            const int accumulate = (p->out_mode == D2D_OUT_ADD && c->have_vjp && c->vjp_has_phi) ? 1 : 0;
+            hipLaunchKernelGGL(d2d::vjp_reduce_kernel, dim3((unsigned)n_elem), dim3(256), 0, c->stream, c->d_partial.p, (long)rows, n_elem,
+                               c->d_vjp.p, accumulate);
+            HIP_TRY(hipGetLastError());
+            c->have_vjp = true;
+            c->vjp_has_phi = true;
+        }
+        return D2D_OK;
+    }
     // candidates side by side while the contributions fit a modest scratch buffer (and the grid's y dimension)
     const bool side_by_side = c->opt_parallel && C >= 2 && C <= 65535 && (long long)C * a.cells <= (1ll << 26);
     if (side_by_side) {
@@ -694,8 +748,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     if (!c->have_grid) return fail(D2D_ERR_STATE, "d2d_set_grid must come before a sweep");
     c->have_kernel_time = false;  // whatever this launch turns out to be, the previous launch's kernel time is stale
     if (p->solver == D2D_SOLVER_MINPATH || p->solver == D2D_SOLVER_FERMAT) {
-        if (d_stats || grad_mode) return fail(D2D_ERR_UNSUPPORTED, "the optimiser-based solvers have no stats / gradient kernels");
-        return opt_sweep_launch(c, p, tx);
+        if (d_stats) return fail(D2D_ERR_UNSUPPORTED, "the optimiser-based solvers have no instrumented build");
+        return opt_sweep_launch(c, p, tx, grad_mode);
     }
     if (p->solver != D2D_SOLVER_IMAGE) return fail(D2D_ERR_INVALID, "unknown solver %d", p->solver);
     if (p->max_order >= 1)

@@ -2179,6 +2179,7 @@ struct ObjTables {
     const float4* __restrict__ refl;         // [2N] {ox, oy, nx, ny}, {tx, ty, sq, |t|}
     const unsigned char* __restrict__ kind;  // [N] D2D_WALL / D2D_RIS / D2D_VERTEX
     const float2* __restrict__ sincos;       // [N] {sin(phi), cos(phi)} (RIS)
+    const float4* __restrict__ xys;          // [N] {origin.x, origin.y, dest.x, dest.y}: the raw end points (gradient sweeps)
     int N;
 };
 

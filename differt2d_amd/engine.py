@@ -197,8 +197,8 @@ class Context:
         self.set_cotangent(cotangent)
         self.launch_vg(make_params(**kw), tx, scene_vjp=True)
         value = self.get_map()
-        tx_bar, walls_bar = self.get_scene_vjp()
-        return {"value": value, "grad_rx": self.get_grad_rx(), "tx_bar": tx_bar, "walls_bar": walls_bar}
+        tx_bar, walls_bar, phi_bar = self.get_scene_vjp(with_phi=True)
+        return {"value": value, "grad_rx": self.get_grad_rx(), "tx_bar": tx_bar, "walls_bar": walls_bar, "phi_bar": phi_bar}
 
     def launch_stats(self, params: L.Params, tx) -> np.ndarray:
         """Runs the instrumented kernel build; returns the executed-work counters (include/d2d.h)."""

@@ -449,8 +449,7 @@ class Scene(Plottable):
         ctx = self._ctx()
         cands = None
         if self._solver_of(path_cls) != "image":
-            if want_grad:
-                raise L.D2DUnsupported(-4, "grad / value_and_grad are implemented for ImagePath only")
+            # (grad / value_and_grad: the derivative through the solver's Adam loop, reference optimize.py:83-97)
             cands = self.all_path_candidates(min_order, max_order, order=order, filter_objects=filter_objects)
         sextra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, cands or [], key)
         extra = {**extra, **sextra, "grid_role": L.GRID_RX if grid_is_rx else L.GRID_TX}
@@ -505,30 +504,38 @@ class Scene(Plottable):
 
     def receivers_grid_value_and_vjp(
         self, X, Y, fun: PathFun, fun_kwargs: Optional[Mapping] = None, *, cotangent=None, path_cls: type = ImagePath,
-        min_order: int = 0, max_order: int = 1, order: Optional[int] = None,
-        filter_objects: Optional[Callable[[Object], bool]] = None, **kwargs,
+        path_cls_kwargs: Optional[Mapping] = None, min_order: int = 0, max_order: int = 1, order: Optional[int] = None,
+        filter_objects: Optional[Callable[[Object], bool]] = None, key=None, **kwargs,
     ):
         """Reverse-mode sweep w.r.t. the SCENE parameters (what users of the reference obtain by wrapping the sweep
         in ``jax.value_and_grad``, e.g. examples/plot_power_optimize.py:78-93): for every transmitter returns
-        ``(name, dict(value=Z, grad_rx=dZ/drx, tx_bar=<cot, dZ/dtx>, objects_bar=<cot, dZ/dxys>[N,2,2]))`` where
-        ``cotangent`` (default ones, i.e. the gradient of ``Z.sum()``) has the grid's shape."""
+        ``(name, dict(value=Z, grad_rx=dZ/drx, tx_bar=<cot, dZ/dtx>, objects_bar=<cot, dZ/dxys>[N,2,2],
+        phi_bar=<cot, dZ/dphi>[N]))`` where ``cotangent`` (default ones, i.e. the gradient of ``Z.sum()``) has the grid's
+        shape.  ``objects_bar[j]`` of a ``Vertex`` carries the gradient w.r.t. its point in row 0; ``phi_bar`` is non-zero
+        for ``RIS`` objects only (``path_cls=MinPath`` / ``FermatPath``: the derivative goes through the solver's Adam loop,
+        reference optimize.py:83-97; pass ``path_cls_kwargs`` / ``key`` as for the sweep)."""
         X = np.ascontiguousarray(X, dtype=F)
         Y = np.ascontiguousarray(Y, dtype=F)
-        native, common = self._sweep_params(fun, (), fun_kwargs, path_cls, None, min_order, max_order, order, kwargs)
+        native, common = self._sweep_params(fun, (), fun_kwargs, path_cls, path_cls_kwargs, min_order, max_order, order, kwargs)
         if native is None:
             raise L.D2DUnsupported(-4, "the scene VJP needs a natively fused fun (differt2d_amd.utils)")
-        if self._solver_of(path_cls) != "image":
-            raise L.D2DUnsupported(-4, "the scene VJP is implemented for ImagePath only")
-        common["solver"] = "image"
         name, extra = native
         ctx = self._ctx()
+        cands = None
+        if self._solver_of(path_cls) != "image":
+            cands = self.all_path_candidates(min_order, max_order, order=order, filter_objects=filter_objects)
+        sextra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, cands or [], key)
+        extra = {**extra, **sextra}
         for tx_name, tx in self.transmitters.items():
             self._upload(ctx, filter_objects)
             ctx.set_grid(X, Y)
             ctx.set_cotangent(cotangent)
+            if theta0 is not None:
+                ctx.set_theta0(theta0)
             ctx.launch_vg(make_params(fun=name, **extra, **common), tx.xy, scene_vjp=True)
-            tx_bar, objects_bar = ctx.get_scene_vjp()
-            yield tx_name, {"value": ctx.get_map(), "grad_rx": ctx.get_grad_rx(), "tx_bar": tx_bar, "objects_bar": objects_bar}
+            tx_bar, objects_bar, phi_bar = ctx.get_scene_vjp(with_phi=True)
+            yield tx_name, {"value": ctx.get_map(), "grad_rx": ctx.get_grad_rx(), "tx_bar": tx_bar, "objects_bar": objects_bar,
+                            "phi_bar": phi_bar}
 
     def accumulate_on_transmitters_grid_over_paths(
         self, X, Y, fun: PathFun, fun_args: tuple = (), fun_kwargs: Optional[Mapping] = None, *, reduce_all: bool = False,

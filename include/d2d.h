@@ -165,7 +165,9 @@ int d2d_power_map_launch(d2d_ctx* ctx, const d2d_params* params, const float* tx
  * sum(Z)). Reset by d2d_set_grid. */
 int d2d_set_cotangent(d2d_ctx* ctx, const float* cot);
 
-/* Fused value+grad sweep (hand-derived reverse mode, no autodiff): writes the value map exactly as
+/* Value+grad sweep.  ImagePath: fused, hand-derived reverse mode.  MinPath / FermatPath (differt2d/geometry.py:1117-1288):
+ * the derivative of the reference's lax.scan of Adam steps (differt2d/optimize.py:83-97) carried forward as tangents
+ * through the same loop (d2d_optgrad.hpp), for Wall, RIS (incl. phi, geometry.py:698-711) and Vertex objects.  Writes the value map exactly as
  * d2d_power_map_launch does, the per-cell gradient d Z[i,j] / d rx[i,j] (resident, [m][n][2]) and, when
  * want_scene_vjp != 0, the VJP of the map w.r.t. the transmitter position and every object end point,
  * contracted with the cotangent. out_mode D2D_OUT_ADD accumulates all of them (reduce_all). Asynchronous. */

@@ -116,12 +116,15 @@ class TorchBackend:
 
     name = "torch"
 
-    def __init__(self, dtype="float32"):
+    def __init__(self, dtype="float32", diff_solver=False):
         import torch
 
         self.torch = torch
         self.tdtype = getattr(torch, dtype)
         self.eps = torch.finfo(self.tdtype).eps
+        # True: MinPath / FermatPath keep the autograd graph through every Adam step (the reference differentiates
+        # through its lax.scan, optimize.py:83-97); False: the solver's result is a constant of the outer graph
+        self.diff_solver = diff_solver
 
     def c(self, x):
         return self.torch.tensor(x, dtype=self.tdtype)
@@ -779,6 +782,8 @@ def opt_path(solver, tx, objs, rx, theta0, steps, xp=NUMPY):
     n = len(objs)
     if n == 0:
         return [tx, rx], xp.c(0.0) * X(rx)
+    if getattr(xp, "diff_solver", False):
+        return opt_path_diff(solver, tx, objs, rx, theta0, steps, xp)
     tb = TorchBackend("float32" if getattr(xp, "dtype", None) == np.float32 or xp.name == "torch" else "float64")
     n_unknowns = sum(o.parameters_count() for o in objs)
     batch = np.broadcast_shapes(np.shape(X(tx)), np.shape(X(rx)))
@@ -809,6 +814,32 @@ def opt_path(solver, tx, objs, rx, theta0, steps, xp=NUMPY):
     pts = [_bcast(p, batch, xp) for p in pts]
     loss = xp.asarray(loss.detach().numpy()) if xp.name == "numpy" else loss
     return pts, loss
+
+
+def opt_path_diff(solver, tx, objs, rx, theta0, steps, tb):
+    """opt_path with the autograd graph kept through every Adam step: jax.value_and_grad inside the scan becomes
+    torch.autograd.grad(..., create_graph=True), so that reverse mode through the whole solve gives what the reference's
+    reverse mode through lax.scan gives (optimize.py:83-97).  ``tx`` / ``rx`` / ``objs`` hold torch tensors."""
+    import torch
+
+    n_unknowns = sum(o.parameters_count() for o in objs)
+    batch = torch.broadcast_shapes(X(tx).shape, X(rx).shape)
+
+    def loss_of(pts):
+        return path_length(pts, tb) if solver == "fermat" else path_loss(objs, pts, tb)
+
+    def vg(x):
+        pts = parametric_to_cartesian(objs, x, tx, rx, tb)
+        loss = loss_of(pts)
+        loss = loss + 0 * sum(x) if n_unknowns else loss
+        g = torch.autograd.grad(loss.sum(), x, create_graph=True) if n_unknowns else []
+        return loss, list(g)
+
+    x0 = [torch.full(tuple(batch), float(theta0[i]), dtype=tb.tdtype).requires_grad_(True) for i in range(n_unknowns)]
+    x, last_loss = adam_minimize(vg, x0, steps=steps, xp=tb)
+    pts = parametric_to_cartesian(objs, x, tx, rx, tb)
+    loss = path_loss(objs, pts, tb) if solver == "fermat" else last_loss  # geometry.py:1204 / :1284-1288
+    return [p.expand(*batch, 2) for p in pts], loss
 
 
 def _np(x):
@@ -1018,3 +1049,31 @@ def power_map_value_and_grads_batched(walls, tx, Xg, Yg, cotangent=None, dtype="
         if gw is not None:
             walls_bar += gw.detach().numpy()
     return {"value": value.reshape(shape), "grad_rx": grad.reshape(*shape, 2), "tx_bar": tx_bar, "walls_bar": walls_bar}
+
+
+def opt_value_and_grads(kinds, xys, phis, tx, Xg, Yg, cands, theta0s, solver="min", steps=100, cotangent=None,
+                        dtype="float64", grid_role="rx", **kwargs):
+    """Value map and reverse-mode gradients of a MinPath / FermatPath sweep over a scene of Wall / RIS / Vertex objects
+    (BASELINE.json configs[4]), differentiating THROUGH the Adam loop like the reference does (optimize.py:83-97).
+
+    ``kinds[N]`` (WALL / RIS / VERTEX), ``xys[N, 2, 2]`` (a Vertex keeps its point in row 0), ``phis[N]``; ``cands``: list of
+    index arrays; ``theta0s``: one list of initial guesses per candidate.  Returns dict(value[m, n], grad_cell[m, n, 2],
+    fixed_bar[2], xys_bar[N, 2, 2], phi_bar[N]) -- the last three contracted with ``cotangent`` (default ones)."""
+    import torch
+
+    tb = TorchBackend(dtype, diff_solver=True)
+    w = tb.asarray(np.asarray(xys)).clone().requires_grad_(True)
+    ph = tb.asarray(np.asarray(phis)).clone().requires_grad_(True)
+    t = tb.asarray(np.asarray(tx)).clone().requires_grad_(True)
+    gx = tb.asarray(np.asarray(Xg)).clone().requires_grad_(True)
+    gy = tb.asarray(np.asarray(Yg)).clone().requires_grad_(True)
+    objs = [Obj(int(k), w[j, 0] if int(k) == VERTEX else w[j], ph[j]) for j, k in enumerate(kinds)]
+    grid = vec(gx, gy, tb)
+    a, b = (t, grid) if grid_role == "rx" else (grid, t)
+    Z = facc(a, objs, cands, b, solver=solver, xp=tb, theta0s=theta0s, steps=steps, **kwargs)
+    ct = torch.ones_like(Z) if cotangent is None else tb.asarray(np.asarray(cotangent))
+    gw, gp, gt = torch.autograd.grad((Z * ct).sum(), [w, ph, t], retain_graph=True, allow_unused=True)
+    ggx, ggy = torch.autograd.grad(Z.sum(), [gx, gy], allow_unused=True)
+    z = lambda g, ref: (torch.zeros_like(ref) if g is None else g).detach().numpy()
+    return {"value": Z.detach().numpy(), "grad_cell": np.stack([z(ggx, gx), z(ggy, gy)], axis=-1), "fixed_bar": z(gt, t),
+            "xys_bar": z(gw, w), "phi_bar": z(gp, ph)}

@@ -199,3 +199,149 @@ def test_candidates_side_by_side_equal_one_after_the_other(path_cls_name):
     finally:
         ctx.set_option("opt_parallel", 1)
     assert np.array_equal(a, b, equal_nan=True) and np.isfinite(a).all() and (a > 0).any()
+
+
+# ---- short-horizon parity of the solver itself (pin the hand-derived theta-gradient and the Adam update
+# exactly rather than statistically): the interaction points after 1, 10 and 50 steps from the same theta0 -----------------
+
+
+def _scene_tables(scene):
+    from differt2d_amd.geometry import objects_to_tables
+
+    return objects_to_tables(scene.objects)
+
+
+@pytest.mark.parametrize("solver", ["min", "fermat"])
+@pytest.mark.parametrize("steps", [1, 10, 50])
+def test_solver_trajectory_matches_oracle_after_few_steps(solver, steps):
+    """After `steps` Adam iterations from the same theta0 the interaction points agree with the oracle's (autodiff gradient
+    of the objective, same Adam update) to 1e-6 absolute (coordinates are O(1)): the hand-derived d objective / d theta and
+    the update rule are right; the long-horizon differences of test_ris_vertex_sweep_matches_oracle are amplified rounding."""
+    from differt2d_amd.engine import default_context, make_params
+    from oracle import ref as R
+
+    scene = _ris_scene()
+    xys, kind, phi = _scene_tables(scene)
+    objs = _oracle_objs(scene)
+    # order 1 over Wall / RIS / Vertex, and two order-2 candidates mixing kinds
+    cands = [np.array(c, np.int32) for c in ([0], [1], [2], [3], [4], [5], [0, 4], [4, 1], [3, 5], [2, 0, 4])]
+    rng = np.random.default_rng(11)
+    theta0 = [rng.random(sum(objs[int(i)].parameters_count() for i in c), dtype=F) for c in cands]
+    tx = np.array([[0.2, 0.2], [0.31, 0.77], [0.9, 0.12]], F)
+    rx = np.array([[0.8, 0.6], [0.62, 0.18], [0.15, 0.85]], F)
+    ctx = default_context()
+    ctx.set_scene(xys, kind, phi)
+    p = make_params(min_order=0, max_order=4, solver=solver, steps=steps, approx=True)
+    got = ctx.trace_paths(p, tx, rx, cands, theta0=[np.pad(t, (0, 4 - len(t))) for t in theta0])
+    worst = 0.0
+    for ci, c in enumerate(cands):
+        inter = [objs[int(i)] for i in c]
+        pts, loss = R.opt_path(solver, tx, inter, rx, theta0[ci], steps, R.NUMPY)
+        want = np.stack(pts, axis=1)  # (P, k + 2, 2)
+        g = got["xys"][:, ci, : len(c) + 2]
+        worst = max(worst, float(np.abs(g - want).max()))
+        np.testing.assert_allclose(g, want, rtol=0, atol=1e-6, err_msg=f"candidate {c.tolist()} after {steps} steps")
+        np.testing.assert_allclose(got["loss"][:, ci], np.broadcast_to(loss, (3,)), rtol=1e-4, atol=1e-6)
+    print(f"{solver} {steps} steps: max |points - oracle| = {worst:.2e}")
+
+
+# ---- gradients THROUGH the solver (BASELINE.json configs[4]: "grad w.r.t. RIS vertices") -----------------------------
+
+
+def _opt_case(steps, solver, approx, grid=(7, 5), role="rx", seed=3):
+    scene = _ris_scene()
+    xys, kind, phi = _scene_tables(scene)
+    objs = _oracle_objs(scene)
+    x = np.linspace(0.07, 0.93, grid[0]).astype(F)
+    y = np.linspace(0.11, 0.89, grid[1]).astype(F)
+    X, Y = np.meshgrid(x, y)
+    cands = scene.all_path_candidates(min_order=0, max_order=1)
+    rng = np.random.default_rng(seed)
+    theta0 = [rng.random(sum(objs[int(i)].parameters_count() for i in c), dtype=F) for c in cands]
+    return scene, xys, kind, phi, X, Y, cands, theta0
+
+
+def _gpu_opt_grads(xys, kind, phi, tx, X, Y, cands, theta0, cot, **kw):
+    from differt2d_amd.engine import default_context
+
+    ctx = default_context()
+    ctx.set_scene(xys, kind, phi)
+    ctx.set_theta0([np.pad(np.asarray(t, F), (0, 4 - len(t))) for t in theta0])
+    return ctx.value_and_grads(tx, X, Y, cotangent=cot, **kw)
+
+
+@pytest.mark.parametrize("solver,steps", [("min", 30), ("min", 200), ("fermat", 60)])
+@pytest.mark.parametrize("approx", [False, True])
+@pytest.mark.parametrize("role", ["rx", "tx"])
+def test_gradients_through_the_solver_match_autodiff_of_the_oracle(solver, steps, approx, role):
+    """Value, per-cell gradient and the scene VJP (fixed end point, every object's end points incl. the RIS's and the
+    diffraction vertices', the RIS's phi) of a MinPath / FermatPath sweep against reverse-mode autodiff of the oracle
+    through its Adam loop (oracle/ref.py: opt_value_and_grads, torch double backward, fp64)."""
+    from differt2d_amd import _lib as L
+    from oracle import ref as R
+
+    scene, xys, kind, phi, X, Y, cands, theta0 = _opt_case(steps, solver, approx, role=role)
+    tx = scene.transmitters["tx"].xy
+    rng = np.random.default_rng(5)
+    cot = (rng.random(X.shape) + 0.5).astype(F)
+    kw = dict(min_order=0, max_order=1, approx=approx)
+    want = R.opt_value_and_grads(kind, xys, phi, tx, X, Y, cands, theta0, solver=solver, steps=steps, cotangent=cot,
+                                 dtype="float64", grid_role=role, **({"approx": approx}))
+    got = _gpu_opt_grads(xys, kind, phi, tx, X, Y, cands, theta0, cot, solver=solver, steps=steps,
+                         grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw)
+    # the value map of the gradient sweep is the forward sweep's, bit for bit
+    from differt2d_amd.engine import default_context
+
+    fwd = default_context().power_map(tx, X, Y, solver=solver, steps=steps, grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw)
+    assert np.array_equal(got["value"], fwd, equal_nan=True)
+    scale_v = np.abs(want["value"]).max()
+    # cells where the fp32 solver and the fp64 oracle landed on the same solution (see test_ris_vertex_sweep_matches_oracle)
+    stable = np.isclose(got["value"], want["value"], rtol=2e-3, atol=2e-3 * scale_v)
+    assert stable.mean() >= 0.8
+    g, w = got["grad_rx"][stable], want["grad_cell"][stable]
+    fin = np.isfinite(w).all(-1)
+    assert fin.mean() > 0.9
+    gs = np.abs(w[fin]).max()
+    err = np.abs(g[fin] - w[fin])
+    print(f"{solver} {steps} {role} approx={approx}: per-cell grad max err/scale {err.max() / gs:.2e}, median {np.median(err) / gs:.2e}, scale {gs:.3g}")
+    assert np.quantile(err, 0.9) <= 2e-3 * gs and err.max() <= 5e-2 * gs
+    if stable.all():
+        for k_got, k_want in (("tx_bar", "fixed_bar"), ("walls_bar", "xys_bar"), ("phi_bar", "phi_bar")):
+            a, b = np.asarray(got[k_got], np.float64), np.asarray(want[k_want], np.float64)
+            s = max(np.abs(b).max(), 1e-12)
+            print(f"   {k_got}: max err/scale {np.abs(a - b).max() / s:.2e} (scale {s:.3g})")
+            np.testing.assert_allclose(a, b, rtol=5e-3, atol=5e-3 * s, err_msg=k_got)
+    if solver == "min" and approx:
+        assert np.abs(want["phi_bar"][4]) > 0 and not want["phi_bar"][[0, 1, 2, 3, 5, 6]].any()  # only the RIS has a phi
+
+
+def test_scene_mirror_exposes_the_solver_gradients():
+    """Scene.accumulate_on_receivers_grid_over_paths(path_cls=MinPath, value_and_grad=True) and the scene VJP incl. phi_bar
+    (what jax.grad w.r.t. the RIS's vertices / phi returns in the reference) through the Python mirror."""
+    from differt2d_amd.geometry import MinPath
+    from differt2d_amd.utils import received_power
+
+    scene = _ris_scene()
+    X, Y = scene.grid(m=9, n=6)
+    X, Y = X * F(0.9) + F(0.05), Y * F(0.9) + F(0.05)
+    cands = scene.all_path_candidates(order=1)
+    theta0 = [np.full(sum(o.parameters_count() for o in scene.get_interacting_objects(c)), 0.4, F) for c in cands]
+    kw = dict(fun=received_power, path_cls=MinPath, order=1, approx=True, path_cls_kwargs={"steps": 40, "theta0": theta0})
+    Z, dZ = scene.accumulate_on_receivers_grid_over_paths(X, Y, reduce_all=True, value_and_grad=True, **kw)
+    Z0 = scene.accumulate_on_receivers_grid_over_paths(X, Y, reduce_all=True, **kw)
+    assert np.array_equal(Z, Z0) and dZ.shape == (*X.shape, 2) and np.isfinite(dZ).mean() > 0.9 and np.abs(dZ[np.isfinite(dZ)]).max() > 0
+    (name, out), = list(scene.receivers_grid_value_and_vjp(X, Y, **kw))
+    assert np.array_equal(out["value"], Z0) and out["objects_bar"].shape == (7, 2, 2) and out["phi_bar"].shape == (7,)
+    assert out["phi_bar"][4] != 0 and not out["phi_bar"][[0, 1, 2, 3, 5, 6]].any()
+    assert np.abs(out["objects_bar"][4]).max() > 0  # d sum(P) / d (RIS vertices)
+    # finite difference of sum(Z) w.r.t. phi, through the forward sweep only (fp32: loose)
+    from differt2d_amd.geometry import RIS
+
+    def total(phi):
+        ris = RIS(xys=[[0.5, 0.3], [0.5, 0.7]], phi=phi)
+        sc = scene.with_objects(*scene.objects[:4], ris, *scene.objects[5:])
+        return float(sc.accumulate_on_receivers_grid_over_paths(X, Y, reduce_all=True, **kw).astype(np.float64).sum())
+
+    h = 2e-3
+    fd = (total(np.pi / 4 + h) - total(np.pi / 4 - h)) / (2 * h)
+    assert abs(fd - out["phi_bar"][4]) <= 0.05 * abs(fd) + 1e-3, (fd, out["phi_bar"][4])
