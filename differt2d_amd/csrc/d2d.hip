@@ -311,6 +311,9 @@ int adam_cfg(d2d_ctx* c, const d2d_params* p, d2d::AdamCfg* A) {
     A->b1 = 0.9f;
     A->b2 = 0.999f;
     A->eps = 1e-8f;
+    // optax.scale_by_adam: (1 - decay) is a Python float (double arithmetic) multiplied into an fp32 array
+    A->omb1 = (float)(1.0 - 0.9);
+    A->omb2 = (float)(1.0 - 0.999);
     return D2D_OK;
 }
 

@@ -2362,6 +2362,7 @@ struct AdamCfg {
     const float* __restrict__ bc1;  // [steps] 1 - b1^t
     const float* __restrict__ bc2;  // [steps] 1 - b2^t
     float lr, b1, b2, eps;
+    float omb1, omb2;  // 1 - b1, 1 - b2 evaluated in double precision and rounded (optax: Python floats, weakly typed)
 };
 
 __device__ __forceinline__ void theta_to_points(const ObjTables& T, int k, const int (&cd)[D2D_MAX_ORDER],
@@ -2510,8 +2511,8 @@ __device__ __forceinline__ float opt_run(const ObjTables& T, const AdamCfg& A, i
 #pragma unroll
         for (int q = 0; q < D2D_MAX_ORDER; ++q) {
             if (q < nu_) {
-                mu[q] = A.b1 * mu[q] + (1.0f - A.b1) * g[q];
-                nu[q] = A.b2 * nu[q] + (1.0f - A.b2) * (g[q] * g[q]);
+                mu[q] = A.b1 * mu[q] + A.omb1 * g[q];
+                nu[q] = A.b2 * nu[q] + A.omb2 * (g[q] * g[q]);
                 float mh = mu[q] / c1, nh = nu[q] / c2;
                 th[q] = th[q] + (-A.lr) * (mh / (sqrtf(nh) + A.eps));
             }

@@ -433,8 +433,8 @@ __device__ __forceinline__ Dual<B> dopt_run(const AdamCfg& A, const DObj<B> (&ob
 #pragma unroll
         for (int q = 0; q < KK; ++q) {
             if (q < nu_) {
-                mu[q] = A.b1 * mu[q] + (1.0f - A.b1) * g[q];
-                nu[q] = A.b2 * nu[q] + (1.0f - A.b2) * (g[q] * g[q]);
+                mu[q] = A.b1 * mu[q] + A.omb1 * g[q];
+                nu[q] = A.b2 * nu[q] + A.omb2 * (g[q] * g[q]);
                 const Dual<B> mh = mu[q] / c1, nh = nu[q] / c2;
                 th[q] = th[q] + (-A.lr) * (mh / (dsqrt(nh) + A.eps));
             }

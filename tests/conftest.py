@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """libd2d.so must bind the SYSTEM libamdhip64: torch (imported by the autodiff oracle) bundles its own copy under the
+    same SONAME, and a process that loads torch's first reports "no ROCm-capable device" to libd2d afterwards.  Load the
+    library and initialise the HIP runtime before any test gets to import torch, whatever the test order or -k selection."""
+    try:
+        from differt2d_amd import _lib
+
+        if os.path.exists(_lib.LIB_PATH):
+            _lib.device_count()
+    except Exception:  # noqa: BLE001 -- CPU box without the library built yet: the tests that need it say so themselves
+        pass
+
+
 def random_scene(n_walls: int, seed: int = 1234):
     """Layout of Scene.random_uniform_scene (reference scene.py:718-733) with a NumPy PRNG
     (jax.random is unavailable): pts[0] = tx, wall i = pts[1+2i : 3+2i]."""
