@@ -174,6 +174,16 @@ struct d2d_ctx {
     DevBuf<float> d_heavy_list;
     DevBuf<int> d_heavy_cnt, d_heavy_done;
     long long heavy_done_n = 0;
+    // region candidate lists (region_list_kernel), rebuilt by every culled RX-grid launch of max_order >= 2
+    bool use_region_lists = true;
+    long long region_size = 4;         // a region is region_size x region_size patches
+    long long region_slices = 0;       // slices of first walls per region (0: chosen from the number of allowed walls)
+    long long region_budget_mb = 1024; // device memory the lists of one launch may take
+    DevBuf<unsigned long long> d_rl_codes[D2D_MAX_ORDER + 1];
+    DevBuf<int> d_rl_cnt[D2D_MAX_ORDER + 1];
+    DevBuf<d2d::RegionLists> d_rl;     // the descriptor the sweep kernels read
+    d2d::RegionLists rl_host;          // what d_rl holds
+    bool rl_host_valid = false;
     // RCCL (one communicator per ctx, collectives run on the ctx stream)
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -495,6 +505,8 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_stats.release();
     c->d_shadow.release();
     c->d_sched.release();
+    for (int k = 0; k <= D2D_MAX_ORDER; ++k) { c->d_rl_codes[k].release(); c->d_rl_cnt[k].release(); }
+    c->d_rl.release();
     c->d_sched_key.release();
     c->d_sched_override.release();
     c->d_cost.release();
@@ -886,6 +898,41 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             a.pair_prefix_ok = (a.pair && pair_ext_ok && a.shadow_prefix_ok) ? 1 : 0;
         }
     }
+    // region candidate lists (orders >= 2): the culled RX-grid kernels (forward, instrumented, value+grad) read them
+    a.rl = nullptr;
+    if (!txg && c->use_region_lists && p->max_order >= 2 && c->cw.size() >= 2 && c->N <= 4095 && !(grad_mode && p->strict_nan)) {
+        const d2d_host::RegionPlan rp = d2d_host::region_plan(tiles_x, tiles_y, (long long)c->cw.size(), p->min_order, p->max_order,
+                                                             (int)c->region_size, (int)c->region_slices, c->region_budget_mb << 20, d2d::HEAVY_PARTS);
+        const size_t lds_l = (size_t)(3 * c->N + 1) * sizeof(float4) + 512;
+        if (rp.on && lds_l <= d2d_host::LDS_LIMIT) {
+            d2d::RegionLists rl;
+            memset(&rl, 0, sizeof rl);
+            rl.S = rp.S;
+            rl.R = rp.R;
+            rl.regions_x = rp.regions_x;
+            rl.regions_y = rp.regions_y;
+            const size_t slots = (size_t)rp.regions * rp.S;
+            for (int k = 2; k <= p->max_order; ++k) {
+                if (rp.cap[k] <= 0) continue;
+                if ((rc = c->d_rl_codes[k].ensure(slots * (size_t)rp.cap[k]))) return rc;
+                if ((rc = c->d_rl_cnt[k].ensure(slots))) return rc;
+                rl.codes[k] = c->d_rl_codes[k].p;
+                rl.cnt[k] = c->d_rl_cnt[k].p;
+                rl.cap[k] = (int)rp.cap[k];
+            }
+            if ((rc = c->d_rl.ensure(1))) return rc;
+            if (!c->rl_host_valid || std::memcmp(&rl, &c->rl_host, sizeof rl) != 0) {
+                c->rl_host = rl;  // (the copy reads rl_host: it stays valid after this call returns)
+                c->rl_host_valid = true;
+                HIP_TRY(hipMemcpyAsync(c->d_rl.p, &c->rl_host, sizeof rl, hipMemcpyHostToDevice, c->stream));
+            }
+            d2d::SweepArgs al = a;
+            al.cullq_off = (int)((size_t)(3 * c->N + 1) * sizeof(float4));
+            for (int k = (p->min_order > 2 ? p->min_order : 2); k <= p->max_order; ++k)
+                HIP_TRY(d2d::launch_region_lists(k, grad_mode != 0, dim3((unsigned)slots), lds_l, c->stream, al, rl));
+            a.rl = c->d_rl.p;
+        }
+    }
     // dearest-first patch schedule for the culled kernels
     a.sched = nullptr;
     a.n_heavy = 0;
@@ -1119,6 +1166,17 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "pair_masks")) c->use_pair_masks = value != 0;
     else if (!strcmp(name, "opt_parallel")) c->opt_parallel = value != 0;
     else if (!strcmp(name, "txg_exhaustive")) c->txg_exhaustive = value != 0;
+    else if (!strcmp(name, "region_lists")) c->use_region_lists = value != 0;
+    else if (!strcmp(name, "region_size")) {
+        if (value < 1 || value > 64) return fail(D2D_ERR_INVALID, "region_size must lie in 1..64, got %lld", (long long)value);
+        c->region_size = value;
+    } else if (!strcmp(name, "region_slices")) {
+        if (value < 0 || value > 1024) return fail(D2D_ERR_INVALID, "region_slices must lie in 0..1024, got %lld", (long long)value);
+        c->region_slices = value;
+    } else if (!strcmp(name, "region_budget_mb")) {
+        if (value < 1 || value > (64ll << 10)) return fail(D2D_ERR_INVALID, "region_budget_mb must lie in 1..65536, got %lld", (long long)value);
+        c->region_budget_mb = value;
+    }
     else return fail(D2D_ERR_INVALID, "d2d_set_option: unknown option '%s'", name);
     return D2D_OK;
 }

@@ -167,4 +167,52 @@ inline HeavyPlan heavy_plan(long long tiles, long long Nc, long long heavy_split
     return hp;
 }
 
+// ---- region candidate lists (region_list_kernel) ------------------------------------------------------------------
+struct RegionPlan {
+    bool on = false;
+    int R = 0, S = 0;                         // region = R x R patches; S slices of first walls per region
+    int regions_x = 0, regions_y = 0;
+    long long regions = 0;
+    long long cap[D2D_MAX_ORDER + 1] = {0};  // list entries per (region, slice) of order k (0: no list for that order)
+};
+// Lists exist for the orders k in [max(2, min_order), max_order].  A slice never holds more than
+// (ceil(Nc / S) + 1) * (Nc - 1)^(k-1) candidates; the capacity is that bound or what `budget_bytes / orders` allows,
+// whichever is smaller (a list that overflows is marked as not listed and its patches enumerate).  S is a multiple of
+// `parts` (the waves / quarters that share a patch take whole slices).
+inline RegionPlan region_plan(int tiles_x, int tiles_y, long long Nc, int min_order, int max_order, int R, int S_req, long long budget_bytes,
+                              int parts) {
+    RegionPlan rp;
+    if (tiles_x <= 0 || tiles_y <= 0 || Nc < 2 || max_order < 2 || R <= 0 || parts <= 0 || budget_bytes <= 0) return rp;
+    int S = S_req > 0 ? S_req : (int)(parts * ((Nc + 49) / 50));
+    S = ((S + parts - 1) / parts) * parts;
+    if (S > 1024) S = (1024 / parts) * parts;
+    if (S <= 0) return rp;
+    rp.R = R;
+    rp.S = S;
+    rp.regions_x = (tiles_x + R - 1) / R;
+    rp.regions_y = (tiles_y + R - 1) / R;
+    rp.regions = (long long)rp.regions_x * rp.regions_y;
+    const long long slots = rp.regions * S;
+    if (slots <= 0 || slots > 0x7fffffffLL) return rp;
+    const int k0 = min_order > 2 ? min_order : 2;
+    const int orders = max_order - k0 + 1;
+    if (orders <= 0) return rp;
+    const long long per_order = budget_bytes / orders / (long long)sizeof(unsigned long long);
+    const long long cap_budget = per_order / slots;
+    if (cap_budget < 64) return rp;  // not worth having
+    for (int k = k0; k <= max_order; ++k) {
+        long long full = (Nc + S - 1) / S + 1;
+        for (int i = 1; i < k; ++i) {
+            if (full > cap_budget) break;
+            full *= (Nc - 1);
+        }
+        long long cap = full < cap_budget ? full : cap_budget;
+        cap = (cap + 63) / 64 * 64;
+        if (cap > 0x7fffffffLL / 2) cap = (0x7fffffffLL / 2) / 64 * 64;
+        rp.cap[k] = cap;
+    }
+    rp.on = true;
+    return rp;
+}
+
 }  // namespace d2d_host

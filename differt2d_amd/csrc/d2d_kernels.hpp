@@ -33,7 +33,20 @@ namespace d2d {
 
 enum Mode { MODE_HARD = 0, MODE_HSIG = 1, MODE_SIG = 2 };
 
+// Region candidate lists (region_list_kernel): for every order K >= 2, every region of R x R patches and every slice of
+// first-wall positions, the candidates that the tile culling cannot prove invalid for the region's bounding box, in
+// candidate order.  The patches of the region then test and evaluate those instead of enumerating all prefixes themselves.
+struct RegionLists {
+    unsigned long long* codes[D2D_MAX_ORDER + 1];  // [K]: [regions][S][cap[K]]; 12 bits per wall index, first wall lowest; bit 60: see sweep_order_culled
+    int* cnt[D2D_MAX_ORDER + 1];                   // [K]: [regions][S] entries of the slice's list; < 0: not listed (overflow, non-finite cell): enumerate
+    int cap[D2D_MAX_ORDER + 1];
+    int S;                     // slices of first-wall positions (first_wall_range(s, S)); a multiple of HEAVY_PARTS and SPLIT_W
+    int R;                     // a region is R x R patches
+    int regions_x, regions_y;
+};
+
 struct SweepArgs {
+    const RegionLists* __restrict__ rl;  // device copy of the lists' descriptor, or null: every patch enumerates for itself
     // scene tables (device, read-only, wave-uniform indexing -> scalar loads)
     const float4* __restrict__ occl;  // [N]  {p1x, p1y, Ax, Ay}: patched origin and P2-P1 (geometry.py:632-636)
     const float4* __restrict__ refl;  // [2N] {ox, oy, nx, ny}, {tx, ty, sq, 0}: reflection data
@@ -1000,15 +1013,25 @@ struct ListSink {
     }
 };
 
+// Survivors of a region's culling, in candidate order (region_list_kernel).
+struct EmitSink {
+    unsigned long long* dst;
+    int n;    // survivors so far (may exceed cap: the list is then marked as not listed)
+    int cap;
+};
+
 // All candidates of order K >= 1 with tile culling; `tab` = LDS copy of {refl[2N], flt[N]}.
 // K >= 2: only the prefixes whose FIRST position lies in [p_lo, p_hi) (positions into cw[]).  LIST: instead of being
 // added to acc, every contribution that is not exactly zero is appended to `sink` (adding an exact zero never changes
 // acc: acc is never -0.0), so that another wave can add them later in the reference's order.
-template <int K, int MODE, bool STATS, bool GRAD = false, bool LIST = false>
+// EMIT (K >= 2): nothing is evaluated; the survivors of the full culling test are appended to `emit` instead (the box is
+// then a region's, not a patch's).
+template <int K, int MODE, bool STATS, bool GRAD = false, bool LIST = false, bool EMIT = false>
 __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                    const float (&by)[4], float rxx, float rxy, bool lane_bad, float& acc,
                                                    WaveStats& st, GradCtx* g = nullptr, int p_lo = 0,
-                                                   int p_hi = 0x7fffffff, ListSink* sink = nullptr) {
+                                                   int p_hi = 0x7fffffff, ListSink* sink = nullptr, EmitSink* emit = nullptr) {
+    static_assert(!EMIT || K >= 2, "lists exist for orders >= 2");
     const int lane = threadIdx.x & 63;
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
     float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];
@@ -1086,8 +1109,16 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         unsigned long long mask = __ballot(alive2);
         if (STATS) st.c[9] += K;
         D2D_WORK(5 * K);
+        if constexpr (EMIT) {
+            if (alive2) {
+                const int at = emit->n + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                if (at < emit->cap) emit->dst[at] = code;
+            }
+            emit->n += __builtin_popcountll(mask);
+            mask = 0ull;
+        }
         const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-        while (mask) {
+        if constexpr (!EMIT) while (mask) {
             const int b = __builtin_ctzll(mask);
             mask &= mask - 1;
             const unsigned long long cb = cullq[b];
@@ -1314,6 +1345,111 @@ __device__ __forceinline__ void first_wall_range(const SweepArgs& a, int part, i
     hi = (part == parts - 1) ? Nc : boundary((int)(((long)A * (part + 1)) / parts));
 }
 
+// Order K >= 2 from the region's candidate lists (slices [s_lo, s_hi) of first walls): 64 entries at a time, lanes =
+// candidates: the full tile-culling test against the PATCH, then the survivors are evaluated exactly in list order (= the
+// reference's order).  A slice that is not listed is enumerated the old way.
+template <int K, int MODE, bool STATS, bool GRAD, bool LIST>
+__device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const float4* tab, const float (&bx)[4],
+                                                   const float (&by)[4], float rxx, float rxy, bool lane_bad, float& acc,
+                                                   WaveStats& st, GradCtx* g, long region, int s_lo, int s_hi, ListSink* sink) {
+    static_assert(K >= 2, "lists exist for orders >= 2");
+    const int lane = threadIdx.x & 63;
+    const RegionLists* rl = a.rl;
+    const int S = rl->S, cap = rl->cap[K];
+    const int* cnt = rl->cnt[K] + region * S;
+    const unsigned long long* codes = rl->codes[K] + (size_t)region * S * cap;
+    for (int s = s_lo; s < s_hi; ++s) {
+        const int n = cnt[s];
+        if (n < 0) {
+            int lo, hi;
+            first_wall_range(a, s, S, lo, hi);
+            sweep_order_culled<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, lo, hi, sink);
+            continue;
+        }
+        const unsigned long long* src = codes + (size_t)s * cap;
+        for (int off = 0; off < n; off += 64) {
+            const bool have = off + lane < n;
+            const unsigned long long code = src[have ? off + lane : off];
+            bool alive = have;
+            float Ix[K], Iy[K];
+            {
+                WallC w[K];
+                float ix = a.txx, iy = a.txy;
+#pragma unroll
+                for (int d = 0; d < K; ++d) {
+                    const int wd = (int)((code >> (12 * d)) & 0xfffull);
+                    const float4 r0 = tab[2 * wd], r1 = tab[2 * wd + 1], fc = tab[2 * a.N + wd];
+                    w[d] = make_wallc(r0, r1, fc, wd);
+                    image_of(r0, ix, iy, Ix[d], Iy[d]);
+                    ix = Ix[d];
+                    iy = Iy[d];
+                }
+                const bool bypass = GRAD && ((code >> 60) & 1ull);
+                if (bypass) {
+                    alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
+                } else if (alive) {
+                    const unsigned long long sh0 = a.shadow ? a.shadow[w[0].idx] : 0ull;
+                    if (cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive = false;
+                }
+            }
+            unsigned long long mask = __ballot(alive);
+            if (STATS) st.c[9] += K;
+            D2D_WORK(5 * K);
+            const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+            while (mask) {
+                const int b = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(code & 0xffffffffull), b);
+                const unsigned hi32 = (K >= 3) ? (unsigned)__builtin_amdgcn_readlane((int)(code >> 32), b) : 0u;
+                const unsigned long long cu = ((unsigned long long)hi32 << 32) | lo32;
+                int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+                float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
+#pragma unroll
+                for (int d = 0; d < K; ++d) {
+                    ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
+                    // the owning lane's image chain: the same operations on the same operands as the wave-uniform chain
+                    ex[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ix[d]), b));
+                    ey[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Iy[d]), b));
+                }
+                if (LIST) {
+                    float t = 0.0f;
+                    eval_candidate<K, MODE, STATS, GRAD, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, lane_bad, t, st, g);
+                    if (!(t == 0.0f)) sink->push(t);  // non-zero or NaN
+                } else {
+                    eval_candidate<K, MODE, STATS, GRAD, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, g);
+                }
+            }
+            if (STATS) st.c[14] += __builtin_amdgcn_s_memtime() - te0;
+        }
+    }
+}
+
+// Part `part` of `parts` of the order-K candidates (parts > 1: the first walls of first_wall_range(part, parts)), from
+// the region's lists when there are any, else by enumeration.
+template <int K, int MODE, bool STATS, bool GRAD, bool LIST>
+__device__ __forceinline__ void sweep_order_any(const SweepArgs& a, const float4* tab, const float (&bx)[4], const float (&by)[4],
+                                                float rxx, float rxy, bool lane_bad, float& acc, WaveStats& st, GradCtx* g,
+                                                long region, int part, int parts, ListSink* sink) {
+    if constexpr (K >= 2) {
+        if (a.rl != nullptr) {
+            const int S = a.rl->S;  // a multiple of parts
+            sweep_order_listed<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, region, (part * S) / parts,
+                                                           ((part + 1) * S) / parts, sink);
+            return;
+        }
+    }
+    int lo = 0, hi = 0x7fffffff;
+    if (parts > 1) first_wall_range(a, part, parts, lo, hi);
+    sweep_order_culled<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, lo, hi, sink);
+}
+
+// The region (R x R patches) of patch (tcol, trow)
+__device__ __forceinline__ long region_of(const SweepArgs& a, int tcol, int trow) {
+    if (a.rl == nullptr) return 0;
+    const int R = a.rl->R;
+    return (long)(trow / R) * a.rl->regions_x + (tcol / R);
+}
+
 #ifndef D2D_HEAVY_PARTS
 #define D2D_HEAVY_PARTS 4
 #endif
@@ -1367,6 +1503,7 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
 #endif
     const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tcol = (int)(tile % tiles_x), trow = (int)(tile / tiles_x);
+    const long region = region_of(a, tcol, trow);
     const int col = tcol * TILE_W + (lane & (TILE_W - 1));
     const int row = trow * TILE_H + (lane / TILE_W);
     const bool in_range = (col < a.n) && (row < a.m);
@@ -1445,11 +1582,8 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
             if (a.min_order <= 1 && a.max_order >= 1)
                 sweep_order_culled<1, MODE, false, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, 0, 0x7fffffff, &sink);
         }
-        if (a.min_order <= 2 && a.max_order >= 2) {
-            int lo, hi;
-            first_wall_range(a, part, HEAVY_PARTS, lo, hi);
-            sweep_order_culled<2, MODE, false, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, lo, hi, &sink);
-        }
+        if (a.min_order <= 2 && a.max_order >= 2)
+            sweep_order_any<2, MODE, false, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, region, part, HEAVY_PARTS, &sink);
         a.heavy_cnt[hq * 64 + lane] = sink.over ? -1 : sink.cnt;
         if (lane == 0) a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq] = (int)st.work;
         __threadfence();
@@ -1479,10 +1613,10 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
     unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[12] += tq2 - tq1;      // order 1
-    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled<2, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_any<2, MODE, STATS, GRADK, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
     if (STATS) st.c[13] += __builtin_amdgcn_s_memtime() - tq2;  // order 2
-    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled<3, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
-    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_culled<4, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_any<3, MODE, STATS, GRADK, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_any<4, MODE, STATS, GRADK, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
     }
     if (in_range) {
         if (a.out_mode == D2D_OUT_ADD) {
@@ -1535,50 +1669,18 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
 template <int K, int MODE, bool STATS, int W>
 __device__ __forceinline__ void split_order(const SweepArgs& a, const float4* tab, float* lists, int* meta,
                                             const float (&bx)[4], const float (&by)[4], float rxx, float rxy,
-                                            bool lane_bad, float& acc, WaveStats& st) {
+                                            bool lane_bad, float& acc, WaveStats& st, long region) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int Nc = a.Nc;
-    int* cnts = meta;             // [(W - 1)][64]
-    int* flags = meta + (W - 1) * 64;  // [(W - 1)] overflow, then [W + 1] range boundaries
-    int* bounds = flags + (W - 1);
-    // boundaries: position of the alive first wall of rank A * w / W
-    const bool use_dead = a.shadow && a.shadow_prefix_ok;
-    const int n_chunks = (Nc + 63) >> 6;
-    int A = 0;
-    for (int c = 0; c < n_chunks; ++c) {
-        const int pp = c * 64 + lane;
-        const bool alive = pp < Nc && !(use_dead && a.shadow[a.cw[pp]] == ~0ull);
-        A += __builtin_popcountll(__ballot(alive));
-    }
-    auto boundary = [&](int r) -> int {
-        if (r <= 0) return 0;
-        if (r >= A) return Nc;
-        for (int c = 0; c < n_chunks; ++c) {
-            const int pp = c * 64 + lane;
-            const bool alive = pp < Nc && !(use_dead && a.shadow[a.cw[pp]] == ~0ull);
-            unsigned long long m = __ballot(alive);
-            const int n = __builtin_popcountll(m);
-            if (r < n) {
-                for (; r > 0; --r) m &= m - 1;
-                return c * 64 + __builtin_ctzll(m);
-            }
-            r -= n;
-        }
-        return Nc;
-    };
-    const int my_lo = boundary((int)(((long)A * wv) / W));
-    const int my_hi = (wv == W - 1) ? Nc : boundary((int)(((long)A * (wv + 1)) / W));
-    if (lane == 0) {
-        bounds[wv] = my_lo;
-        if (wv == W - 1) bounds[W] = my_hi;
-    }
+    int* cnts = meta;                  // [(W - 1)][64]
+    int* flags = meta + (W - 1) * 64;  // [(W - 1)] overflow
+    // wave w takes part w of W of the first walls (first_wall_range / the region lists' slices)
     if (wv != 0) {
         ListSink sink;
         sink.col = lists + (size_t)(wv - 1) * SPLIT_LIST * 64 + lane;
         sink.cnt = 0;
         sink.over = false;
         float dummy = 0.0f;
-        sweep_order_culled<K, MODE, STATS, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, my_lo, my_hi, &sink);
+        sweep_order_any<K, MODE, STATS, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, region, wv, W, &sink);
         cnts[(wv - 1) * 64 + lane] = sink.cnt;
         const bool over = wave_any(sink.over);
         if (lane == 0) flags[wv - 1] = over ? 1 : 0;
@@ -1588,8 +1690,7 @@ __device__ __forceinline__ void split_order(const SweepArgs& a, const float4* ta
         if (w == 1) __syncthreads();  // uniform: every wave runs this loop
         if (wv == 0) {
             if (w == 0 || flags[w - 1]) {
-                const int lo = (w == 0) ? my_lo : bounds[w], hi = (w == 0) ? my_hi : bounds[w + 1];
-                sweep_order_culled<K, MODE, STATS, false, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, nullptr, lo, hi, nullptr);
+                sweep_order_any<K, MODE, STATS, false, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, nullptr, region, w, W, nullptr);
             } else {
                 const int n = cnts[(w - 1) * 64 + lane];
                 int nmax = n;
@@ -1623,6 +1724,7 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
     const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tile = a.sched ? a.sched[slot] : (int)slot;
     const int tcol = tile % tiles_x, trow = tile / tiles_x;
+    const long region = region_of(a, tcol, trow);
     const int col = tcol * TILE_W + (lane & (TILE_W - 1));
     const int row = trow * TILE_H + (lane / TILE_W);
     const bool in_range = (col < a.n) && (row < a.m);
@@ -1650,9 +1752,9 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
         if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, false>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, nullptr);
         if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, nullptr);
     }
-    if (a.min_order <= 2 && a.max_order >= 2) split_order<2, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st);
-    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) split_order<3, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st);
-    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) split_order<4, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st);
+    if (a.min_order <= 2 && a.max_order >= 2) split_order<2, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st, region);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) split_order<3, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st, region);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) split_order<4, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st, region);
     if (writer && in_range) {
         if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
         else a.out[idx] = acc;
@@ -1673,6 +1775,66 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) atomicAdd(&a.stats[i], st.c[i]);
     }
+}
+
+// Region candidate lists: one wave per (region, slice of first walls).  The wave runs the prefix odometer and the full
+// tile-culling test of order K against the bounding box of the region's cells (R x R patches) and writes the survivors,
+// in candidate order, to the slice's list.  What holds for the box holds for every patch inside it, so a patch that only
+// looks at the listed candidates skips nothing but exact zeros.  A list is marked "not listed" (count -1) when it
+// overflows or when a cell of the region is not comfortably finite; its patches then enumerate that slice themselves.
+template <int K, bool GRAD>
+__global__ void __launch_bounds__(64) region_list_kernel(SweepArgs a, RegionLists rl) {
+    const int lane = threadIdx.x & 63;
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, the culling queue
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    __syncthreads();
+    const long rs = blockIdx.x;
+    const long region = rs / rl.S;
+    const int s = (int)(rs % rl.S);
+    const int ry = (int)(region / rl.regions_x), rx = (int)(region % rl.regions_x);
+    const int c0 = rx * rl.R * TILE_W, r0 = ry * rl.R * TILE_H;
+    const int c1 = min(c0 + rl.R * TILE_W, a.n), r1 = min(r0 + rl.R * TILE_H, a.m);
+    const float inf = __builtin_inff();
+    float x0 = inf, x1 = -inf, y0 = inf, y1 = -inf;
+    bool bad = !(fabsf(a.txx) < 1e18f) || !(fabsf(a.txy) < 1e18f);
+    for (int r = r0; r < r1; ++r)
+        for (int cc = c0 + lane; cc < c1; cc += 64) {
+            const float x = a.X[(long)r * a.n + cc], y = a.Y[(long)r * a.n + cc];
+            bad = bad || !(fabsf(x) < 1e18f) || !(fabsf(y) < 1e18f);
+            x0 = fminf(x0, x);
+            x1 = fmaxf(x1, x);
+            y0 = fminf(y0, y);
+            y1 = fmaxf(y1, y);
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, off, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
+        y0 = fminf(y0, __shfl_xor(y0, off, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+    }
+    int* cnt = rl.cnt[K] + rs;
+    if (wave_any(bad) || !(x0 <= x1) || !(y0 <= y1)) {
+        if (lane == 0) *cnt = -1;
+        return;
+    }
+    const float bx[4] = {x0, x1, x1, x0};
+    const float by[4] = {y0, y0, y1, y1};
+    int lo, hi;
+    first_wall_range(a, s, rl.S, lo, hi);
+    EmitSink em;
+    em.dst = rl.codes[K] + (size_t)rs * rl.cap[K];
+    em.n = 0;
+    em.cap = rl.cap[K];
+    WaveStats st;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st.c[i] = 0;
+    st.shadow = -1;
+    st.work = 0;
+    float dummy = 0.0f;
+    sweep_order_culled<K, MODE_HARD, false, GRAD, false, true>(a, tab, bx, by, 0.0f, 0.0f, false, dummy, st, nullptr, lo, hi, nullptr, &em);
+    if (lane == 0) *cnt = (em.n <= em.cap) ? em.n : -1;
 }
 
 // TX grids (scene.py:1489-1648): the cells are transmitters, (a.txx, a.txy) is the fixed receiver F.  The reference's op

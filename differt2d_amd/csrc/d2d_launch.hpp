@@ -21,4 +21,7 @@ hipError_t launch_txg(int mode, bool grad, int max_order, dim3 grid, size_t lds,
 // power_vg_kernel<MODE, TXG, GRADK>: exhaustive sweeps (strict_nan value+grad; "txg_exhaustive" values)
 hipError_t launch_vg(int mode, bool txg, bool grad, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a);
 
+// region_list_kernel<K, GRAD>: candidate lists of order K (2..4) per region and slice; grid = regions x slices
+hipError_t launch_region_lists(int K, bool grad, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a, const RegionLists& rl);
+
 }  // namespace d2d

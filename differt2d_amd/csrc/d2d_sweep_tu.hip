@@ -1,6 +1,6 @@
 // One translation unit per (kernel family, validity mode): instantiates the sweep kernels of that pair and defines the
 // per-mode launcher that d2d_launch.cpp's dispatchers call.  Compiled several times by the Makefile with
-//   -DD2D_TU_FAMILY={0 fwd, 1 fwd_grad, 2 fwd_split, 3 txg, 4 vg}  -DD2D_TU_MODE={0 hard, 1 hard_sigmoid, 2 sigmoid}
+//   -DD2D_TU_FAMILY={0 fwd, 1 fwd_grad, 2 fwd_split, 3 txg, 4 vg, 5 region lists (mode 0 only)}  -DD2D_TU_MODE={0 hard, 1 hard_sigmoid, 2 sigmoid}
 #include "d2d_launch.hpp"
 
 #ifndef D2D_TU_FAMILY
@@ -77,6 +77,21 @@ hipError_t launch_vg_m<TU_MODE>(bool txg, bool grad, dim3 grid, size_t lds, hipS
     if (txg && grad) hipLaunchKernelGGL((power_vg_kernel<TU_MODE, true, true>), grid, block, lds, s, a);
     else if (txg) hipLaunchKernelGGL((power_vg_kernel<TU_MODE, true, false>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((power_vg_kernel<TU_MODE, false, true>), grid, block, lds, s, a);  // (RX grid, values only: launch_fwd)
+    return hipGetLastError();
+}
+#elif D2D_TU_FAMILY == 5
+// region_list_kernel<K, GRAD>: independent of the validity mode (compiled once, -DD2D_TU_MODE=0)
+hipError_t launch_region_lists(int K, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a, const RegionLists& rl) {
+    const dim3 block(64);
+    if (grad) {
+        if (K == 2) hipLaunchKernelGGL((region_list_kernel<2, true>), grid, block, lds, s, a, rl);
+        else if (K == 3) hipLaunchKernelGGL((region_list_kernel<3, true>), grid, block, lds, s, a, rl);
+        else hipLaunchKernelGGL((region_list_kernel<4, true>), grid, block, lds, s, a, rl);
+    } else {
+        if (K == 2) hipLaunchKernelGGL((region_list_kernel<2, false>), grid, block, lds, s, a, rl);
+        else if (K == 3) hipLaunchKernelGGL((region_list_kernel<3, false>), grid, block, lds, s, a, rl);
+        else hipLaunchKernelGGL((region_list_kernel<4, false>), grid, block, lds, s, a, rl);
+    }
     return hipGetLastError();
 }
 #else

@@ -285,8 +285,10 @@ def test_unsupported_is_loud():
     X, Y = scene.grid(n=4)
     with pytest.raises(L.D2DUnsupported):
         scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MyPath, key=1)
-    with pytest.raises(L.D2DUnsupported):
-        scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, key=1, grad=True)
+    # gradients through the MinPath Adam loop are supported since ABI v4 (tests/test_gpu_opt.py checks their values)
+    gmap = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, key=1, grad=True,
+                                                         reduce_all=True)
+    assert gmap.shape == X.shape + (2,)
     with pytest.raises(L.D2DUnsupported):
         scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, path_cls=MinPath, key=1,
                                                       path_cls_kwargs={"optimizer": object()})
