@@ -108,6 +108,7 @@ SYMBOLS = [
     ("d2d_debug_get_schedule", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"),
                                          np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.c_int64]),
     ("d2d_debug_get_work", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.c_int64]),
+    ("d2d_debug_region_stats", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]),
     ("d2d_last_kernel_ms", C.c_int, [_ctx, C.POINTER(C.c_float)]),
     ("d2d_power_map_wave_cycles", C.c_int, [_ctx, C.POINTER(Params), _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS"),
                                             C.c_int64, C.POINTER(C.c_int64)]),

@@ -28,13 +28,19 @@ template <int MODE> hipError_t launch_fwd_grad_m(int max_order, dim3 grid, size_
 template <int MODE> hipError_t launch_fwd_split_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <int MODE> hipError_t launch_txg_m(bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <int MODE> hipError_t launch_vg_m(bool txg, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <int MODE> hipError_t launch_fwd_listed_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <int MODE> hipError_t launch_fwd_grad_listed_m(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <int MODE> hipError_t launch_fwd_split_listed_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 
 #define D2D_DECLARE_MODE(M)                                                                                   \
     template <> hipError_t launch_fwd_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);           \
     template <> hipError_t launch_fwd_grad_m<M>(int, dim3, size_t, hipStream_t, const SweepArgs&);            \
     template <> hipError_t launch_fwd_split_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);     \
     template <> hipError_t launch_txg_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);           \
-    template <> hipError_t launch_vg_m<M>(bool, bool, dim3, size_t, hipStream_t, const SweepArgs&);
+    template <> hipError_t launch_vg_m<M>(bool, bool, dim3, size_t, hipStream_t, const SweepArgs&);              \
+    template <> hipError_t launch_fwd_listed_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);       \
+    template <> hipError_t launch_fwd_grad_listed_m<M>(int, dim3, size_t, hipStream_t, const SweepArgs&);        \
+    template <> hipError_t launch_fwd_split_listed_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);
 D2D_DECLARE_MODE(MODE_HARD)
 D2D_DECLARE_MODE(MODE_HSIG)
 D2D_DECLARE_MODE(MODE_SIG)
@@ -47,13 +53,16 @@ D2D_DECLARE_MODE(MODE_SIG)
         default: return fn<MODE_SIG>(__VA_ARGS__);             \
     }
 
-hipError_t launch_fwd(int mode, bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+hipError_t launch_fwd(int mode, bool listed, bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    if (listed) { D2D_BY_MODE(launch_fwd_listed_m, stats, max_order, grid, lds, s, a) }
     D2D_BY_MODE(launch_fwd_m, stats, max_order, grid, lds, s, a)
 }
-hipError_t launch_fwd_grad(int mode, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+hipError_t launch_fwd_grad(int mode, bool listed, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    if (listed) { D2D_BY_MODE(launch_fwd_grad_listed_m, max_order, grid, lds, s, a) }
     D2D_BY_MODE(launch_fwd_grad_m, max_order, grid, lds, s, a)
 }
-hipError_t launch_fwd_split(int mode, bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+hipError_t launch_fwd_split(int mode, bool listed, bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    if (listed) { D2D_BY_MODE(launch_fwd_split_listed_m, stats, max_order, grid, lds, s, a) }
     D2D_BY_MODE(launch_fwd_split_m, stats, max_order, grid, lds, s, a)
 }
 hipError_t launch_txg(int mode, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
@@ -174,15 +183,23 @@ struct d2d_ctx {
     DevBuf<float> d_heavy_list;
     DevBuf<int> d_heavy_cnt, d_heavy_done;
     long long heavy_done_n = 0;
-    // region candidate lists (region_list_kernel), rebuilt by every culled RX-grid launch of max_order >= 2
+    // region candidate lists (region_list_kernel / region_refine_kernel), rebuilt by every culled RX-grid launch of max_order >= 2
     bool use_region_lists = true;
-    long long region_size = 4;         // a region is region_size x region_size patches
-    long long region_slices = 0;       // slices of first walls per region (0: chosen from the number of allowed walls)
-    long long region_budget_mb = 1024; // device memory the lists of one launch may take
-    DevBuf<unsigned long long> d_rl_codes[D2D_MAX_ORDER + 1];
-    DevBuf<int> d_rl_cnt[D2D_MAX_ORDER + 1];
+    long long region_size = 4;         // leaf regions (what the sweep kernels read) are region_size x region_size patches
+    long long region_size_top = 16;    // regions listed by enumeration (a multiple of region_size; equal: one level only)
+    long long region_slices = 0;       // slices of first walls per enumerated region (0: chosen from the number of allowed walls)
+    long long region_budget_mb = 512;  // device memory of the list pool
+    DevBuf<unsigned long long> d_rl_pool;
+    DevBuf<float4> d_rl_box;           // bounding boxes of the leaf regions, then of the top regions (region_box_kernel)
+    long long rl_box_key[4] = {-1, 0, 0, 0};  // grid version, leaf R, top R (0: one level) the boxes were built for
+    long long grid_version = 0;        // bumped by d2d_set_grid
+    DevBuf<int> d_rl_next;             // [max_chunks]
+    DevBuf<int> d_rl_idx;              // first / cnt arrays of both levels, all orders
+    DevBuf<int> d_rl_meta;             // [0] patches queued for the enumerating kernel, [1] pool head, [2 ..) leaf region flags, then the queue
     DevBuf<d2d::RegionLists> d_rl;     // the descriptor the sweep kernels read
     d2d::RegionLists rl_host;          // what d_rl holds
+    d2d_host::RegionPlan rl_plan;      // of the last launch that built lists (rl_plan.on) -- d2d_debug_region_stats
+    int rl_max_order = 0;
     bool rl_host_valid = false;
     // RCCL (one communicator per ctx, collectives run on the ctx stream)
     ncclComm_t comm = nullptr;
@@ -505,8 +522,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_stats.release();
     c->d_shadow.release();
     c->d_sched.release();
-    for (int k = 0; k <= D2D_MAX_ORDER; ++k) { c->d_rl_codes[k].release(); c->d_rl_cnt[k].release(); }
-    c->d_rl.release();
+    c->d_rl_pool.release(); c->d_rl_box.release(); c->d_rl_next.release(); c->d_rl_idx.release(); c->d_rl_meta.release(); c->d_rl.release();
     c->d_sched_key.release();
     c->d_sched_override.release();
     c->d_cost.release();
@@ -616,6 +632,7 @@ int d2d_list_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int32_
 int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t n) {
     if (!c || !X || !Y) return fail(D2D_ERR_INVALID, "NULL argument");
     c->cost_tiles = 0;  // the patch-cost history describes another sweep
+    c->grid_version += 1;  // ... and the regions' bounding boxes another grid
     if (m <= 0 || n <= 0) return fail(D2D_ERR_INVALID, "grid must be at least 1 x 1, got %d x %d", m, n);
     int rc = set_device(c);
     if (rc) return rc;
@@ -900,39 +917,85 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     }
     // region candidate lists (orders >= 2): the culled RX-grid kernels (forward, instrumented, value+grad) read them
     a.rl = nullptr;
+    a.fb_n = nullptr;
+    a.fb_list = nullptr;
     if (!txg && c->use_region_lists && p->max_order >= 2 && c->cw.size() >= 2 && c->N <= 4095 && !(grad_mode && p->strict_nan)) {
-        const d2d_host::RegionPlan rp = d2d_host::region_plan(tiles_x, tiles_y, (long long)c->cw.size(), p->min_order, p->max_order,
-                                                             (int)c->region_size, (int)c->region_slices, c->region_budget_mb << 20, d2d::HEAVY_PARTS);
-        const size_t lds_l = (size_t)(3 * c->N + 1) * sizeof(float4) + 512;
-        if (rp.on && lds_l <= d2d_host::LDS_LIMIT) {
-            d2d::RegionLists rl;
-            memset(&rl, 0, sizeof rl);
-            rl.S = rp.S;
-            rl.R = rp.R;
-            rl.regions_x = rp.regions_x;
-            rl.regions_y = rp.regions_y;
-            const size_t slots = (size_t)rp.regions * rp.S;
-            for (int k = 2; k <= p->max_order; ++k) {
-                if (rp.cap[k] <= 0) continue;
-                if ((rc = c->d_rl_codes[k].ensure(slots * (size_t)rp.cap[k]))) return rc;
-                if ((rc = c->d_rl_cnt[k].ensure(slots))) return rc;
-                rl.codes[k] = c->d_rl_codes[k].p;
-                rl.cnt[k] = c->d_rl_cnt[k].p;
-                rl.cap[k] = (int)rp.cap[k];
-            }
+        const d2d_host::RegionPlan rp =
+            d2d_host::region_plan(tiles_x, tiles_y, (long long)c->cw.size(), p->min_order, p->max_order, (int)c->region_size,
+                                  (int)c->region_size_top, (int)c->region_slices, c->region_budget_mb << 20, d2d::RL_CHUNK);
+        const size_t lds_l = (size_t)(3 * c->N + 1) * sizeof(float4) + 512;                                         // tables + culling queue
+        const size_t lds_r = (size_t)(3 * c->N + 1) * sizeof(float4) + (size_t)d2d::RL_GATHER * sizeof(unsigned long long);  // tables + gather buffer
+        if (rp.on && lds_l <= d2d_host::LDS_LIMIT && lds_r <= d2d_host::LDS_LIMIT) {
+            const int orders = p->max_order - rp.k_lo + 1;
+            const size_t per_order = (size_t)rp.leaf.slots + (size_t)rp.top.slots;
+            if ((rc = c->d_rl_pool.ensure((size_t)rp.max_chunks * d2d::RL_CHUNK))) return rc;
+            if ((rc = c->d_rl_next.ensure((size_t)rp.max_chunks))) return rc;
+            if ((rc = c->d_rl_idx.ensure(per_order * (size_t)orders))) return rc;
+            if ((rc = c->d_rl_meta.ensure(2 + (size_t)rp.leaf.regions + (size_t)tiles))) return rc;
             if ((rc = c->d_rl.ensure(1))) return rc;
+            HIP_TRY(hipMemsetAsync(c->d_rl_meta.p, 0, (2 + (size_t)rp.leaf.regions) * sizeof(int), c->stream));
+            {
+                // the regions' bounding boxes depend on the grid only
+                const long long key[4] = {c->grid_version, rp.leaf.R, rp.top.R, (long long)c->m * 0x100000000ll + c->n};
+                const size_t nbox = (size_t)rp.leaf.regions + (size_t)rp.top.regions;
+                if (std::memcmp(key, c->rl_box_key, sizeof key) != 0 || c->d_rl_box.n < nbox) {
+                    if ((rc = c->d_rl_box.ensure(nbox))) return rc;
+                    hipLaunchKernelGGL(d2d::region_box_kernel, dim3((unsigned)rp.leaf.regions), dim3(256), 0, c->stream, c->d_X.p, c->d_Y.p,
+                                       c->m, c->n, rp.leaf.R, rp.leaf.regions_x, c->d_rl_box.p);
+                    hipLaunchKernelGGL(d2d::region_box_kernel, dim3((unsigned)rp.top.regions), dim3(256), 0, c->stream, c->d_X.p, c->d_Y.p,
+                                       c->m, c->n, rp.top.R, rp.top.regions_x, c->d_rl_box.p + rp.leaf.regions);
+                    HIP_TRY(hipGetLastError());
+                    std::memcpy(c->rl_box_key, key, sizeof key);
+                }
+            }
+            auto fill = [](d2d::RegionLevel& l, const d2d_host::RegionLevelPlan& lp_) {
+                l.S = lp_.S;
+                l.R = lp_.R;
+                l.regions_x = lp_.regions_x;
+                l.regions_y = lp_.regions_y;
+            };
+            d2d::RegionLists rl;
+            d2d::RegionLevel top;
+            memset(&rl, 0, sizeof rl);
+            memset(&top, 0, sizeof top);
+            fill(rl.leaf, rp.leaf);
+            fill(top, rp.top);
+            rl.leaf.box = c->d_rl_box.p;
+            top.box = c->d_rl_box.p + rp.leaf.regions;
+            int* at = c->d_rl_idx.p;
+            int chunk_at = 0;
+            for (int k = rp.k_lo; k <= p->max_order; ++k) {
+                rl.leaf.cnt[k] = at; at += rp.leaf.slots;
+                rl.leaf.chunk0[k] = chunk_at; chunk_at += (int)rp.leaf.slots;
+                top.cnt[k] = at; at += rp.top.slots;
+                top.chunk0[k] = chunk_at; chunk_at += (int)rp.top.slots;
+            }
+            rl.lp.pool = c->d_rl_pool.p;
+            rl.lp.next = c->d_rl_next.p;
+            rl.lp.head = c->d_rl_meta.p + 1;
+            rl.lp.n_static = (int)rp.n_static;
+            rl.lp.max_chunks = (int)rp.max_chunks;
+            rl.flag = c->d_rl_meta.p + 2;
+            a.fb_n = c->d_rl_meta.p;
+            a.fb_list = c->d_rl_meta.p + 2 + rp.leaf.regions;
             if (!c->rl_host_valid || std::memcmp(&rl, &c->rl_host, sizeof rl) != 0) {
                 c->rl_host = rl;  // (the copy reads rl_host: it stays valid after this call returns)
                 c->rl_host_valid = true;
                 HIP_TRY(hipMemcpyAsync(c->d_rl.p, &c->rl_host, sizeof rl, hipMemcpyHostToDevice, c->stream));
             }
             d2d::SweepArgs al = a;
+            al.fb_n = nullptr;
             al.cullq_off = (int)((size_t)(3 * c->N + 1) * sizeof(float4));
-            for (int k = (p->min_order > 2 ? p->min_order : 2); k <= p->max_order; ++k)
-                HIP_TRY(d2d::launch_region_lists(k, grad_mode != 0, dim3((unsigned)slots), lds_l, c->stream, al, rl));
+            for (int k = rp.k_lo; k <= p->max_order; ++k) {
+                HIP_TRY(d2d::launch_region_lists(k, grad_mode != 0, dim3((unsigned)rp.top.slots), lds_l, c->stream, al, top, rl.lp));
+                HIP_TRY(d2d::launch_region_refine(k, grad_mode != 0, dim3((unsigned)rp.leaf.regions), lds_r, c->stream, al, rl.leaf, top, rl.lp, rl.flag));
+            }
             a.rl = c->d_rl.p;
+            c->rl_plan = rp;
+            c->rl_max_order = p->max_order;
         }
     }
+    if (!a.rl) c->rl_plan.on = false;
     // dearest-first patch schedule for the culled kernels
     a.sched = nullptr;
     a.n_heavy = 0;
@@ -1016,7 +1079,12 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4) + 512;  // tables, adjoint table, culling queue
             if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
             a.cullq_off = (int)((size_t)(4 * c->N + 1) * sizeof(float4));
-            HIP_TRY(d2d::launch_fwd_grad(mode, p->max_order, grid_patches, lds2, c->stream, a));
+            HIP_TRY(d2d::launch_fwd_grad(mode, a.rl != nullptr, p->max_order, grid_patches, lds2, c->stream, a));
+            if (a.rl) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
+                d2d::SweepArgs af = a;
+                af.rl = nullptr; af.sched = nullptr; af.n_heavy = 0;
+                HIP_TRY(d2d::launch_fwd_grad(mode, false, p->max_order, dim3((unsigned)std::min<long long>(tiles, 1024)), lds2, c->stream, af));
+            }
         } else if (txg_culled) {
             // TX grid, culled value+grad sweep
             const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4);
@@ -1068,8 +1136,15 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
     }
     a.cullq_off = (int)(split ? split_base : (size_t)(4 * c->N + 1) * sizeof(float4));
-    if (split) HIP_TRY(d2d::launch_fwd_split(mode, d_stats != nullptr, p->max_order, grid_patches, split_lds, c->stream, a));
-    else HIP_TRY(d2d::launch_fwd(mode, d_stats != nullptr, p->max_order, grid_fwd, tab_lds, c->stream, a));
+    if (split) HIP_TRY(d2d::launch_fwd_split(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, grid_patches, split_lds, c->stream, a));
+    else HIP_TRY(d2d::launch_fwd(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, grid_fwd, tab_lds, c->stream, a));
+    if (a.rl) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
+        d2d::SweepArgs af = a;
+        af.rl = nullptr; af.sched = nullptr; af.n_heavy = 0;
+        const dim3 gq((unsigned)std::min<long long>(tiles, 1024));
+        if (split) HIP_TRY(d2d::launch_fwd_split(mode, false, d_stats != nullptr, p->max_order, gq, split_lds, c->stream, af));
+        else HIP_TRY(d2d::launch_fwd(mode, false, d_stats != nullptr, p->max_order, gq, tab_lds, c->stream, af));
+    }
     D2D_KERNEL_DONE();
     return D2D_OK;
 }
@@ -1170,6 +1245,9 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "region_size")) {
         if (value < 1 || value > 64) return fail(D2D_ERR_INVALID, "region_size must lie in 1..64, got %lld", (long long)value);
         c->region_size = value;
+    } else if (!strcmp(name, "region_size_top")) {
+        if (value < 1 || value > 1024) return fail(D2D_ERR_INVALID, "region_size_top must lie in 1..1024, got %lld", (long long)value);
+        c->region_size_top = value;
     } else if (!strcmp(name, "region_slices")) {
         if (value < 0 || value > 1024) return fail(D2D_ERR_INVALID, "region_slices must lie in 0..1024, got %lld", (long long)value);
         c->region_slices = value;
@@ -1206,6 +1284,32 @@ int d2d_debug_get_work(d2d_ctx* c, uint32_t* work, int64_t n) {
     if (!c->d_cost.p || c->cost_tiles != n) return fail(D2D_ERR_STATE, "no work history of %lld patches", (long long)n);
     HIP_TRY(hipMemcpyAsync(work, c->d_cost.p, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return D2D_OK;
+}
+
+int d2d_debug_region_stats(d2d_ctx* c, int64_t* out) {
+    if (!c || !out) return fail(D2D_ERR_INVALID, "NULL argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!c->rl_plan.on) return D2D_OK;
+    const d2d_host::RegionPlan& rp = c->rl_plan;
+    std::vector<int> meta(2 + (size_t)rp.leaf.regions);
+    HIP_TRY(hipMemcpyAsync(meta.data(), c->d_rl_meta.p, meta.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    const int orders = c->rl_max_order - rp.k_lo + 1;
+    const size_t per_order = (size_t)rp.leaf.slots + (size_t)rp.top.slots;
+    std::vector<int> idx(per_order * (size_t)orders);
+    HIP_TRY(hipMemcpyAsync(idx.data(), c->d_rl_idx.p, idx.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out[0] = meta[1] + rp.n_static;
+    out[1] = rp.max_chunks;
+    out[2] = meta[0];
+    for (long long r = 0; r < rp.leaf.regions; ++r) out[3] += meta[2 + (size_t)r] != 0;
+    for (int k = rp.k_lo; k <= c->rl_max_order && k <= 4; ++k) {
+        const int* cnt = idx.data() + per_order * (size_t)(k - rp.k_lo);
+        for (long long i = 0; i < rp.leaf.slots; ++i) out[2 + k] += cnt[i] > 0 ? cnt[i] : 0;
+    }
+    out[7] = rp.leaf.regions;
     return D2D_OK;
 }
 

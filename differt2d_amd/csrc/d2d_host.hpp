@@ -167,50 +167,49 @@ inline HeavyPlan heavy_plan(long long tiles, long long Nc, long long heavy_split
     return hp;
 }
 
-// ---- region candidate lists (region_list_kernel) ------------------------------------------------------------------
+// ---- region candidate lists (region_list_kernel / region_refine_kernel) ----------------------------------------------
+struct RegionLevelPlan {
+    int R = 0, S = 0;  // region = R x R patches; S lists (slices of first walls) per region
+    int regions_x = 0, regions_y = 0;
+    long long regions = 0, slots = 0;  // slots = regions * S = lists per order
+};
 struct RegionPlan {
     bool on = false;
-    int R = 0, S = 0;                         // region = R x R patches; S slices of first walls per region
-    int regions_x = 0, regions_y = 0;
-    long long regions = 0;
-    long long cap[D2D_MAX_ORDER + 1] = {0};  // list entries per (region, slice) of order k (0: no list for that order)
+    RegionLevelPlan top, leaf;  // top: listed by enumeration, S slices; leaf: one list per region, refined from top
+    long long n_static = 0;     // chunks that are some list's first chunk
+    long long max_chunks = 0;   // pool chunks of `chunk` entries
+    int k_lo = 2;               // lists exist for the orders [k_lo, max_order]
 };
-// Lists exist for the orders k in [max(2, min_order), max_order].  A slice never holds more than
-// (ceil(Nc / S) + 1) * (Nc - 1)^(k-1) candidates; the capacity is that bound or what `budget_bytes / orders` allows,
-// whichever is smaller (a list that overflows is marked as not listed and its patches enumerate).  S is a multiple of
-// `parts` (the waves / quarters that share a patch take whole slices).
-inline RegionPlan region_plan(int tiles_x, int tiles_y, long long Nc, int min_order, int max_order, int R, int S_req, long long budget_bytes,
-                              int parts) {
+// Lists exist for the orders k in [max(2, min_order), max_order].  R_top is rounded down to a multiple of R_leaf (at
+// least R_leaf).  The pool holds budget_bytes worth of 8-byte entries in chunks of `chunk`; every list owns one chunk.
+inline RegionPlan region_plan(int tiles_x, int tiles_y, long long Nc, int min_order, int max_order, int R_leaf, int R_top, int S_req,
+                              long long budget_bytes, int chunk) {
     RegionPlan rp;
-    if (tiles_x <= 0 || tiles_y <= 0 || Nc < 2 || max_order < 2 || R <= 0 || parts <= 0 || budget_bytes <= 0) return rp;
-    int S = S_req > 0 ? S_req : (int)(parts * ((Nc + 49) / 50));
-    S = ((S + parts - 1) / parts) * parts;
-    if (S > 1024) S = (1024 / parts) * parts;
+    if (tiles_x <= 0 || tiles_y <= 0 || Nc < 2 || max_order < 2 || R_leaf <= 0 || chunk <= 0 || budget_bytes <= 0) return rp;
+    int S = S_req > 0 ? S_req : (int)((Nc + 3) / 4);
+    if (S > 1024) S = 1024;
     if (S <= 0) return rp;
-    rp.R = R;
-    rp.S = S;
-    rp.regions_x = (tiles_x + R - 1) / R;
-    rp.regions_y = (tiles_y + R - 1) / R;
-    rp.regions = (long long)rp.regions_x * rp.regions_y;
-    const long long slots = rp.regions * S;
-    if (slots <= 0 || slots > 0x7fffffffLL) return rp;
-    const int k0 = min_order > 2 ? min_order : 2;
-    const int orders = max_order - k0 + 1;
-    if (orders <= 0) return rp;
-    const long long per_order = budget_bytes / orders / (long long)sizeof(unsigned long long);
-    const long long cap_budget = per_order / slots;
-    if (cap_budget < 64) return rp;  // not worth having
-    for (int k = k0; k <= max_order; ++k) {
-        long long full = (Nc + S - 1) / S + 1;
-        for (int i = 1; i < k; ++i) {
-            if (full > cap_budget) break;
-            full *= (Nc - 1);
-        }
-        long long cap = full < cap_budget ? full : cap_budget;
-        cap = (cap + 63) / 64 * 64;
-        if (cap > 0x7fffffffLL / 2) cap = (0x7fffffffLL / 2) / 64 * 64;
-        rp.cap[k] = cap;
-    }
+    if (R_top < R_leaf) R_top = R_leaf;
+    R_top = (R_top / R_leaf) * R_leaf;
+    auto level = [&](int R, int Sl) {
+        RegionLevelPlan l;
+        l.R = R;
+        l.S = Sl;
+        l.regions_x = (tiles_x + R - 1) / R;
+        l.regions_y = (tiles_y + R - 1) / R;
+        l.regions = (long long)l.regions_x * l.regions_y;
+        l.slots = l.regions * Sl;
+        return l;
+    };
+    rp.leaf = level(R_leaf, 1);
+    rp.top = level(R_top, S);
+    if (rp.leaf.slots <= 0 || rp.leaf.slots > 0x3fffffffLL || rp.top.slots <= 0 || rp.top.slots > 0x3fffffffLL) return rp;
+    rp.k_lo = min_order > 2 ? min_order : 2;
+    if (rp.k_lo > max_order) return rp;
+    rp.n_static = (rp.leaf.slots + rp.top.slots) * (max_order - rp.k_lo + 1);
+    rp.max_chunks = budget_bytes / ((long long)sizeof(unsigned long long) * chunk);
+    if (rp.max_chunks > 0x7fffffffLL) rp.max_chunks = 0x7fffffffLL;
+    if (rp.n_static > 0x7fffffffLL || rp.max_chunks < 2 * rp.n_static) return rp;  // not worth having
     rp.on = true;
     return rp;
 }

@@ -33,20 +33,40 @@ namespace d2d {
 
 enum Mode { MODE_HARD = 0, MODE_HSIG = 1, MODE_SIG = 2 };
 
-// Region candidate lists (region_list_kernel): for every order K >= 2, every region of R x R patches and every slice of
-// first-wall positions, the candidates that the tile culling cannot prove invalid for the region's bounding box, in
-// candidate order.  The patches of the region then test and evaluate those instead of enumerating all prefixes themselves.
-struct RegionLists {
-    unsigned long long* codes[D2D_MAX_ORDER + 1];  // [K]: [regions][S][cap[K]]; 12 bits per wall index, first wall lowest; bit 60: see sweep_order_culled
-    int* cnt[D2D_MAX_ORDER + 1];                   // [K]: [regions][S] entries of the slice's list; < 0: not listed (overflow, non-finite cell): enumerate
-    int cap[D2D_MAX_ORDER + 1];
-    int S;                     // slices of first-wall positions (first_wall_range(s, S)); a multiple of HEAVY_PARTS and SPLIT_W
-    int R;                     // a region is R x R patches
+// Region candidate lists: for every order K >= 2, every region of R x R patches and every slice of first-wall positions,
+// the candidates that the tile culling cannot prove invalid for the region's bounding box, in candidate order.  The
+// patches of a region then test and evaluate those instead of enumerating all prefixes themselves.  Two levels: big
+// regions are listed by enumeration (region_list_kernel), the regions the sweep kernels read by filtering their parent's
+// lists (region_refine_kernel).  A list is a chain of 128-entry chunks of one pool; an entry holds 12 bits per wall
+// index, first wall lowest (bit 60: see sweep_order_culled).
+constexpr int RL_CHUNK = 128;
+struct ListPool {
+    unsigned long long* pool;  // [max_chunks][RL_CHUNK]
+    int* next;                 // [max_chunks] the chunk that continues a chunk
+    int* head;                 // continuation chunks handed out so far (may run past the pool: those lists are not listed)
+    int n_static;              // chunks [0, n_static) are the lists' first chunks; continuation chunks follow
+    int max_chunks;
+};
+struct RegionLevel {
+    int* cnt[D2D_MAX_ORDER + 1];    // [K]: [regions][S] entries; < 0: not listed (pool exhausted, non-finite cell)
+    int chunk0[D2D_MAX_ORDER + 1];  // [K]: list i of order K starts in chunk chunk0[K] + i
+    int S;                          // lists per region: slices of first-wall positions (first_wall_range(s, S)); 1 at the leaf level
+    int R;                          // a region is R x R patches
     int regions_x, regions_y;
+    const float4* box;              // [regions] bounding boxes of the regions' cells (region_box_kernel)
+};
+struct RegionLists {
+    RegionLevel leaf;  // the level the sweep kernels read (one list per region and order)
+    ListPool lp;
+    int* flag;         // [leaf regions] != 0: some list of the region is not listed
 };
 
 struct SweepArgs {
-    const RegionLists* __restrict__ rl;  // device copy of the lists' descriptor, or null: every patch enumerates for itself
+    const RegionLists* __restrict__ rl;  // LISTED kernels: device copy of the lists' descriptor
+    // Patches a LISTED kernel cannot take (a list of their region is not listed, or a cell is not comfortably finite) are
+    // queued here and swept by the enumerating kernel launched right behind it (fb_n != null there: workgroups walk the queue)
+    int* fb_n;
+    int* fb_list;
     // scene tables (device, read-only, wave-uniform indexing -> scalar loads)
     const float4* __restrict__ occl;  // [N]  {p1x, p1y, Ax, Ay}: patched origin and P2-P1 (geometry.py:632-636)
     const float4* __restrict__ refl;  // [2N] {ox, oy, nx, ny}, {tx, ty, sq, 0}: reflection data
@@ -1013,12 +1033,43 @@ struct ListSink {
     }
 };
 
-// Survivors of a region's culling, in candidate order (region_list_kernel).
+// Survivors of a region's culling, in candidate order (region_list_kernel / region_refine_kernel): wave-uniform state
+// of the list being written.
 struct EmitSink {
-    unsigned long long* dst;
-    int n;    // survivors so far (may exceed cap: the list is then marked as not listed)
-    int cap;
+    ListPool lp;
+    int cur;    // chunk that takes the next entry (initially the list's static first chunk)
+    int n;      // entries so far
+    bool over;  // the pool ran out: the list is not listed
 };
+
+// Appends the codes of the lanes in `mask` (at most 64) in lane order.
+__device__ __forceinline__ void emit_batch(EmitSink& e, unsigned long long code, bool alive, unsigned long long mask) {
+    const int lane = threadIdx.x & 63;
+    const int cntm = __builtin_popcountll(mask);
+    if (cntm == 0 || e.over) return;
+    const int start = e.n;
+    const int in_cur = start & (RL_CHUNK - 1);
+    const bool fresh = in_cur == 0 && start > 0;  // the current chunk is full
+    int newc = -1;
+    if (fresh || in_cur + cntm > RL_CHUNK) {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(e.lp.head, 1);
+        c = __builtin_amdgcn_readfirstlane(c) + e.lp.n_static;
+        if (c >= e.lp.max_chunks) {
+            e.over = true;
+            return;
+        }
+        newc = c;
+        if (lane == 0) e.lp.next[e.cur] = c;
+    }
+    if (alive) {
+        const int pos = start + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        const int chunk = (!fresh && (pos / RL_CHUNK) == (start / RL_CHUNK)) ? e.cur : newc;
+        e.lp.pool[(size_t)chunk * RL_CHUNK + (pos & (RL_CHUNK - 1))] = code;
+    }
+    if (newc >= 0) e.cur = newc;
+    e.n = start + cntm;
+}
 
 // All candidates of order K >= 1 with tile culling; `tab` = LDS copy of {refl[2N], flt[N]}.
 // K >= 2: only the prefixes whose FIRST position lies in [p_lo, p_hi) (positions into cw[]).  LIST: instead of being
@@ -1110,11 +1161,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         if (STATS) st.c[9] += K;
         D2D_WORK(5 * K);
         if constexpr (EMIT) {
-            if (alive2) {
-                const int at = emit->n + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                if (at < emit->cap) emit->dst[at] = code;
-            }
-            emit->n += __builtin_popcountll(mask);
+            emit_batch(*emit, code, alive2, mask);
             mask = 0ull;
         }
         const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1345,109 +1392,126 @@ __device__ __forceinline__ void first_wall_range(const SweepArgs& a, int part, i
     hi = (part == parts - 1) ? Nc : boundary((int)(((long)A * (part + 1)) / parts));
 }
 
-// Order K >= 2 from the region's candidate lists (slices [s_lo, s_hi) of first walls): 64 entries at a time, lanes =
-// candidates: the full tile-culling test against the PATCH, then the survivors are evaluated exactly in list order (= the
-// reference's order).  A slice that is not listed is enumerated the old way.
+// One batch of a candidate list, lanes = candidates: decodes the lane's entry, builds its image chain and runs the full
+// tile-culling test against the box (bx, by).  Returns the ballot of the entries that cannot be dropped.
+template <int K, bool GRAD>
+__device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, const float4* tab, const float (&bx)[4], const float (&by)[4],
+                                                         unsigned long long code, bool have, float (&Ix)[K], float (&Iy)[K]) {
+    bool alive = have;
+    WallC w[K];
+    float ix = a.txx, iy = a.txy;
+#pragma unroll
+    for (int d = 0; d < K; ++d) {
+        const int wd = (int)((code >> (12 * d)) & 0xfffull);
+        const float4 r0 = tab[2 * wd], r1 = tab[2 * wd + 1], fc = tab[2 * a.N + wd];
+        w[d] = make_wallc(r0, r1, fc, wd);
+        image_of(r0, ix, iy, Ix[d], Iy[d]);
+        ix = Ix[d];
+        iy = Iy[d];
+    }
+    const bool bypass = GRAD && ((code >> 60) & 1ull);
+    if (bypass) {
+        alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
+    } else if (alive) {
+        const unsigned long long sh0 = a.shadow ? a.shadow[w[0].idx] : 0ull;
+        if (cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive = false;
+    }
+    return __ballot(alive);
+}
+
+// Order K >= 2 from the region's candidate list: 64 entries at a time, lanes = candidates: the full tile-culling test
+// against the PATCH; the survivors are then evaluated exactly in list order (= the reference's order).  parts > 1: only
+// the survivors whose rank lies in part `part` of `parts` (the list is culled twice then: once to count).
 template <int K, int MODE, bool STATS, bool GRAD, bool LIST>
 __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                    const float (&by)[4], float rxx, float rxy, bool lane_bad, float& acc,
-                                                   WaveStats& st, GradCtx* g, long region, int s_lo, int s_hi, ListSink* sink) {
+                                                   WaveStats& st, GradCtx* g, long region, int part, int parts, ListSink* sink) {
     static_assert(K >= 2, "lists exist for orders >= 2");
     const int lane = threadIdx.x & 63;
     const RegionLists* rl = a.rl;
-    const int S = rl->S, cap = rl->cap[K];
-    const int* cnt = rl->cnt[K] + region * S;
-    const unsigned long long* codes = rl->codes[K] + (size_t)region * S * cap;
-    for (int s = s_lo; s < s_hi; ++s) {
-        const int n = cnt[s];
-        if (n < 0) {
-            int lo, hi;
-            first_wall_range(a, s, S, lo, hi);
-            sweep_order_culled<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, lo, hi, sink);
-            continue;
-        }
-        const unsigned long long* src = codes + (size_t)s * cap;
+    const int n = rl->leaf.cnt[K][region];  // >= 0: patches of a region with a list that is not listed go to the enumerating kernel
+    const int chunk0 = rl->leaf.chunk0[K] + (int)region;
+    const unsigned long long* pool = rl->lp.pool;
+    const int* next = rl->lp.next;
+    int r_lo = 0, r_hi = 0x7fffffff;
+    if (parts > 1) {
+        int T = 0, chunk = chunk0;
         for (int off = 0; off < n; off += 64) {
             const bool have = off + lane < n;
-            const unsigned long long code = src[have ? off + lane : off];
-            bool alive = have;
+            const unsigned long long code = pool[(size_t)chunk * RL_CHUNK + (off & (RL_CHUNK - 1)) + (have ? lane : 0)];
+            if ((off & (RL_CHUNK - 1)) == RL_CHUNK - 64 && off + 64 < n) chunk = next[chunk];
             float Ix[K], Iy[K];
-            {
-                WallC w[K];
-                float ix = a.txx, iy = a.txy;
-#pragma unroll
-                for (int d = 0; d < K; ++d) {
-                    const int wd = (int)((code >> (12 * d)) & 0xfffull);
-                    const float4 r0 = tab[2 * wd], r1 = tab[2 * wd + 1], fc = tab[2 * a.N + wd];
-                    w[d] = make_wallc(r0, r1, fc, wd);
-                    image_of(r0, ix, iy, Ix[d], Iy[d]);
-                    ix = Ix[d];
-                    iy = Iy[d];
-                }
-                const bool bypass = GRAD && ((code >> 60) & 1ull);
-                if (bypass) {
-                    alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
-                } else if (alive) {
-                    const unsigned long long sh0 = a.shadow ? a.shadow[w[0].idx] : 0ull;
-                    if (cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive = false;
-                }
-            }
-            unsigned long long mask = __ballot(alive);
-            if (STATS) st.c[9] += K;
+            T += __builtin_popcountll(cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy));
             D2D_WORK(5 * K);
-            const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-            while (mask) {
-                const int b = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(code & 0xffffffffull), b);
-                const unsigned hi32 = (K >= 3) ? (unsigned)__builtin_amdgcn_readlane((int)(code >> 32), b) : 0u;
-                const unsigned long long cu = ((unsigned long long)hi32 << 32) | lo32;
-                int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
-                float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
-#pragma unroll
-                for (int d = 0; d < K; ++d) {
-                    ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
-                    // the owning lane's image chain: the same operations on the same operands as the wave-uniform chain
-                    ex[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ix[d]), b));
-                    ey[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Iy[d]), b));
-                }
-                if (LIST) {
-                    float t = 0.0f;
-                    eval_candidate<K, MODE, STATS, GRAD, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, lane_bad, t, st, g);
-                    if (!(t == 0.0f)) sink->push(t);  // non-zero or NaN
-                } else {
-                    eval_candidate<K, MODE, STATS, GRAD, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, g);
-                }
-            }
-            if (STATS) st.c[14] += __builtin_amdgcn_s_memtime() - te0;
         }
+        r_lo = (int)(((long)T * part) / parts);
+        r_hi = (int)(((long)T * (part + 1)) / parts);
+    }
+    int ord = 0, chunk = chunk0;
+    for (int off = 0; off < n && ord < r_hi; off += 64) {
+        const bool have = off + lane < n;
+        const unsigned long long code = pool[(size_t)chunk * RL_CHUNK + (off & (RL_CHUNK - 1)) + (have ? lane : 0)];
+        if ((off & (RL_CHUNK - 1)) == RL_CHUNK - 64 && off + 64 < n) chunk = next[chunk];
+        float Ix[K], Iy[K];
+        unsigned long long mask = cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy);
+        if (STATS) st.c[9] += K;
+        D2D_WORK(5 * K);
+        int budget = 64;
+        if (parts > 1) {
+            const int nb = __builtin_popcountll(mask);
+            int skip = r_lo - ord;  // survivors of this batch that belong to earlier parts
+            budget = r_hi - (ord > r_lo ? ord : r_lo);
+            ord += nb;
+            for (; skip > 0 && mask; --skip) mask &= mask - 1;
+        }
+        const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+        while (mask && budget > 0) {
+            const int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            --budget;
+            const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(code & 0xffffffffull), b);
+            const unsigned hi32 = (K >= 3) ? (unsigned)__builtin_amdgcn_readlane((int)(code >> 32), b) : 0u;
+            const unsigned long long cu = ((unsigned long long)hi32 << 32) | lo32;
+            int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+            float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+                ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
+                // the owning lane's image chain: the same operations on the same operands as the wave-uniform chain
+                ex[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ix[d]), b));
+                ey[d] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Iy[d]), b));
+            }
+            if (LIST) {
+                float t = 0.0f;
+                eval_candidate<K, MODE, STATS, GRAD, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, lane_bad, t, st, g);
+                if (!(t == 0.0f)) sink->push(t);  // non-zero or NaN
+            } else {
+                eval_candidate<K, MODE, STATS, GRAD, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, g);
+            }
+        }
+        if (STATS) st.c[14] += __builtin_amdgcn_s_memtime() - te0;
     }
 }
 
-// Part `part` of `parts` of the order-K candidates (parts > 1: the first walls of first_wall_range(part, parts)), from
-// the region's lists when there are any, else by enumeration.
-template <int K, int MODE, bool STATS, bool GRAD, bool LIST>
+// Part `part` of `parts` of the order-K candidates: LISTED, the survivors of the region's list by rank; else the first
+// walls of first_wall_range(part, parts), by enumeration.
+template <int K, int MODE, bool STATS, bool GRAD, bool LIST, bool LISTED>
 __device__ __forceinline__ void sweep_order_any(const SweepArgs& a, const float4* tab, const float (&bx)[4], const float (&by)[4],
                                                 float rxx, float rxy, bool lane_bad, float& acc, WaveStats& st, GradCtx* g,
                                                 long region, int part, int parts, ListSink* sink) {
-    if constexpr (K >= 2) {
-        if (a.rl != nullptr) {
-            const int S = a.rl->S;  // a multiple of parts
-            sweep_order_listed<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, region, (part * S) / parts,
-                                                           ((part + 1) * S) / parts, sink);
-            return;
-        }
+    if constexpr (K >= 2 && LISTED) {
+        sweep_order_listed<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, region, part, parts, sink);
+    } else {
+        int lo = 0, hi = 0x7fffffff;
+        if (parts > 1) first_wall_range(a, part, parts, lo, hi);
+        sweep_order_culled<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, lo, hi, sink);
     }
-    int lo = 0, hi = 0x7fffffff;
-    if (parts > 1) first_wall_range(a, part, parts, lo, hi);
-    sweep_order_culled<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, lo, hi, sink);
 }
 
 // The region (R x R patches) of patch (tcol, trow)
 __device__ __forceinline__ long region_of(const SweepArgs& a, int tcol, int trow) {
-    if (a.rl == nullptr) return 0;
-    const int R = a.rl->R;
-    return (long)(trow / R) * a.rl->regions_x + (tcol / R);
+    const int R = a.rl->leaf.R;
+    return (long)(trow / R) * a.rl->leaf.regions_x + (tcol / R);
 }
 
 #ifndef D2D_HEAVY_PARTS
@@ -1466,19 +1530,17 @@ constexpr int TILE_H = 8;
 // candidates contribute exactly 0 to the value and to every adjoint; what culling cannot reproduce are the
 // reference's autodiff NaN artefacts of candidates it never evaluates (see DESIGN.md "NaN parity"): those are
 // covered by the exhaustive power_vg_kernel (d2d_params.strict_nan).
-template <int MODE, bool STATS, int MAXK, bool GRADK = false>
-__global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs a) {
+// LISTED: the orders >= 2 come from the region candidate lists (a.rl); a patch that cannot use them is queued for the
+// enumerating build of the same kernel (LISTED = false), which is launched right behind with a.fb_n set.
+template <int MODE, bool STATS, int MAXK, bool GRADK, bool LISTED>
+__device__ __forceinline__ void fwd_patch(const SweepArgs& a, const float4* tab, float* wl, const long b0, const bool from_queue) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
-    // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index), staged once per wave
-    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
-    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
-    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
-    float* wl = reinterpret_cast<float*>(tab + 3 * a.N);
     const bool scene = GRADK && a.partial != nullptr;
-    if (scene)
+    if (scene) {
         for (int i = lane; i < 4 * a.N; i += 64) wl[i] = 0.0f;
-    __syncthreads();
+        __syncthreads();
+    }
     float tbx_sum = 0.0f, tby_sum = 0.0f;  // scene VJP w.r.t. the fixed end point (wave sum)
     WaveStats st;
 #pragma unroll
@@ -1493,17 +1555,16 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     // four quarters of first walls, swept by four single-wave workgroups that leave their non-zero contributions as
     // ordered lists in global memory; the quarter that finishes last adds them up in candidate order (bit for bit the
     // reference's sum) and writes the cell.  A list cannot overflow: it holds as many entries as the quarter has candidates.
-    const long b0 = blockIdx.x;
-    const bool quarter = !STATS && !GRADK && MAXK == 2 && (b0 < (long)HEAVY_PARTS * a.n_heavy);  // wave-uniform
+    const bool quarter = !STATS && !GRADK && MAXK == 2 && !from_queue && (b0 < (long)HEAVY_PARTS * a.n_heavy);  // wave-uniform
     const long tile0 = quarter ? (b0 / HEAVY_PARTS) : (b0 - (long)(HEAVY_PARTS - 1) * a.n_heavy);
     const int part = quarter ? (int)(b0 % HEAVY_PARTS) : 0;
-    const long tile = a.sched ? (long)a.sched[tile0] : tile0;
+    const long tile = from_queue ? b0 : (a.sched ? (long)a.sched[tile0] : tile0);
 #ifdef D2D_AB_TIMELINE
     const unsigned long long t_line0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, common to all XCDs
 #endif
     const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tcol = (int)(tile % tiles_x), trow = (int)(tile / tiles_x);
-    const long region = region_of(a, tcol, trow);
+    const long region = LISTED ? region_of(a, tcol, trow) : 0;
     const int col = tcol * TILE_W + (lane & (TILE_W - 1));
     const int row = trow * TILE_H + (lane / TILE_W);
     const bool in_range = (col < a.n) && (row < a.m);
@@ -1513,6 +1574,13 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     const float rxx = a.X[idx], rxy = a.Y[idx];
     const bool lane_bad = !(fabsf(rxx) < 1e18f) || !(fabsf(rxy) < 1e18f) || !(fabsf(a.txx) < 1e18f) ||
                           !(fabsf(a.txy) < 1e18f);
+    if (LISTED) {
+        // not this kernel's patch: leave it (once) to the enumerating kernel
+        if (a.rl->flag[region] != 0 || wave_any(lane_bad)) {
+            if (part == 0 && lane == 0) a.fb_list[atomicAdd(a.fb_n, 1)] = (int)tile;
+            return;
+        }
+    }
     float acc = 0.0f;  // scene.py:1893
     GradCtx g;
     g.grx = g.gry = g.tbx = g.tby = 0.0f;
@@ -1583,7 +1651,7 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
                 sweep_order_culled<1, MODE, false, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, 0, 0x7fffffff, &sink);
         }
         if (a.min_order <= 2 && a.max_order >= 2)
-            sweep_order_any<2, MODE, false, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, region, part, HEAVY_PARTS, &sink);
+            sweep_order_any<2, MODE, false, false, true, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, region, part, HEAVY_PARTS, &sink);
         a.heavy_cnt[hq * 64 + lane] = sink.over ? -1 : sink.cnt;
         if (lane == 0) a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq] = (int)st.work;
         __threadfence();
@@ -1613,10 +1681,10 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
     unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[12] += tq2 - tq1;      // order 1
-    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_any<2, MODE, STATS, GRADK, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
+    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_any<2, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
     if (STATS) st.c[13] += __builtin_amdgcn_s_memtime() - tq2;  // order 2
-    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_any<3, MODE, STATS, GRADK, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
-    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_any<4, MODE, STATS, GRADK, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_any<3, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_any<4, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
     }
     if (in_range) {
         if (a.out_mode == D2D_OUT_ADD) {
@@ -1660,13 +1728,34 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     }
 }
 
+template <int MODE, bool STATS, int MAXK, bool GRADK = false, bool LISTED = false>
+__global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs a) {
+    const int lane = threadIdx.x & 63;
+    // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index), staged once per wave
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    float* wl = reinterpret_cast<float*>(tab + 3 * a.N);
+    __syncthreads();
+    if (!LISTED && a.fb_n != nullptr) {
+        // the patches the LISTED launch in front of this one left behind (usually none)
+        const int n = *a.fb_n;
+        for (int i = blockIdx.x; i < n; i += gridDim.x) {
+            fwd_patch<MODE, STATS, MAXK, GRADK, false>(a, tab, wl, (long)a.fb_list[i], true);
+            __syncthreads();
+        }
+        return;
+    }
+    fwd_patch<MODE, STATS, MAXK, GRADK, LISTED>(a, tab, wl, (long)blockIdx.x, false);
+}
+
 // Forward sweep with every 8 x 8 patch shared by W waves (one workgroup).  Patches differ a lot in cost and the dearest
 // ones sit on the critical path of a launch that only holds a few patches per SIMD (1024^2: 16), so the orders K >= 2
 // are cut into W contiguous ranges of first-wall positions (balanced over the first walls that the shadow masks do not
 // kill outright).  Wave 0 adds its range to acc directly; waves 1 .. W-1 record their non-zero contributions as ordered
 // per-lane lists in LDS, which wave 0 then adds in range order: the same left-to-right fp32 sum as the reference's
 // (scene.py:1893-1916), bit for bit.  A list that overflows is discarded and wave 0 redoes that range itself.
-template <int K, int MODE, bool STATS, int W>
+template <int K, int MODE, bool STATS, int W, bool LISTED>
 __device__ __forceinline__ void split_order(const SweepArgs& a, const float4* tab, float* lists, int* meta,
                                             const float (&bx)[4], const float (&by)[4], float rxx, float rxy,
                                             bool lane_bad, float& acc, WaveStats& st, long region) {
@@ -1680,7 +1769,7 @@ __device__ __forceinline__ void split_order(const SweepArgs& a, const float4* ta
         sink.cnt = 0;
         sink.over = false;
         float dummy = 0.0f;
-        sweep_order_any<K, MODE, STATS, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, region, wv, W, &sink);
+        sweep_order_any<K, MODE, STATS, false, true, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, region, wv, W, &sink);
         cnts[(wv - 1) * 64 + lane] = sink.cnt;
         const bool over = wave_any(sink.over);
         if (lane == 0) flags[wv - 1] = over ? 1 : 0;
@@ -1690,7 +1779,7 @@ __device__ __forceinline__ void split_order(const SweepArgs& a, const float4* ta
         if (w == 1) __syncthreads();  // uniform: every wave runs this loop
         if (wv == 0) {
             if (w == 0 || flags[w - 1]) {
-                sweep_order_any<K, MODE, STATS, false, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, nullptr, region, w, W, nullptr);
+                sweep_order_any<K, MODE, STATS, false, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, nullptr, region, w, W, nullptr);
             } else {
                 const int n = cnts[(w - 1) * 64 + lane];
                 int nmax = n;
@@ -1705,26 +1794,19 @@ __device__ __forceinline__ void split_order(const SweepArgs& a, const float4* ta
     __syncthreads();  // lists and meta are reused by the next order
 }
 
-template <int MODE, bool STATS, int MAXK, int W>
-__global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
+template <int MODE, bool STATS, int MAXK, int W, bool LISTED>
+__device__ __forceinline__ void split_patch(const SweepArgs& a, const float4* tab, float* lists, int* meta, const long slot, const bool from_queue) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
-    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then the contribution lists and their bookkeeping
-    for (int i = threadIdx.x; i < 2 * a.N; i += 64 * W) tab[i] = a.refl[i];
-    for (int i = threadIdx.x; i < a.N; i += 64 * W) tab[2 * a.N + i] = a.flt[i];
-    float* lists = reinterpret_cast<float*>(tab + 3 * a.N);
-    int* meta = reinterpret_cast<int*>(lists + (size_t)(W - 1) * SPLIT_LIST * 64);
-    __syncthreads();
-    const long slot = blockIdx.x;
     WaveStats st;
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.c[i] = 0;
     st.shadow = -1;
     st.work = 0;
     const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-    const int tile = a.sched ? a.sched[slot] : (int)slot;
+    const int tile = from_queue ? (int)slot : (a.sched ? a.sched[slot] : (int)slot);
     const int tcol = tile % tiles_x, trow = tile / tiles_x;
-    const long region = region_of(a, tcol, trow);
+    const long region = LISTED ? region_of(a, tcol, trow) : 0;
     const int col = tcol * TILE_W + (lane & (TILE_W - 1));
     const int row = trow * TILE_H + (lane / TILE_W);
     const bool in_range = (col < a.n) && (row < a.m);
@@ -1734,6 +1816,13 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
     const float rxx = a.X[idx], rxy = a.Y[idx];
     const bool lane_bad = !(fabsf(rxx) < 1e18f) || !(fabsf(rxy) < 1e18f) || !(fabsf(a.txx) < 1e18f) ||
                           !(fabsf(a.txy) < 1e18f);
+    if (LISTED) {
+        // not this kernel's patch (every wave of the workgroup sees the same cells): leave it to the enumerating kernel
+        if (a.rl->flag[region] != 0 || wave_any(lane_bad)) {
+            if (threadIdx.x == 0) a.fb_list[atomicAdd(a.fb_n, 1)] = tile;
+            return;
+        }
+    }
     float acc = 0.0f;  // scene.py:1893
     float x0 = rxx, x1 = rxx, y0 = rxy, y1 = rxy;
 #pragma unroll
@@ -1752,9 +1841,9 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
         if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, false>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, nullptr);
         if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, nullptr);
     }
-    if (a.min_order <= 2 && a.max_order >= 2) split_order<2, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st, region);
-    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) split_order<3, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st, region);
-    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) split_order<4, MODE, STATS, W>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st, region);
+    if (a.min_order <= 2 && a.max_order >= 2) split_order<2, MODE, STATS, W, LISTED>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st, region);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) split_order<3, MODE, STATS, W, LISTED>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st, region);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) split_order<4, MODE, STATS, W, LISTED>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st, region);
     if (writer && in_range) {
         if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
         else a.out[idx] = acc;
@@ -1762,6 +1851,7 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
     if (STATS && writer && lane == 0 && a.wave_cycles) a.wave_cycles[tile] = __builtin_amdgcn_s_memtime() - t_start;
     if (!STATS && a.cost_out) {  // workgroup-uniform: the work of the patch = the sum over its W waves
         __shared__ unsigned wave_work[W];
+        __syncthreads();  // (a workgroup that walks the queue reuses it)
         if (lane == 0) wave_work[wv] = st.work;
         __syncthreads();
         if (wv == 0 && lane == 0) {
@@ -1777,64 +1867,126 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
     }
 }
 
-// Region candidate lists: one wave per (region, slice of first walls).  The wave runs the prefix odometer and the full
-// tile-culling test of order K against the bounding box of the region's cells (R x R patches) and writes the survivors,
-// in candidate order, to the slice's list.  What holds for the box holds for every patch inside it, so a patch that only
-// looks at the listed candidates skips nothing but exact zeros.  A list is marked "not listed" (count -1) when it
-// overflows or when a cell of the region is not comfortably finite; its patches then enumerate that slice themselves.
+template <int MODE, bool STATS, int MAXK, int W, bool LISTED = false>
+__global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then the contribution lists and their bookkeeping
+    for (int i = threadIdx.x; i < 2 * a.N; i += 64 * W) tab[i] = a.refl[i];
+    for (int i = threadIdx.x; i < a.N; i += 64 * W) tab[2 * a.N + i] = a.flt[i];
+    float* lists = reinterpret_cast<float*>(tab + 3 * a.N);
+    int* meta = reinterpret_cast<int*>(lists + (size_t)(W - 1) * SPLIT_LIST * 64);
+    __syncthreads();
+    if (!LISTED && a.fb_n != nullptr) {
+        const int n = *a.fb_n;  // the patches the LISTED launch in front of this one left behind (usually none)
+        for (int i = blockIdx.x; i < n; i += gridDim.x) {
+            split_patch<MODE, STATS, MAXK, W, false>(a, tab, lists, meta, (long)a.fb_list[i], true);
+            __syncthreads();
+        }
+        return;
+    }
+    split_patch<MODE, STATS, MAXK, W, LISTED>(a, tab, lists, meta, (long)blockIdx.x, false);
+}
+
+// Bounding box of the cells of a region, from the level's table (region_box_kernel: {x0, x1, y0, y1}, x0 = NaN when a
+// cell is not comfortably finite); false when nothing may be culled for the region.
+__device__ __forceinline__ bool region_box(const SweepArgs& a, const float4* __restrict__ box, long region, float (&bx)[4], float (&by)[4]) {
+    const float4 b = box[region];
+    bx[0] = b.x; bx[1] = b.y; bx[2] = b.y; bx[3] = b.x;
+    by[0] = b.z; by[1] = b.z; by[2] = b.w; by[3] = b.w;
+    return (b.x <= b.y) && (b.z <= b.w) && (fabsf(a.txx) < 1e18f) && (fabsf(a.txy) < 1e18f);
+}
+
+// Region candidate lists by enumeration: one wave per (region, slice of first walls) of level `lv`.  The wave runs the
+// prefix odometer and the full tile-culling test of order K against the bounding box of the region's cells and writes
+// the survivors, in candidate order, to the slice's list.  What holds for the box holds for everything inside it, so
+// whoever only looks at the listed candidates skips nothing but exact zeros.  A list is marked "not listed" (count -1)
+// when the pool runs out or when a cell of the region is not comfortably finite.
 template <int K, bool GRAD>
-__global__ void __launch_bounds__(64) region_list_kernel(SweepArgs a, RegionLists rl) {
+__global__ void __launch_bounds__(64) region_list_kernel(SweepArgs a, RegionLevel lv, ListPool lp) {
     const int lane = threadIdx.x & 63;
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, the culling queue
     for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
     for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
     __syncthreads();
     const long rs = blockIdx.x;
-    const long region = rs / rl.S;
-    const int s = (int)(rs % rl.S);
-    const int ry = (int)(region / rl.regions_x), rx = (int)(region % rl.regions_x);
-    const int c0 = rx * rl.R * TILE_W, r0 = ry * rl.R * TILE_H;
-    const int c1 = min(c0 + rl.R * TILE_W, a.n), r1 = min(r0 + rl.R * TILE_H, a.m);
-    const float inf = __builtin_inff();
-    float x0 = inf, x1 = -inf, y0 = inf, y1 = -inf;
-    bool bad = !(fabsf(a.txx) < 1e18f) || !(fabsf(a.txy) < 1e18f);
-    for (int r = r0; r < r1; ++r)
-        for (int cc = c0 + lane; cc < c1; cc += 64) {
-            const float x = a.X[(long)r * a.n + cc], y = a.Y[(long)r * a.n + cc];
-            bad = bad || !(fabsf(x) < 1e18f) || !(fabsf(y) < 1e18f);
-            x0 = fminf(x0, x);
-            x1 = fmaxf(x1, x);
-            y0 = fminf(y0, y);
-            y1 = fmaxf(y1, y);
-        }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        x0 = fminf(x0, __shfl_xor(x0, off, 64));
-        x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
-        y0 = fminf(y0, __shfl_xor(y0, off, 64));
-        y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
-    }
-    int* cnt = rl.cnt[K] + rs;
-    if (wave_any(bad) || !(x0 <= x1) || !(y0 <= y1)) {
-        if (lane == 0) *cnt = -1;
-        return;
-    }
-    const float bx[4] = {x0, x1, x1, x0};
-    const float by[4] = {y0, y0, y1, y1};
-    int lo, hi;
-    first_wall_range(a, s, rl.S, lo, hi);
+    const long region = rs / lv.S;
+    const int s = (int)(rs % lv.S);
+    float bx[4], by[4];
+    const bool ok = region_box(a, lv.box, region, bx, by);
     EmitSink em;
-    em.dst = rl.codes[K] + (size_t)rs * rl.cap[K];
+    em.lp = lp;
+    em.cur = lv.chunk0[K] + (int)rs;
     em.n = 0;
-    em.cap = rl.cap[K];
-    WaveStats st;
+    em.over = !ok;
+    if (ok) {
+        int lo, hi;
+        first_wall_range(a, s, lv.S, lo, hi);
+        WaveStats st;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) st.c[i] = 0;
-    st.shadow = -1;
-    st.work = 0;
-    float dummy = 0.0f;
-    sweep_order_culled<K, MODE_HARD, false, GRAD, false, true>(a, tab, bx, by, 0.0f, 0.0f, false, dummy, st, nullptr, lo, hi, nullptr, &em);
-    if (lane == 0) *cnt = (em.n <= em.cap) ? em.n : -1;
+        for (int i = 0; i < 16; ++i) st.c[i] = 0;
+        st.shadow = -1;
+        st.work = 0;
+        float dummy = 0.0f;
+        sweep_order_culled<K, MODE_HARD, false, GRAD, false, true>(a, tab, bx, by, 0.0f, 0.0f, false, dummy, st, nullptr, lo, hi, nullptr, &em);
+    }
+    if (lane == 0) lv.cnt[K][rs] = em.over ? -1 : em.n;
+}
+
+// Region candidate lists by refinement: one wave per region of level `lv` (one list per region), whose R divides the
+// parent level's.  The wave gathers the parent region's lists (all slices, in order) through LDS into full batches and
+// keeps what the tile culling cannot drop for its own, smaller box.  `flag`: raised when the list is not listed.
+constexpr int RL_GATHER = 512;  // entries of the gather buffer (LDS)
+template <int K, bool GRAD>
+__global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLevel lv, RegionLevel parent, ListPool lp, int* flag) {
+    const int lane = threadIdx.x & 63;
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then the gather buffer
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    unsigned long long* buf = reinterpret_cast<unsigned long long*>(tab + 3 * a.N + 1);
+    __syncthreads();
+    const long region = blockIdx.x;
+    const int rx = (int)(region % lv.regions_x), ry = (int)(region / lv.regions_x);
+    float bx[4], by[4];
+    bool ok = region_box(a, lv.box, region, bx, by);
+    const int up = parent.R / lv.R;
+    const long pslot0 = ((long)(ry / up) * parent.regions_x + (rx / up)) * parent.S;
+    const int* pcnt = parent.cnt[K] + pslot0;
+    for (int ps = 0; ps < parent.S; ++ps) ok = ok && (pcnt[ps] >= 0);
+    EmitSink em;
+    em.lp = lp;
+    em.cur = lv.chunk0[K] + (int)region;
+    em.n = 0;
+    em.over = !ok;
+    if (ok) {
+        int total = 0;
+        auto process = [&]() {
+            __builtin_amdgcn_wave_barrier();
+            for (int off = 0; off < total; off += 64) {
+                const bool have = off + lane < total;
+                const unsigned long long code = buf[have ? off + lane : off];
+                float Ix[K], Iy[K];
+                const unsigned long long mask = cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy);
+                emit_batch(em, code, have && ((mask >> lane) & 1ull), mask);
+            }
+            total = 0;
+            __builtin_amdgcn_wave_barrier();
+        };
+        for (int ps = 0; ps < parent.S; ++ps) {
+            const int n = pcnt[ps];
+            int chunk = parent.chunk0[K] + (int)(pslot0 + ps);
+            for (int off = 0; off < n; off += 64) {
+                if (total + 64 > RL_GATHER) process();
+                const int m = min(64, n - off);
+                if (lane < m) buf[total + lane] = lp.pool[(size_t)chunk * RL_CHUNK + (off & (RL_CHUNK - 1)) + lane];
+                total += m;
+                if ((off & (RL_CHUNK - 1)) == RL_CHUNK - 64 && off + 64 < n) chunk = lp.next[chunk];
+            }
+        }
+        process();
+    }
+    if (lane == 0) {
+        lv.cnt[K][region] = em.over ? -1 : em.n;
+        if (em.over) flag[region] = 1;
+    }
 }
 
 // TX grids (scene.py:1489-1648): the cells are transmitters, (a.txx, a.txy) is the fixed receiver F.  The reference's op
@@ -2108,6 +2260,52 @@ __global__ void __launch_bounds__(256) patch_order_kernel(const unsigned char* _
     for (int i = 0; i < SCHED_PER_THREAD; ++i) {
         const long t = base + (long)i * 256 + threadIdx.x;
         if (t < n_tiles) sched[start[key[t]] + local[i]] = (int)t;
+    }
+}
+
+// Bounding boxes of the cells of every region of R x R patches (one 256-thread workgroup per region): {x0, x1, y0, y1},
+// x0 = NaN when some cell is not comfortably finite.  Depends on the grid only: rebuilt when the grid or R changes.
+__global__ void __launch_bounds__(256) region_box_kernel(const float* __restrict__ X, const float* __restrict__ Y, int m, int n, int R,
+                                                         int regions_x, float4* __restrict__ box) {
+    const int region = blockIdx.x;
+    const int rx = region % regions_x, ry = region / regions_x;
+    const int c0 = rx * R * TILE_W, r0 = ry * R * TILE_H;
+    const int c1 = min(c0 + R * TILE_W, n), r1 = min(r0 + R * TILE_H, m);
+    const int w = c1 - c0, cells = w * (r1 - r0);
+    const float inf = __builtin_inff();
+    float x0 = inf, x1 = -inf, y0 = inf, y1 = -inf;
+    bool bad = false;
+    for (int i = threadIdx.x; i < cells; i += 256) {
+        const long idx = (long)(r0 + i / w) * n + (c0 + i % w);
+        const float x = X[idx], y = Y[idx];
+        bad = bad || !(fabsf(x) < 1e18f) || !(fabsf(y) < 1e18f);
+        x0 = fminf(x0, x);
+        x1 = fmaxf(x1, x);
+        y0 = fminf(y0, y);
+        y1 = fmaxf(y1, y);
+    }
+    __shared__ float sm[4][4];
+    __shared__ int sbad[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, off, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
+        y0 = fminf(y0, __shfl_xor(y0, off, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+    }
+    const bool wbad = __any(bad);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sm[wv][0] = x0; sm[wv][1] = x1; sm[wv][2] = y0; sm[wv][3] = y1;
+        sbad[wv] = wbad ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) {
+            x0 = fminf(x0, sm[i][0]); x1 = fmaxf(x1, sm[i][1]); y0 = fminf(y0, sm[i][2]); y1 = fmaxf(y1, sm[i][3]);
+        }
+        const bool anybad = sbad[0] | sbad[1] | sbad[2] | sbad[3];
+        box[region] = make_float4(anybad ? __builtin_nanf("") : x0, x1, y0, y1);
     }
 }
 

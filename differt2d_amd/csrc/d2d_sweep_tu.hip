@@ -1,6 +1,7 @@
 // One translation unit per (kernel family, validity mode): instantiates the sweep kernels of that pair and defines the
 // per-mode launcher that d2d_launch.cpp's dispatchers call.  Compiled several times by the Makefile with
-//   -DD2D_TU_FAMILY={0 fwd, 1 fwd_grad, 2 fwd_split, 3 txg, 4 vg, 5 region lists (mode 0 only)}  -DD2D_TU_MODE={0 hard, 1 hard_sigmoid, 2 sigmoid}
+//   -DD2D_TU_FAMILY={0 fwd, 1 fwd_grad, 2 fwd_split, 3 txg, 4 vg, 5 region lists (mode 0 only),
+//   6 fwd / 7 fwd_grad / 8 fwd_split with the orders >= 2 taken from the region lists (LISTED)}  -DD2D_TU_MODE={0 hard, 1 hard_sigmoid, 2 sigmoid}
 #include "d2d_launch.hpp"
 
 #ifndef D2D_TU_FAMILY
@@ -79,18 +80,75 @@ hipError_t launch_vg_m<TU_MODE>(bool txg, bool grad, dim3 grid, size_t lds, hipS
     else hipLaunchKernelGGL((power_vg_kernel<TU_MODE, false, true>), grid, block, lds, s, a);  // (RX grid, values only: launch_fwd)
     return hipGetLastError();
 }
+#elif D2D_TU_FAMILY == 6
+template <int MODE> hipError_t launch_fwd_listed_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <>
+hipError_t launch_fwd_listed_m<TU_MODE>(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    const dim3 block(64);
+    if (stats) {
+        if (max_order <= 2) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, true, 2, false, true>), grid, block, lds, s, a);
+        else if (max_order == 3) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, true, 3, false, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, true, 4, false, true>), grid, block, lds, s, a);
+    } else {
+        if (max_order <= 2) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 2, false, true>), grid, block, lds, s, a);
+        else if (max_order == 3) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 3, false, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 4, false, true>), grid, block, lds, s, a);
+    }
+    return hipGetLastError();
+}
+#elif D2D_TU_FAMILY == 7
+template <int MODE> hipError_t launch_fwd_grad_listed_m(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <>
+hipError_t launch_fwd_grad_listed_m<TU_MODE>(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    const dim3 block(64);
+    if (max_order <= 2) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 2, true, true>), grid, block, lds, s, a);
+    else if (max_order == 3) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 3, true, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 4, true, true>), grid, block, lds, s, a);
+    return hipGetLastError();
+}
+#elif D2D_TU_FAMILY == 8
+template <int MODE> hipError_t launch_fwd_split_listed_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <>
+hipError_t launch_fwd_split_listed_m<TU_MODE>(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    const dim3 block(64 * SPLIT_W);
+    if (stats) {
+        if (max_order <= 2) hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, true, 2, SPLIT_W, true>), grid, block, lds, s, a);
+        else if (max_order == 3) hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, true, 3, SPLIT_W, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, true, 4, SPLIT_W, true>), grid, block, lds, s, a);
+    } else {
+        if (max_order <= 2) hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, false, 2, SPLIT_W, true>), grid, block, lds, s, a);
+        else if (max_order == 3) hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, false, 3, SPLIT_W, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, false, 4, SPLIT_W, true>), grid, block, lds, s, a);
+    }
+    return hipGetLastError();
+}
 #elif D2D_TU_FAMILY == 5
-// region_list_kernel<K, GRAD>: independent of the validity mode (compiled once, -DD2D_TU_MODE=0)
-hipError_t launch_region_lists(int K, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a, const RegionLists& rl) {
+// region_list_kernel / region_refine_kernel <K, GRAD>: independent of the validity mode (compiled once, -DD2D_TU_MODE=0)
+hipError_t launch_region_lists(int K, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a, const RegionLevel& lv,
+                               const ListPool& lp) {
     const dim3 block(64);
     if (grad) {
-        if (K == 2) hipLaunchKernelGGL((region_list_kernel<2, true>), grid, block, lds, s, a, rl);
-        else if (K == 3) hipLaunchKernelGGL((region_list_kernel<3, true>), grid, block, lds, s, a, rl);
-        else hipLaunchKernelGGL((region_list_kernel<4, true>), grid, block, lds, s, a, rl);
+        if (K == 2) hipLaunchKernelGGL((region_list_kernel<2, true>), grid, block, lds, s, a, lv, lp);
+        else if (K == 3) hipLaunchKernelGGL((region_list_kernel<3, true>), grid, block, lds, s, a, lv, lp);
+        else hipLaunchKernelGGL((region_list_kernel<4, true>), grid, block, lds, s, a, lv, lp);
     } else {
-        if (K == 2) hipLaunchKernelGGL((region_list_kernel<2, false>), grid, block, lds, s, a, rl);
-        else if (K == 3) hipLaunchKernelGGL((region_list_kernel<3, false>), grid, block, lds, s, a, rl);
-        else hipLaunchKernelGGL((region_list_kernel<4, false>), grid, block, lds, s, a, rl);
+        if (K == 2) hipLaunchKernelGGL((region_list_kernel<2, false>), grid, block, lds, s, a, lv, lp);
+        else if (K == 3) hipLaunchKernelGGL((region_list_kernel<3, false>), grid, block, lds, s, a, lv, lp);
+        else hipLaunchKernelGGL((region_list_kernel<4, false>), grid, block, lds, s, a, lv, lp);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_region_refine(int K, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a, const RegionLevel& lv,
+                                const RegionLevel& parent, const ListPool& lp, int* flag) {
+    const dim3 block(64);
+    if (grad) {
+        if (K == 2) hipLaunchKernelGGL((region_refine_kernel<2, true>), grid, block, lds, s, a, lv, parent, lp, flag);
+        else if (K == 3) hipLaunchKernelGGL((region_refine_kernel<3, true>), grid, block, lds, s, a, lv, parent, lp, flag);
+        else hipLaunchKernelGGL((region_refine_kernel<4, true>), grid, block, lds, s, a, lv, parent, lp, flag);
+    } else {
+        if (K == 2) hipLaunchKernelGGL((region_refine_kernel<2, false>), grid, block, lds, s, a, lv, parent, lp, flag);
+        else if (K == 3) hipLaunchKernelGGL((region_refine_kernel<3, false>), grid, block, lds, s, a, lv, parent, lp, flag);
+        else hipLaunchKernelGGL((region_refine_kernel<4, false>), grid, block, lds, s, a, lv, parent, lp, flag);
     }
     return hipGetLastError();
 }

@@ -219,6 +219,11 @@ int d2d_set_option(d2d_ctx* ctx, const char* name, int64_t value);
  * of 0..n-1) instead; n = 0 removes the override. */
 int d2d_debug_set_schedule(d2d_ctx* ctx, const int32_t* order, int64_t n);
 int d2d_debug_get_schedule(d2d_ctx* ctx, int32_t* order, uint8_t* key, int64_t n);
+/* Region candidate lists of the last launch that built any (all zeros otherwise): out[0] pool chunks handed out,
+ * [1] pool chunks available, [2] patches left to the enumerating kernel, [3] leaf regions with a list that is not listed,
+ * [4] / [5] / [6] entries of the leaf lists of order 2 / 3 / 4, [7] leaf regions.  Waits for the stream. */
+int d2d_debug_region_stats(d2d_ctx* ctx, int64_t* out /* [8] */);
+
 /* The work history behind the schedule: what each of the n patches took in the last culled sweep (units of ~25
  * wave-instructions, counted by the kernels). */
 int d2d_debug_get_work(d2d_ctx* ctx, uint32_t* work, int64_t n);
