@@ -31,6 +31,27 @@
 
 namespace d2d {
 
+// Tables that no kernel writes while it reads them (scene constants, masks and lists built by the kernels in front) are
+// read through the constant address space: a wave-uniform index then always becomes a scalar load (s_load, scalar
+// cache), also behind stores the compiler cannot tell apart from the table (a plain global load is only scalarised when
+// nothing in front of it may have clobbered it).
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* cmem(const T* p) {
+    return (const __attribute__((address_space(4))) T*)(unsigned long long)p;
+}
+
+// (class types such as float4 cannot be copied out of another address space: go through the built-in vector types)
+__device__ __forceinline__ float4 ldc4(const float4* p, long i) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = ((const __attribute__((address_space(4))) v4f*)(unsigned long long)p)[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int4 ldc4i(const int4* p, long i) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i v = ((const __attribute__((address_space(4))) v4i*)(unsigned long long)p)[i];
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+
 enum Mode { MODE_HARD = 0, MODE_HSIG = 1, MODE_SIG = 2 };
 
 // Region candidate lists: for every order K >= 2, every region of R x R patches and every slice of first-wall positions,
@@ -61,7 +82,38 @@ struct RegionLists {
     int* flag;         // [leaf regions] != 0: some list of the region is not listed
 };
 
+// Spilled candidates.  A patch evaluates its first `u0` surviving candidates itself; whatever survives the culling
+// beyond that (the dear patches of a launch: next to the transmitter a patch can hold ten times the mean) is handed
+// over, in candidate order, as units of at most U candidates that spill_eval_kernel evaluates one wave per unit; the
+// contributions that are not exactly zero come back as records and spill_merge_kernel adds them, in candidate order, to
+// the sum the patch had reached -- the same left-to-right fp32 sum as the reference's (scene.py:1893-1916), bit for bit.
+struct Spill {
+    int* counters;               // [0] entries, [1] nodes, [2] units, [3] spilled patches, [4] records, [5] patches given up, [6] entries of all leaf lists
+    unsigned long long* codes;   // [cap_entries] candidate (12 bits per wall index, first wall lowest) | order << 56
+    int* rec_of;                 // [cap_entries] the record of an entry's contribution, -1: exactly zero in every lane
+    int4* nodes;                 // [cap_nodes] {first entry, entries (<= 64), -, -}: what one batch of a patch spilled
+    int* node_next;              // [cap_nodes] the patch's next node, -1 at the end
+    int4* units;                 // [cap_units] {patch, first entry, entries (<= U), -}
+    int* tiles;                  // [patches] the spilled patches (-1: given up, the enumerating kernel redoes it)
+    int* tile_first;             // [patches] first node of spilled patch i
+    float* acc;                  // [patches][64] the sum the patch had reached when it began to spill
+    float* vals;                 // [cap_recs][64] records
+    int cap_entries, cap_nodes, cap_units, cap_recs;
+    int U;
+    int w0;            // a patch spills what is left once its work counter has reached this (units of ~25 wave-instructions)
+};
+// wave-uniform state of a patch that may spill
+struct SpillSink {
+    const Spill* sp;  // null: never spills
+    unsigned w0;      // the patch spills what is left once its work counter (WaveStats::work) has reached this
+    int slot;         // index into Spill::tiles once the patch has spilled, else -1
+    int last_node;
+    int tile;
+    bool dead;        // an allocation failed after the patch began to spill: the enumerating kernel redoes the patch
+};
+
 struct SweepArgs {
+    const Spill* __restrict__ sp;        // LISTED forward kernels: where dear patches spill candidates to (or null)
     const RegionLists* __restrict__ rl;  // LISTED kernels: device copy of the lists' descriptor
     // Patches a LISTED kernel cannot take (a list of their region is not listed, or a cell is not comfortably finite) are
     // queued here and swept by the enumerating kernel launched right behind it (fb_n != null there: workgroups walk the queue)
@@ -280,9 +332,9 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // candidate before any exact division.  (Not in the GRAD build: the reference's autodiff NaN traps depend
     // on all interaction points.)
     if (PREF && !GRAD && K > 0) {
-        const float4 r0 = a.refl[2 * cand[K - 1]];
-        const float4 r1 = a.refl[2 * cand[K - 1] + 1];
-        const float4 fc = a.flt[cand[K - 1]];
+        const float4 r0 = ldc4(a.refl, 2 * cand[K - 1]);
+        const float4 r1 = ldc4(a.refl, 2 * cand[K - 1] + 1);
+        const float4 fc = ldc4(a.flt, cand[K - 1]);
         float ux = rxx - imgx[K - 1], uy = rxy - imgy[K - 1];
         float vx = r0.x - rxx, vy = r0.y - rxy;
         float un = ux * r0.z + uy * r0.w;
@@ -309,7 +361,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         float ptx = rxx, pty = rxy;
 #pragma unroll
         for (int i = K - 1; i >= 0; --i) {
-            const float4 r0 = a.refl[2 * cand[i]];
+            const float4 r0 = ldc4(a.refl, 2 * cand[i]);
             float ux = ptx - imgx[i], uy = pty - imgy[i];
             float vx = r0.x - ptx, vy = r0.y - pty;
             float un = ux * r0.z + uy * r0.w;
@@ -366,8 +418,8 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     bool nanflag = false;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        const float4 r0 = a.refl[2 * cand[i]];
-        const float4 r1 = a.refl[2 * cand[i] + 1];
+        const float4 r0 = ldc4(a.refl, 2 * cand[i]);
+        const float4 r1 = ldc4(a.refl, 2 * cand[i] + 1);
         float dx = px[i + 1] - r0.x, dy = py[i + 1] - r0.y;
         float s = div1_exact(r1.x * dx + r1.y * dy, r1.z);
         if (MODE == MODE_HARD) {
@@ -416,15 +468,16 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     bool active = live;     // lanes still undecided
     // The wall that finished off the previous candidate of this wave is tried first ("shadow cache"): or / max
     // do not depend on the order of the tests, and neighbouring candidates tend to share their occluder.
-    for (int jj = -1; jj < a.N; ++jj) {
-        int j = jj;
-        if (jj < 0) {
-            if (st.shadow < 0 || st.shadow >= a.N) continue;
-            j = st.shadow;
-        } else if (jj == st.shadow) {
-            continue;
-        }
-        const float4 w = a.occl[j];
+    // (the next wall's data are fetched while this one is tested: a lone wave would otherwise sit out one scalar-load
+    // latency per wall)
+    const int sh = (st.shadow >= 0 && st.shadow < a.N) ? st.shadow : -1;
+    int j = sh >= 0 ? sh : 0;
+    int nxt = sh >= 0 ? 0 : 1;
+    if (nxt == sh) ++nxt;
+    float4 w = ldc4(a.occl, a.N > 0 ? j : 0);
+    for (bool more = a.N > 0; more;) {
+        const bool has_next = nxt < a.N;
+        const float4 wn = ldc4(a.occl, has_next ? nxt : j);
 #pragma unroll
         for (int i = 0; i <= K; ++i) {
             const int ig0 = (i == 0) ? -1 : cand[i - 1];
@@ -486,6 +539,11 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             st.shadow = j;
             break;
         }
+        more = has_next;
+        j = nxt;
+        w = wn;
+        ++nxt;
+        if (nxt == sh) ++nxt;
     }
     // every lane occluded (or off its walls): valid == 0 whatever the loss is
     if (!wave_any(active)) return;
@@ -514,7 +572,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         float bound = 0.0f;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            const float4 r0 = a.refl[2 * cand[i]];
+            const float4 r0 = ldc4(a.refl, 2 * cand[i]);
             float s2 = 2.0f * __builtin_fmaf(nvx[i], r0.z, nvy[i] * r0.w);
             float ex = __builtin_fmaf(s2, r0.z, nvx[i + 1] - nvx[i]);
             float ey = __builtin_fmaf(s2, r0.w, nvy[i + 1] - nvy[i]);
@@ -526,7 +584,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     if (!loss_known) {
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            const float4 r0 = a.refl[2 * cand[i]];
+            const float4 r0 = ldc4(a.refl, 2 * cand[i]);
             float ix, iy, rx_, ry_;
             normalize2(px[i + 1] - px[i], py[i + 1] - py[i], ix, iy);
             normalize2(px[i + 2] - px[i + 1], py[i + 2] - py[i + 1], rx_, ry_);
@@ -623,7 +681,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             if (K > 0 && wave_any(lossbar != 0.0f)) {
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
-                    const float4 r0 = a.refl[2 * cand[i]];
+                    const float4 r0 = ldc4(a.refl, 2 * cand[i]);
                     float v1x = px[i + 1] - px[i], v1y = py[i + 1] - py[i];
                     float v2x = px[i + 2] - px[i + 1], v2y = py[i + 2] - py[i + 1];
                     float ix, iy, rx_, ry_;
@@ -652,8 +710,8 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             if (K > 0) {
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
-                    const float4 r0 = a.refl[2 * cand[i]];
-                    const float4 r1 = a.refl[2 * cand[i] + 1];
+                    const float4 r0 = ldc4(a.refl, 2 * cand[i]);
+                    const float4 r1 = ldc4(a.refl, 2 * cand[i] + 1);
                     float dx = px[i + 1] - r0.x, dy = py[i + 1] - r0.y;
                     float s = (r1.x * dx + r1.y * dy) / r1.z;
                     float x = on_w ? (1.0f - s) : (s - 0.0f);
@@ -672,7 +730,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             occ = (sel == 1) && (hit_j >= 0) && (vbar != 0.0f);
             if (wave_any(occ)) {
                 const int jj = occ ? hit_j : 0;
-                const float4 w = a.occl[jj];
+                const float4 w = ldc4(a.occl, jj);
                 float qx = 0.0f, qy = 0.0f, q1x = 0.0f, q1y = 0.0f;  // P3 = p[hit_i], P4 = p[hit_i + 1]
 #pragma unroll
                 for (int i = 0; i <= K; ++i)
@@ -724,7 +782,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         for (int i = 0; i < KK; ++i) ibx_[i] = iby_[i] = 0.0f;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            const float4 r0 = a.refl[2 * cand[i]];
+            const float4 r0 = ldc4(a.refl, 2 * cand[i]);
             const float ptx = px[i + 2], pty = py[i + 2];  // the point the step started from
             float ux = ptx - imgx[i], uy = pty - imgy[i];
             float vx = r0.x - ptx, vy = r0.y - pty;
@@ -750,7 +808,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         float txbx = pbx[0], txby = pby[0];
 #pragma unroll
         for (int i = K - 1; i >= 0; --i) {
-            const float4 r0 = a.refl[2 * cand[i]];
+            const float4 r0 = ldc4(a.refl, 2 * cand[i]);
             const float prx = (i == 0) ? txx : imgx[i > 0 ? i - 1 : 0];
             const float pry = (i == 0) ? txy : imgy[i > 0 ? i - 1 : 0];
             float wx = prx - r0.x, wy = pry - r0.y;
@@ -776,8 +834,8 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             // normals -> wall end points: n = m / len, m = (t_y, -t_x); t = dest - origin
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-                const float4 r0 = a.refl[2 * cand[i]];
-                const float4 r1 = a.refl[2 * cand[i] + 1];
+                const float4 r0 = ldc4(a.refl, 2 * cand[i]);
+                const float4 r1 = ldc4(a.refl, 2 * cand[i] + 1);
                 float len = r1.w;  // |t| guarded to 1
                 bool z = (r1.x * r1.x + r1.y * r1.y == 0.0f);
                 float d = z ? 0.0f : (nbx[i] * r0.z + nby[i] * r0.w);
@@ -823,32 +881,32 @@ __device__ __forceinline__ void sweep_order(const SweepArgs& a, float txx, float
         return;
     }
     for (int i0 = 0; i0 < a.Nc; ++i0) {
-        cand[0] = a.cw[i0];
-        image_of(a.refl[2 * cand[0]], txx, txy, imgx[0], imgy[0]);
+        cand[0] = cmem(a.cw)[i0];
+        image_of(ldc4(a.refl, 2 * cand[0]), txx, txy, imgx[0], imgy[0]);
         if (K == 1) {
             eval_candidate<K, MODE, STATS, GRAD, true, TXG>(a, cand, imgx, imgy, txx, txy, rxx, rxy, lane_bad, acc, st, g);
             continue;
         }
         for (int i1 = 0; i1 < a.Nc; ++i1) {
-            cand[1] = a.cw[i1];
+            cand[1] = cmem(a.cw)[i1];
             if (cand[1] == cand[0]) continue;
-            image_of(a.refl[2 * cand[1]], imgx[0], imgy[0], imgx[1], imgy[1]);
+            image_of(ldc4(a.refl, 2 * cand[1]), imgx[0], imgy[0], imgx[1], imgy[1]);
             if (K == 2) {
                 eval_candidate<K, MODE, STATS, GRAD, true, TXG>(a, cand, imgx, imgy, txx, txy, rxx, rxy, lane_bad, acc, st, g);
                 continue;
             }
             for (int i2 = 0; i2 < a.Nc; ++i2) {
-                cand[2] = a.cw[i2];
+                cand[2] = cmem(a.cw)[i2];
                 if (cand[2] == cand[1]) continue;
-                image_of(a.refl[2 * cand[2]], imgx[1], imgy[1], imgx[2], imgy[2]);
+                image_of(ldc4(a.refl, 2 * cand[2]), imgx[1], imgy[1], imgx[2], imgy[2]);
                 if (K == 3) {
                     eval_candidate<K, MODE, STATS, GRAD, true, TXG>(a, cand, imgx, imgy, txx, txy, rxx, rxy, lane_bad, acc, st, g);
                     continue;
                 }
                 for (int i3 = 0; i3 < a.Nc; ++i3) {
-                    cand[3] = a.cw[i3];
+                    cand[3] = cmem(a.cw)[i3];
                     if (cand[3] == cand[2]) continue;
-                    image_of(a.refl[2 * cand[3]], imgx[2], imgy[2], imgx[3], imgy[3]);
+                    image_of(ldc4(a.refl, 2 * cand[3]), imgx[2], imgy[2], imgx[3], imgy[3]);
                     eval_candidate<(K >= 4 ? 4 : K), MODE, STATS, GRAD, true, TXG>(a, cand, imgx, imgy, txx, txy, rxx, rxy, lane_bad, acc, st, g);
                 }
             }
@@ -975,7 +1033,7 @@ __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float
                 const int wl_ = WIDE ? w[lvl].idx : w[lvl + 1 < K ? lvl + 1 : lvl].idx;  // later wall (P4 side)
                 const int ea = WIDE ? pka : ka, eb = WIDE ? pkb : kb;   // earlier wall's bin range
                 const int la = WIDE ? ka : pka, lb = WIDE ? kb : pkb;   // later wall's bin range
-                const unsigned long long m = a.pair[(size_t)we * a.N + wl_];
+                const unsigned long long m = cmem(a.pair)[(size_t)we * a.N + wl_];
                 const unsigned long long row = (unsigned long long)(((1u << (eb + 1)) - 1u) & ~((1u << ea) - 1u));
                 unsigned long long need = row * 0x0101010101010101ull;
                 const unsigned long long rows = (lb >= 7 ? ~0ull : ((1ull << (8 * (lb + 1))) - 1ull)) & ~((1ull << (8 * la)) - 1ull);
@@ -1071,6 +1129,67 @@ __device__ __forceinline__ void emit_batch(EmitSink& e, unsigned long long code,
     e.n = start + cntm;
 }
 
+// Hands the candidates of the lanes in `mask` (in lane order) over to spill_eval_kernel.  False: nothing could be
+// allocated (the caller then either evaluates them itself or gives the patch up).
+__device__ __forceinline__ bool spill_mask(SpillSink& k, int K, unsigned long long code, unsigned long long mask) {
+    const int lane = threadIdx.x & 63;
+    const Spill* sp = k.sp;
+    const int cnt = __builtin_popcountll(mask);
+    const int U = sp->U;
+    const int nunits = (cnt + U - 1) / U;
+    int base = 0, node = 0, ub = 0, slot = k.slot;
+    if (lane == 0) {
+        base = atomicAdd(&sp->counters[0], cnt);
+        node = atomicAdd(&sp->counters[1], 1);
+        ub = atomicAdd(&sp->counters[2], nunits);
+        if (slot < 0) slot = atomicAdd(&sp->counters[3], 1);
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    node = __builtin_amdgcn_readfirstlane(node);
+    ub = __builtin_amdgcn_readfirstlane(ub);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    const bool ok = base + cnt <= sp->cap_entries && node < sp->cap_nodes && ub + nunits <= sp->cap_units;
+    // slots that were handed out are always filled in (the kernels behind walk all of them)
+    if (lane < nunits && ub + lane < sp->cap_units) {
+        const int c = ok ? min(U, cnt - lane * U) : 0;
+        sp->units[ub + lane] = make_int4(k.tile, base + lane * U, c, slot);
+    }
+    if (lane == 0) {
+        if (node < sp->cap_nodes) {
+            sp->nodes[node] = make_int4(base, ok ? cnt : 0, 0, 0);
+            sp->node_next[node] = -1;
+        }
+        if (k.slot < 0) {
+            sp->tiles[slot] = k.tile;
+            sp->tile_first[slot] = (node < sp->cap_nodes) ? node : -1;
+        } else if (node < sp->cap_nodes && k.last_node >= 0) {
+            sp->node_next[k.last_node] = node;
+        }
+    }
+    k.slot = slot;
+    if (node < sp->cap_nodes) k.last_node = node;
+    if (!ok) return false;
+    if ((mask >> lane) & 1ull) sp->codes[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = code | ((unsigned long long)K << 56);
+    return true;
+}
+
+// Spills the surviving candidates in `mask` (what is left of a batch) when the patch has done its share of work; true:
+// they are gone (spilled -- or the patch is given up because the buffers are full: the enumerating kernel redoes it).
+// Once a patch has spilled, everything behind is spilled too (its own sum must stay a prefix of the whole).
+__device__ __forceinline__ bool spill_rest(SpillSink& k, int K, unsigned long long code, unsigned long long mask, unsigned work) {
+    if (k.sp == nullptr) return false;
+    if (k.dead) return true;
+    if (k.slot < 0 && work < k.w0) return false;
+    if (mask && !spill_mask(k, K, code, mask)) {
+        k.dead = true;
+        if ((threadIdx.x & 63) == 0) {
+            k.sp->tiles[k.slot] = -1;
+            atomicAdd(&k.sp->counters[5], 1);
+        }
+    }
+    return true;
+}
+
 // All candidates of order K >= 1 with tile culling; `tab` = LDS copy of {refl[2N], flt[N]}.
 // K >= 2: only the prefixes whose FIRST position lies in [p_lo, p_hi) (positions into cw[]).  LIST: instead of being
 // added to acc, every contribution that is not exactly zero is appended to `sink` (adding an exact zero never changes
@@ -1081,7 +1200,8 @@ template <int K, int MODE, bool STATS, bool GRAD = false, bool LIST = false, boo
 __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                    const float (&by)[4], float rxx, float rxy, bool lane_bad, float& acc,
                                                    WaveStats& st, GradCtx* g = nullptr, int p_lo = 0,
-                                                   int p_hi = 0x7fffffff, ListSink* sink = nullptr, EmitSink* emit = nullptr) {
+                                                   int p_hi = 0x7fffffff, ListSink* sink = nullptr, EmitSink* emit = nullptr,
+                                                   SpillSink* spill = nullptr) {
     static_assert(!EMIT || K >= 2, "lists exist for orders >= 2");
     const int lane = threadIdx.x & 63;
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
@@ -1106,7 +1226,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int p0 = c * 64 + lane;
-            fmask[c] = __ballot(p0 < Nc && a.shadow[a.cw[p0 < Nc ? p0 : 0]] != ~0ull);
+            fmask[c] = __ballot(p0 < Nc && cmem(a.shadow)[cmem(a.cw)[p0 < Nc ? p0 : 0]] != ~0ull);
         }
     }
     auto next_first = [&](int from) -> int {
@@ -1153,7 +1273,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 ix = Ix[d];
                 iy = Iy[d];
             }
-            const unsigned long long sh0 = a.shadow ? a.shadow[w[0].idx] : 0ull;
+            const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[w[0].idx] : 0ull;
             const bool bypass = GRAD && ((code >> 60) & 1ull);
             if (alive2 && !bypass && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive2 = false;
         }
@@ -1177,7 +1297,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
 #pragma unroll
             for (int d = 0; d < K; ++d) {
                 ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
-                image_of(a.refl[2 * ce[d]], d == 0 ? a.txx : ex[d > 0 ? d - 1 : 0], d == 0 ? a.txy : ey[d > 0 ? d - 1 : 0], ex[d], ey[d]);
+                image_of(ldc4(a.refl, 2 * ce[d]), d == 0 ? a.txx : ex[d > 0 ? d - 1 : 0], d == 0 ? a.txy : ey[d > 0 ? d - 1 : 0], ex[d], ey[d]);
             }
             if (LIST) {
                 float t = 0.0f;
@@ -1212,11 +1332,11 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
     while (true) {
         bool skip_all = false;
         if (use_amask && amask_for != pos[0]) {
-            const int w0 = a.cw[pos[0]];
+            const int w0 = cmem(a.cw)[pos[0]];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int p1 = c * 64 + lane;
-                const bool ok = p1 < Nc && p1 != pos[0] && a.pair[(size_t)w0 * a.N + a.cw[p1 < Nc ? p1 : 0]] != ~0ull;
+                const bool ok = p1 < Nc && p1 != pos[0] && cmem(a.pair)[(size_t)w0 * a.N + cmem(a.cw)[p1 < Nc ? p1 : 0]] != ~0ull;
                 amask[c] = __ballot(ok);
             }
             amask_for = pos[0];
@@ -1227,8 +1347,8 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         // images of the prefix
 #pragma unroll
         for (int d = 0; d < K - 1; ++d) {
-            cand[d] = a.cw[pos[d]];
-            const float4 r0 = a.refl[2 * cand[d]];
+            cand[d] = cmem(a.cw)[pos[d]];
+            const float4 r0 = ldc4(a.refl, 2 * cand[d]);
             image_of(r0, d == 0 ? a.txx : imgx[d > 0 ? d - 1 : 0], d == 0 ? a.txy : imgy[d > 0 ? d - 1 : 0], imgx[d], imgy[d]);
         }
         const float pIx = (K == 1) ? a.txx : imgx[K >= 2 ? K - 2 : 0];
@@ -1245,7 +1365,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         // NaN whether or not the candidate is valid.  A dead prefix therefore keeps the candidates whose last-wall pole
         // may cross the patch (a cheap test, few survivors) and evaluates those exactly.  NaN artefacts that only arise
         // deeper in a dead prefix's chain are not reproduced (d2d_params.strict_nan is the exhaustive kernel).
-        bool prefix_dead = (K >= 2) && a.shadow && a.shadow_prefix_ok && (a.shadow[cand[0]] == ~0ull);
+        bool prefix_dead = (K >= 2) && a.shadow && a.shadow_prefix_ok && (cmem(a.shadow)[cand[0]] == ~0ull);
         if (K >= 3 && !GRAD && prefix_dead) {
             // the FIRST wall is dead: so are all (N-1)^(K-2) prefixes that start with it -- leave the inner positions at
             // their end so that the odometer below moves straight on to the next first wall
@@ -1256,14 +1376,14 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
             // two consecutive walls of the prefix whose windows are mutually invisible bin for bin: whatever follows,
             // the segment between them is occluded (or one of its ends is off its wall)
 #pragma unroll
-            for (int d = 0; d + 1 < K - 1; ++d) prefix_dead = prefix_dead || (a.pair[(size_t)cand[d] * a.N + cand[d + 1]] == ~0ull);
+            for (int d = 0; d + 1 < K - 1; ++d) prefix_dead = prefix_dead || (cmem(a.pair)[(size_t)cand[d] * a.N + cand[d + 1]] == ~0ull);
         }
         for (int chunk = 0; chunk < ((prefix_dead && !GRAD) ? 0 : n_chunks); ++chunk) {
             // ---- lanes = candidates: lane l <-> last wall = cw[chunk * 64 + l]
             const int lp = chunk * 64 + lane;
             bool alive = (lp < Nc) && (lp != last_prefix_pos);
             if (QUEUE) {
-                const int wl = a.cw[lp < Nc ? lp : 0];
+                const int wl = cmem(a.cw)[lp < Nc ? lp : 0];
                 const float4 r0 = tab[2 * wl], r1 = tab[2 * wl + 1], fc = tab[2 * a.N + wl];
                 const WallC wlast = make_wallc(r0, r1, fc, wl);
                 float lx, ly;
@@ -1292,7 +1412,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 continue;
             }
             {
-                const int wl = a.cw[lp < Nc ? lp : 0];
+                const int wl = cmem(a.cw)[lp < Nc ? lp : 0];
                 WallC w[K];
                 float Ix[K], Iy[K];
                 const float4 r0 = tab[2 * wl], r1 = tab[2 * wl + 1], fc = tab[2 * a.N + wl];
@@ -1301,12 +1421,12 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
 #pragma unroll
                 for (int d = 0; d < K - 1; ++d) {
                     const int wd = cand[d];
-                    w[d] = make_wallc(a.refl[2 * wd], a.refl[2 * wd + 1], a.flt[wd], wd);
+                    w[d] = make_wallc(ldc4(a.refl, 2 * wd), ldc4(a.refl, 2 * wd + 1), ldc4(a.flt, wd), wd);
                     Ix[d] = imgx[d];
                     Iy[d] = imgy[d];
                 }
                 unsigned long long sh0 = 0ull;
-                if (a.shadow) sh0 = a.shadow[(K == 1) ? wl : cand[0]];
+                if (a.shadow) sh0 = cmem(a.shadow)[(K == 1) ? wl : cand[0]];
                 if (GRAD && prefix_dead) alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
                 else if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive = false;
             }
@@ -1316,10 +1436,11 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
             const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
             // ---- lanes = RX cells: survivors in ascending order (= the reference's order)
             while (mask) {
+                if (K == 1 && spill && spill_rest(*spill, 1, (unsigned long long)cmem(a.cw)[lp < Nc ? lp : 0], mask, st.work)) break;
                 const int b = __builtin_ctzll(mask);
                 mask &= mask - 1;
-                cand[K - 1] = a.cw[chunk * 64 + b];
-                image_of(a.refl[2 * cand[K - 1]], pIx, pIy, imgx[K - 1], imgy[K - 1]);
+                cand[K - 1] = cmem(a.cw)[chunk * 64 + b];
+                image_of(ldc4(a.refl, 2 * cand[K - 1]), pIx, pIy, imgx[K - 1], imgy[K - 1]);
                 if (LIST) {
                     float t = 0.0f;
                     eval_candidate<K, MODE, STATS, GRAD, false, false>(a, cand, imgx, imgy, a.txx, a.txy, rxx, rxy, lane_bad, t, st, g);
@@ -1369,7 +1490,7 @@ __device__ __forceinline__ void first_wall_range(const SweepArgs& a, int part, i
     int A = 0;
     for (int c = 0; c < n_chunks; ++c) {
         const int pp = c * 64 + lane;
-        const bool alive = pp < Nc && !(use_dead && a.shadow[a.cw[pp]] == ~0ull);
+        const bool alive = pp < Nc && !(use_dead && cmem(a.shadow)[cmem(a.cw)[pp]] == ~0ull);
         A += __builtin_popcountll(__ballot(alive));
     }
     auto boundary = [&](int r) -> int {
@@ -1377,7 +1498,7 @@ __device__ __forceinline__ void first_wall_range(const SweepArgs& a, int part, i
         if (r >= A) return Nc;
         for (int c = 0; c < n_chunks; ++c) {
             const int pp = c * 64 + lane;
-            const bool alive = pp < Nc && !(use_dead && a.shadow[a.cw[pp]] == ~0ull);
+            const bool alive = pp < Nc && !(use_dead && cmem(a.shadow)[cmem(a.cw)[pp]] == ~0ull);
             unsigned long long m = __ballot(alive);
             const int n = __builtin_popcountll(m);
             if (r < n) {
@@ -1413,7 +1534,7 @@ __device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, con
     if (bypass) {
         alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
     } else if (alive) {
-        const unsigned long long sh0 = a.shadow ? a.shadow[w[0].idx] : 0ull;
+        const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[w[0].idx] : 0ull;
         if (cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive = false;
     }
     return __ballot(alive);
@@ -1425,14 +1546,16 @@ __device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, con
 template <int K, int MODE, bool STATS, bool GRAD, bool LIST>
 __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                    const float (&by)[4], float rxx, float rxy, bool lane_bad, float& acc,
-                                                   WaveStats& st, GradCtx* g, long region, int part, int parts, ListSink* sink) {
+                                                   WaveStats& st, GradCtx* g, long region, int part, int parts, ListSink* sink,
+                                                   SpillSink* spill = nullptr) {
     static_assert(K >= 2, "lists exist for orders >= 2");
     const int lane = threadIdx.x & 63;
     const RegionLists* rl = a.rl;
-    const int n = rl->leaf.cnt[K][region];  // >= 0: patches of a region with a list that is not listed go to the enumerating kernel
-    const int chunk0 = rl->leaf.chunk0[K] + (int)region;
-    const unsigned long long* pool = rl->lp.pool;
-    const int* next = rl->lp.next;
+    const auto* rlc = cmem(rl);
+    const int n = cmem(rlc->leaf.cnt[K])[region];  // >= 0: patches of a region with a list that is not listed go to the enumerating kernel
+    const int chunk0 = rlc->leaf.chunk0[K] + (int)region;
+    const auto* pool = cmem(rlc->lp.pool);
+    const auto* next = cmem(rlc->lp.next);
     int r_lo = 0, r_hi = 0x7fffffff;
     if (parts > 1) {
         int T = 0, chunk = chunk0;
@@ -1466,6 +1589,7 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
         }
         const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
         while (mask && budget > 0) {
+            if (spill && spill_rest(*spill, K, code, mask, st.work)) break;
             const int b = __builtin_ctzll(mask);
             mask &= mask - 1;
             --budget;
@@ -1498,9 +1622,9 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
 template <int K, int MODE, bool STATS, bool GRAD, bool LIST, bool LISTED>
 __device__ __forceinline__ void sweep_order_any(const SweepArgs& a, const float4* tab, const float (&bx)[4], const float (&by)[4],
                                                 float rxx, float rxy, bool lane_bad, float& acc, WaveStats& st, GradCtx* g,
-                                                long region, int part, int parts, ListSink* sink) {
+                                                long region, int part, int parts, ListSink* sink, SpillSink* spill = nullptr) {
     if constexpr (K >= 2 && LISTED) {
-        sweep_order_listed<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, region, part, parts, sink);
+        sweep_order_listed<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, region, part, parts, sink, spill);
     } else {
         int lo = 0, hi = 0x7fffffff;
         if (parts > 1) first_wall_range(a, part, parts, lo, hi);
@@ -1510,8 +1634,8 @@ __device__ __forceinline__ void sweep_order_any(const SweepArgs& a, const float4
 
 // The region (R x R patches) of patch (tcol, trow)
 __device__ __forceinline__ long region_of(const SweepArgs& a, int tcol, int trow) {
-    const int R = a.rl->leaf.R;
-    return (long)(trow / R) * a.rl->leaf.regions_x + (tcol / R);
+    const int R = cmem(a.rl)->leaf.R;
+    return (long)(trow / R) * cmem(a.rl)->leaf.regions_x + (tcol / R);
 }
 
 #ifndef D2D_HEAVY_PARTS
@@ -1576,11 +1700,19 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, const float4* tab,
                           !(fabsf(a.txy) < 1e18f);
     if (LISTED) {
         // not this kernel's patch: leave it (once) to the enumerating kernel
-        if (a.rl->flag[region] != 0 || wave_any(lane_bad)) {
+        if (cmem(cmem(a.rl)->flag)[region] != 0 || wave_any(lane_bad)) {
             if (part == 0 && lane == 0) a.fb_list[atomicAdd(a.fb_n, 1)] = (int)tile;
             return;
         }
     }
+    constexpr bool SPILL = LISTED && !GRADK;  // (the value+grad sweep keeps every patch in one wave)
+    SpillSink spl;
+    spl.sp = SPILL ? a.sp : nullptr;
+    spl.w0 = SPILL && a.sp ? (unsigned)cmem(a.sp)->w0 : 0xffffffffu;
+    spl.slot = -1;
+    spl.last_node = -1;
+    spl.tile = (int)tile;
+    spl.dead = false;
     float acc = 0.0f;  // scene.py:1893
     GradCtx g;
     g.grx = g.gry = g.tbx = g.tby = 0.0f;
@@ -1595,14 +1727,14 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, const float4* tab,
         bool poison_all = false;
         const bool deep = a.max_order >= 2 && a.Nc >= 2;  // candidates (w0, .., w) exist for every other allowed w0
         for (int i = 0; i < a.Nc; ++i) {
-            const float4 r0 = a.refl[2 * a.cw[i]];
+            const float4 r0 = ldc4(a.refl, 2 * cmem(a.cw)[i]);
             float vx = r0.x - rxx, vy = r0.y - rxy;
             const bool here = (vx * r0.z + vy * r0.w) == 0.0f;
             on_line = on_line || here;
             if (scene && wave_any(here)) {
                 poison_all = poison_all || deep;
                 if (lane == 0) {
-                    float* w4 = wl + 4 * a.cw[i];
+                    float* w4 = wl + 4 * cmem(a.cw)[i];
                     w4[0] = w4[1] = w4[2] = w4[3] = __builtin_nanf("");
                 }
             }
@@ -1613,7 +1745,7 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, const float4* tab,
             if (scene && on_line) g.tbx = g.tby = qnan;
             if (scene && poison_all && lane == 0)
                 for (int i = 0; i < a.Nc; ++i) {
-                    float* w4 = wl + 4 * a.cw[i];
+                    float* w4 = wl + 4 * cmem(a.cw)[i];
                     w4[0] = w4[1] = w4[2] = w4[3] = qnan;
                 }
         }
@@ -1675,17 +1807,29 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, const float4* tab,
         st.work = work;
         if (lane == 0) a.heavy_done[tile0] = 0;  // ready for the next launch
     } else {
-    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, GRADK>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 0 && a.max_order >= 0) {
+        sweep_order<0, MODE, STATS, GRADK>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, &g);
+    }
     unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[11] += tq1 - tq0;      // order 0
-    if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 1 && a.max_order >= 1)
+        sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, 0, 0x7fffffff, nullptr, nullptr, SPILL ? &spl : nullptr);
     unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[12] += tq2 - tq1;      // order 1
-    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_any<2, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
+    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_any<2, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr, SPILL ? &spl : nullptr);
     if (STATS) st.c[13] += __builtin_amdgcn_s_memtime() - tq2;  // order 2
-    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_any<3, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
-    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_any<4, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_any<3, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr, SPILL ? &spl : nullptr);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_any<4, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr, SPILL ? &spl : nullptr);
     }
+    if (SPILL && spl.dead) {
+        // the spill buffers ran out half way: the enumerating kernel redoes the patch
+        if (lane == 0) a.fb_list[atomicAdd(a.fb_n, 1)] = (int)tile;
+        return;
+    }
+    if (SPILL && spl.slot >= 0) {
+        // spill_merge_kernel finishes the sum and writes the cells
+        spl.sp->acc[(size_t)spl.slot * 64 + lane] = acc;
+    } else
     if (in_range) {
         if (a.out_mode == D2D_OUT_ADD) {
             a.out[idx] = a.out[idx] + acc;
@@ -1733,8 +1877,8 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
     const int lane = threadIdx.x & 63;
     // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index), staged once per wave
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
-    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
-    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = ldc4(a.refl, i);
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = ldc4(a.flt, i);
     float* wl = reinterpret_cast<float*>(tab + 3 * a.N);
     __syncthreads();
     if (!LISTED && a.fb_n != nullptr) {
@@ -1747,6 +1891,77 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
         return;
     }
     fwd_patch<MODE, STATS, MAXK, GRADK, LISTED>(a, tab, wl, (long)blockIdx.x, false);
+}
+
+// The spilled candidates (Spill): one unit (<= U consecutive candidates of one patch) per wave, workgroups stride over the
+// units.  Every candidate is evaluated exactly as the patch itself would have (same op chain); a contribution that is
+// not exactly zero in some lane becomes a record, to be added by spill_merge_kernel in candidate order.
+template <int MODE, bool STATS, int MAXK>
+__global__ void __launch_bounds__(64) spill_eval_kernel(SweepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const Spill spv = *a.sp;  // (by value: the stores below could alias the descriptor)
+    const Spill* sp = &spv;
+    const int n_units = __builtin_amdgcn_readfirstlane(min(sp->counters[2], sp->cap_units));
+    const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
+    WaveStats st;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st.c[i] = 0;
+    st.work = 0;
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int4 unit_v = ldc4i(sp->units, u);
+        // (wave-uniform values in scalar registers: everything indexed by them is then fetched with scalar loads)
+        const int4 unit = make_int4(__builtin_amdgcn_readfirstlane(unit_v.x), __builtin_amdgcn_readfirstlane(unit_v.y),
+                                    __builtin_amdgcn_readfirstlane(unit_v.z), __builtin_amdgcn_readfirstlane(unit_v.w));
+        const int tile = unit.x, start = unit.y, count = unit.z;
+        const int tcol = tile % tiles_x, trow = tile / tiles_x;
+        const int col = tcol * TILE_W + (lane & (TILE_W - 1));
+        const int row = trow * TILE_H + (lane / TILE_W);
+        const int ccol = col < a.n ? col : a.n - 1;
+        const int crow = row < a.m ? row : a.m - 1;
+        const long idx = (long)crow * a.n + ccol;
+        const float rxx = a.X[idx], rxy = a.Y[idx];  // comfortably finite: the patch checked before it spilled
+        st.shadow = -1;
+        for (int i = 0; i < count; ++i) {
+            const unsigned long long cu_v = cmem(sp->codes)[start + i];
+            const unsigned long long cu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cu_v >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(cu_v & 0xffffffffull));
+            const int K = (int)((cu >> 56) & 7ull);
+            int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+            float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
+#pragma unroll
+            for (int d = 0; d < MAXK; ++d) {
+                if (d < K) {
+                    ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
+                    image_of(ldc4(a.refl, 2 * ce[d]), d == 0 ? a.txx : ex[d > 0 ? d - 1 : 0], d == 0 ? a.txy : ey[d > 0 ? d - 1 : 0], ex[d], ey[d]);
+                }
+            }
+            float t = 0.0f;
+            if (K == 1) eval_candidate<1, MODE, STATS, false, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, false, t, st, nullptr);
+            else if (K == 2) eval_candidate<2, MODE, STATS, false, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, false, t, st, nullptr);
+            else if (MAXK >= 3 && K == 3) eval_candidate<(MAXK >= 3 ? 3 : 2), MODE, STATS, false, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, false, t, st, nullptr);
+            else if (MAXK >= 4 && K == 4) eval_candidate<(MAXK >= 4 ? 4 : 2), MODE, STATS, false, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, false, t, st, nullptr);
+            int rec = -1;
+            if (wave_any(!(t == 0.0f))) {  // non-zero or NaN somewhere
+                if (lane == 0) rec = atomicAdd(&sp->counters[4], 1);
+                rec = __builtin_amdgcn_readfirstlane(rec);
+                if (rec < sp->cap_recs) {
+                    sp->vals[(size_t)rec * 64 + lane] = t;
+                } else {
+                    // no room for the record: the patch is given up (once) and redone by the enumerating kernel
+                    if (lane == 0 && atomicExch(&sp->tiles[unit.w], -1) >= 0) {
+                        a.fb_list[atomicAdd(a.fb_n, 1)] = tile;
+                        atomicAdd(&sp->counters[5], 1);
+                    }
+                    rec = -1;
+                }
+            }
+            if (lane == 0) sp->rec_of[start + i] = rec;
+        }
+    }
+    if (STATS && lane == 0 && a.stats) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atomicAdd(&a.stats[i], st.c[i]);
+    }
 }
 
 // Forward sweep with every 8 x 8 patch shared by W waves (one workgroup).  Patches differ a lot in cost and the dearest
@@ -1818,7 +2033,7 @@ __device__ __forceinline__ void split_patch(const SweepArgs& a, const float4* ta
                           !(fabsf(a.txy) < 1e18f);
     if (LISTED) {
         // not this kernel's patch (every wave of the workgroup sees the same cells): leave it to the enumerating kernel
-        if (a.rl->flag[region] != 0 || wave_any(lane_bad)) {
+        if (cmem(cmem(a.rl)->flag)[region] != 0 || wave_any(lane_bad)) {
             if (threadIdx.x == 0) a.fb_list[atomicAdd(a.fb_n, 1)] = tile;
             return;
         }
@@ -1870,8 +2085,8 @@ __device__ __forceinline__ void split_patch(const SweepArgs& a, const float4* ta
 template <int MODE, bool STATS, int MAXK, int W, bool LISTED = false>
 __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then the contribution lists and their bookkeeping
-    for (int i = threadIdx.x; i < 2 * a.N; i += 64 * W) tab[i] = a.refl[i];
-    for (int i = threadIdx.x; i < a.N; i += 64 * W) tab[2 * a.N + i] = a.flt[i];
+    for (int i = threadIdx.x; i < 2 * a.N; i += 64 * W) tab[i] = ldc4(a.refl, i);
+    for (int i = threadIdx.x; i < a.N; i += 64 * W) tab[2 * a.N + i] = ldc4(a.flt, i);
     float* lists = reinterpret_cast<float*>(tab + 3 * a.N);
     int* meta = reinterpret_cast<int*>(lists + (size_t)(W - 1) * SPLIT_LIST * 64);
     __syncthreads();
@@ -1904,8 +2119,8 @@ template <int K, bool GRAD>
 __global__ void __launch_bounds__(64) region_list_kernel(SweepArgs a, RegionLevel lv, ListPool lp) {
     const int lane = threadIdx.x & 63;
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, the culling queue
-    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
-    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = ldc4(a.refl, i);
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = ldc4(a.flt, i);
     __syncthreads();
     const long rs = blockIdx.x;
     const long region = rs / lv.S;
@@ -1936,11 +2151,11 @@ __global__ void __launch_bounds__(64) region_list_kernel(SweepArgs a, RegionLeve
 // keeps what the tile culling cannot drop for its own, smaller box.  `flag`: raised when the list is not listed.
 constexpr int RL_GATHER = 512;  // entries of the gather buffer (LDS)
 template <int K, bool GRAD>
-__global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLevel lv, RegionLevel parent, ListPool lp, int* flag) {
+__global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLevel lv, RegionLevel parent, ListPool lp, int* flag, int* total_out) {
     const int lane = threadIdx.x & 63;
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then the gather buffer
-    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
-    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = ldc4(a.refl, i);
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = ldc4(a.flt, i);
     unsigned long long* buf = reinterpret_cast<unsigned long long*>(tab + 3 * a.N + 1);
     __syncthreads();
     const long region = blockIdx.x;
@@ -1986,6 +2201,7 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
     if (lane == 0) {
         lv.cnt[K][region] = em.over ? -1 : em.n;
         if (em.over) flag[region] = 1;
+        else if (total_out) atomicAdd(total_out, em.n);
     }
 }
 
@@ -2011,20 +2227,20 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
     while (true) {
 #pragma unroll
         for (int d = 0; d < K - 1; ++d) {
-            cand[d] = a.cw[pos[d]];
-            image_of(a.refl[2 * cand[d]], d == 0 ? cx : imgx[d > 0 ? d - 1 : 0], d == 0 ? cy : imgy[d > 0 ? d - 1 : 0], imgx[d], imgy[d]);
+            cand[d] = cmem(a.cw)[pos[d]];
+            image_of(ldc4(a.refl, 2 * cand[d]), d == 0 ? cx : imgx[d > 0 ? d - 1 : 0], d == 0 ? cy : imgy[d > 0 ? d - 1 : 0], imgx[d], imgy[d]);
         }
         const int last_prefix_pos = (K == 1) ? -1 : pos[K >= 2 ? K - 2 : 0];
         bool prefix_dead = false;
         if (K >= 3 && !GRAD && a.pair && a.pair_prefix_ok) {
 #pragma unroll
-            for (int d = 0; d + 1 < K - 1; ++d) prefix_dead = prefix_dead || (a.pair[(size_t)cand[d] * a.N + cand[d + 1]] == ~0ull);
+            for (int d = 0; d + 1 < K - 1; ++d) prefix_dead = prefix_dead || (cmem(a.pair)[(size_t)cand[d] * a.N + cand[d + 1]] == ~0ull);
         }
         for (int chunk = 0; chunk < (prefix_dead ? 0 : n_chunks); ++chunk) {
             const int lp = chunk * 64 + lane;
             bool alive = (lp < Nc) && (lp != last_prefix_pos);
             {
-                const int wl = a.cw[lp < Nc ? lp : 0];
+                const int wl = cmem(a.cw)[lp < Nc ? lp : 0];
                 WallC w[K];
                 float Ix[K], Iy[K];
                 const float4 r0 = tab[2 * wl], r1 = tab[2 * wl + 1], fc = tab[2 * a.N + wl];
@@ -2033,11 +2249,11 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
 #pragma unroll
                 for (int j = 1; j < K; ++j) {
                     const int wd = cand[K - 1 - j];
-                    const float4 q0 = a.refl[2 * wd];
-                    w[j] = make_wallc(q0, a.refl[2 * wd + 1], a.flt[wd], wd);
+                    const float4 q0 = ldc4(a.refl, 2 * wd);
+                    w[j] = make_wallc(q0, ldc4(a.refl, 2 * wd + 1), ldc4(a.flt, wd), wd);
                     image_of(q0, Ix[j - 1], Iy[j - 1], Ix[j], Iy[j]);
                 }
-                const unsigned long long sh0 = a.shadow ? a.shadow[wl] : 0ull;
+                const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[wl] : 0ull;
                 if (alive && cull_candidate<K, true>(bx, by, w, Ix, Iy, a, sh0)) alive = false;
             }
             unsigned long long mask = __ballot(alive);
@@ -2045,8 +2261,8 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
             while (mask) {
                 const int b = __builtin_ctzll(mask);
                 mask &= mask - 1;
-                cand[K - 1] = a.cw[chunk * 64 + b];
-                image_of(a.refl[2 * cand[K - 1]], K == 1 ? cx : imgx[K >= 2 ? K - 2 : 0], K == 1 ? cy : imgy[K >= 2 ? K - 2 : 0], imgx[K - 1], imgy[K - 1]);
+                cand[K - 1] = cmem(a.cw)[chunk * 64 + b];
+                image_of(ldc4(a.refl, 2 * cand[K - 1]), K == 1 ? cx : imgx[K >= 2 ? K - 2 : 0], K == 1 ? cy : imgy[K >= 2 ? K - 2 : 0], imgx[K - 1], imgy[K - 1]);
                 eval_candidate<K, MODE, false, GRAD, false, true>(a, cand, imgx, imgy, cx, cy, a.txx, a.txy, lane_bad, acc, st, g);
             }
         }
@@ -2080,8 +2296,8 @@ __global__ void __launch_bounds__(64) power_fwd_txg_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
-    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = a.refl[i];
-    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = a.flt[i];
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = ldc4(a.refl, i);
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = ldc4(a.flt, i);
     float* wl = reinterpret_cast<float*>(tab + 3 * a.N);
     const bool scene = GRADK && a.partial != nullptr;
     if (scene)
@@ -2192,13 +2408,13 @@ __global__ void __launch_bounds__(256) patch_cost_kernel(SweepArgs a, unsigned c
     int alive_n = 0;
     for (int c0 = 0; c0 < a.Nc; c0 += 64) {
         const int lp = c0 + lane;
-        const int wl = a.cw[lp < a.Nc ? lp : 0];
+        const int wl = cmem(a.cw)[lp < a.Nc ? lp : 0];
         WallC w[1];
         float Ix[1], Iy[1];
-        const float4 r0 = a.refl[2 * wl], r1 = a.refl[2 * wl + 1], fc = a.flt[wl];
+        const float4 r0 = ldc4(a.refl, 2 * wl), r1 = ldc4(a.refl, 2 * wl + 1), fc = ldc4(a.flt, wl);
         w[0] = make_wallc(r0, r1, fc, wl);
         image_of(r0, a.txx, a.txy, Ix[0], Iy[0]);
-        const unsigned long long sh0 = a.shadow ? a.shadow[wl] : 0ull;
+        const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[wl] : 0ull;
         const bool alive = lp < a.Nc && !cull_candidate<1>(bx, by, w, Ix, Iy, a, sh0);
         alive_n += __builtin_popcountll(__ballot(alive));
     }
@@ -2306,6 +2522,39 @@ __global__ void __launch_bounds__(256) region_box_kernel(const float* __restrict
         }
         const bool anybad = sbad[0] | sbad[1] | sbad[2] | sbad[3];
         box[region] = make_float4(anybad ? __builtin_nanf("") : x0, x1, y0, y1);
+    }
+}
+
+// Finishes the spilled patches: adds the recorded contributions of a patch's spilled candidates, in candidate order, to
+// the sum the patch had reached, and writes the cells (scene.py:1909, 1934-1953).  One wave per spilled patch (strided).
+__global__ void __launch_bounds__(64) spill_merge_kernel(SweepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const Spill* sp = a.sp;
+    const int n = sp->counters[3];
+    const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
+    for (int slot = blockIdx.x; slot < n; slot += gridDim.x) {
+        const int tile = sp->tiles[slot];
+        if (tile < 0) continue;  // given up: the enumerating kernel redoes it
+        float acc = sp->acc[(size_t)slot * 64 + lane];
+        for (int node = sp->tile_first[slot]; node >= 0; node = sp->node_next[node]) {
+            const int4 nd = sp->nodes[node];
+            const int r = lane < nd.y ? sp->rec_of[nd.x + lane] : -1;
+            unsigned long long m = __ballot(r >= 0);
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int rr = __builtin_amdgcn_readlane(r, b);
+                acc = acc + sp->vals[(size_t)rr * 64 + lane];
+            }
+        }
+        const int tcol = tile % tiles_x, trow = tile / tiles_x;
+        const int col = tcol * TILE_W + (lane & (TILE_W - 1));
+        const int row = trow * TILE_H + (lane / TILE_W);
+        if (col < a.n && row < a.m) {
+            const long idx = (long)row * a.n + col;
+            if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
+            else a.out[idx] = acc;
+        }
     }
 }
 

@@ -221,8 +221,9 @@ int d2d_debug_set_schedule(d2d_ctx* ctx, const int32_t* order, int64_t n);
 int d2d_debug_get_schedule(d2d_ctx* ctx, int32_t* order, uint8_t* key, int64_t n);
 /* Region candidate lists of the last launch that built any (all zeros otherwise): out[0] pool chunks handed out,
  * [1] pool chunks available, [2] patches left to the enumerating kernel, [3] leaf regions with a list that is not listed,
- * [4] / [5] / [6] entries of the leaf lists of order 2 / 3 / 4, [7] leaf regions.  Waits for the stream. */
-int d2d_debug_region_stats(d2d_ctx* ctx, int64_t* out /* [8] */);
+ * [4] / [5] / [6] entries of the leaf lists of order 2 / 3 / 4, [7] leaf regions; spilled candidates: [8] entries,
+ * [9] nodes, [10] units, [11] patches that spilled, [12] records, [13] patches given up.  Waits for the stream. */
+int d2d_debug_region_stats(d2d_ctx* ctx, int64_t* out /* [14] */);
 
 /* The work history behind the schedule: what each of the n patches took in the last culled sweep (units of ~25
  * wave-instructions, counted by the kernels). */
