@@ -862,6 +862,23 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     }
     for (int k = 0; k <= D2D_MAX_ORDER; ++k) a.fnum[k] = integer_pow(p->r_coef, k);
     a.h2 = p->height * p->height;
+    // sigmoid validity: an upper bound of |fun| lets the kernels skip contributions that cannot change the running sum
+    a.sig_l2f = 1e30f;
+    a.sig_mono = 1;
+    for (int k = p->min_order; k <= p->max_order; ++k) a.sig_mono = a.sig_mono && (a.fnum[k] >= 0.0f || p->fun_id != D2D_FUN_RECEIVED_POWER);
+    if (p->fun_id == D2D_FUN_ONE) {
+        a.sig_l2f = 0.0f;
+    } else if (p->fun_id == D2D_FUN_RECEIVED_POWER && a.h2 > 0.0f && std::isfinite(a.h2)) {
+        float fm = 0.0f;  // received_power = r_coef^k / (h^2 + r^2) <= |r_coef|^k / h^2
+        bool ok = true;
+        for (int k = p->min_order; k <= p->max_order; ++k) {
+            const float f = std::fabs(a.fnum[k]) / a.h2;
+            ok = ok && std::isfinite(f);
+            fm = std::fmax(fm, f);
+        }
+        if (ok && fm > 0.0f) a.sig_l2f = std::log2(fm) + 1e-3f;
+        else if (ok) a.sig_l2f = -1e30f;  // fun == 0 throughout
+    }
     a.fun_id = p->fun_id;
     a.out_mode = p->out_mode;
     a.patch = p->patch;

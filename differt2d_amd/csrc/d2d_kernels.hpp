@@ -138,6 +138,8 @@ struct SweepArgs {
     float flt_lo, flt_hi;      // conservative "certainly outside the window" thresholds for the divide-free filter
     float on_lo, on_hi;        // parametric coordinate certainly outside the wall: s < on_lo or s > on_hi => on_objects == 0
     float loss_skip;           // a loss certainly below this cannot change less(loss, tol) (see eval_candidate); < 0: never
+    float sig_l2f;             // MODE_SIG: log2 of an upper bound of |fun| over the launch's orders, 1e30: none (sig_zc_of)
+    int sig_mono;              // MODE_SIG: fun >= 0 throughout, so a cell's running sum never shrinks
     // first-segment shadow culling (shadow_tx_kernel): bit b of shadow[w] = every point of wall w with parametric
     // coordinate in [b/64, (b+1)/64] (and within shadow_dperp of the wall's line) is certainly hidden from the fixed
     // end point by some other object
@@ -269,6 +271,15 @@ __device__ __forceinline__ float clampact(float x, float alpha) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+// Sigmoid validity (MODE_SIG): the pre-activation z below which a candidate's contribution valid * fun <= exp(z) * f_max
+// is certainly less than a quarter ulp of `acc` -- adding it would leave acc unchanged under round to nearest, whatever
+// its sign.  l2f = log2 of an upper bound of |fun| (SweepArgs::sig_l2f; huge: no bound, nothing may be skipped); 0.01 in
+// log2 units covers the rounding of expf, of the products and of this estimate itself.  acc == 0 or denormal: < -89.
+__device__ __forceinline__ float sig_zc_of(float l2f, float acc) {
+    const int E = (int)((__float_as_uint(acc) >> 23) & 0xffu) - 127;
+    return ((float)(E - 25) - l2f - 0.01f) * 0.69314718f;
+}
 
 // Per-lane gradient state of the value+grad kernel (GRAD build of eval_candidate).
 struct GradCtx {
@@ -445,7 +456,10 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         }
     }
     // sigmoid(z) is exactly 0 only once exp(-z) overflows: z <= -89
-    bool on_zero = (MODE == MODE_HARD) ? !on_b : (MODE == MODE_HSIG) ? (on_c == 0.0f) : (on_z <= -89.0f);
+    // ... or, for this lane's running sum, once the contribution is certainly below a quarter ulp of it (sig_zc_of; not in
+    // the value+grad build: the adjoints are not absorbed by the sum)
+    bool on_zero = (MODE == MODE_HARD) ? !on_b : (MODE == MODE_HSIG) ? (on_c == 0.0f)
+                   : (on_z <= (GRAD ? -89.0f : fmaxf(-89.0f, sig_zc_of(a.sig_l2f, acc))));
     if (K > 0 && !wave_any(!on_zero || bad)) return;  // valid == 0 in every lane: acc + 0.0
 
     // Lanes for which the occlusion result can still change the output.  (is_valid = all(on_objects,
@@ -999,9 +1013,9 @@ __device__ __forceinline__ bool pole_possible(const float (&qx)[4], const float 
 template <int K, bool WIDE = false>
 __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float (&by)[4], const WallC (&w)[K],
                                                const float (&Ix)[K], const float (&Iy)[K], const SweepArgs& a,
-                                               unsigned long long shadow0) {
+                                               unsigned long long shadow0, float on_lo, float on_hi) {
     const float eps = 1.1920929e-07f;
-    const float on_lo = a.on_lo, on_hi = a.on_hi, shadow_dperp = a.shadow_dperp, shadow_lo = a.shadow_lo, shadow_inv = a.shadow_inv;
+    const float shadow_dperp = a.shadow_dperp, shadow_lo = a.shadow_lo, shadow_inv = a.shadow_inv;
     float qx[4], qy[4];
     // 8-bin range that the previous (later-in-path) wall's interaction point can occupy, for the wall-to-wall masks
     int pka = 0, pkb = -1;
@@ -1275,7 +1289,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
             }
             const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[w[0].idx] : 0ull;
             const bool bypass = GRAD && ((code >> 60) & 1ull);
-            if (alive2 && !bypass && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive2 = false;
+            if (alive2 && !bypass && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi)) alive2 = false;
         }
         unsigned long long mask = __ballot(alive2);
         if (STATS) st.c[9] += K;
@@ -1428,7 +1442,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 unsigned long long sh0 = 0ull;
                 if (a.shadow) sh0 = cmem(a.shadow)[(K == 1) ? wl : cand[0]];
                 if (GRAD && prefix_dead) alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
-                else if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive = false;
+                else if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi)) alive = false;
             }
             unsigned long long mask = __ballot(alive);
             if (STATS) st.c[9] += K;
@@ -1517,7 +1531,8 @@ __device__ __forceinline__ void first_wall_range(const SweepArgs& a, int part, i
 // tile-culling test against the box (bx, by).  Returns the ballot of the entries that cannot be dropped.
 template <int K, bool GRAD>
 __device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, const float4* tab, const float (&bx)[4], const float (&by)[4],
-                                                         unsigned long long code, bool have, float (&Ix)[K], float (&Iy)[K]) {
+                                                         unsigned long long code, bool have, float (&Ix)[K], float (&Iy)[K], float on_lo,
+                                                         float on_hi) {
     bool alive = have;
     WallC w[K];
     float ix = a.txx, iy = a.txy;
@@ -1535,7 +1550,7 @@ __device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, con
         alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
     } else if (alive) {
         const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[w[0].idx] : 0ull;
-        if (cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0)) alive = false;
+        if (cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, on_lo, on_hi)) alive = false;
     }
     return __ballot(alive);
 }
@@ -1564,7 +1579,7 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
             const unsigned long long code = pool[(size_t)chunk * RL_CHUNK + (off & (RL_CHUNK - 1)) + (have ? lane : 0)];
             if ((off & (RL_CHUNK - 1)) == RL_CHUNK - 64 && off + 64 < n) chunk = next[chunk];
             float Ix[K], Iy[K];
-            T += __builtin_popcountll(cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy));
+            T += __builtin_popcountll(cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi));
             D2D_WORK(5 * K);
         }
         r_lo = (int)(((long)T * part) / parts);
@@ -1576,7 +1591,23 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
         const unsigned long long code = pool[(size_t)chunk * RL_CHUNK + (off & (RL_CHUNK - 1)) + (have ? lane : 0)];
         if ((off & (RL_CHUNK - 1)) == RL_CHUNK - 64 && off + 64 < n) chunk = next[chunk];
         float Ix[K], Iy[K];
-        unsigned long long mask = cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy);
+        float on_lo = a.on_lo, on_hi = a.on_hi;
+        if (MODE == MODE_SIG && !LIST && !GRAD && parts == 1 && a.sig_mono) {
+            // Sigmoid validity is never exactly zero near a wall, but every contribution is >= 0 and the sum only grows: a
+            // candidate whose contribution is certainly below a quarter ulp of the sum it would be added to leaves that
+            // sum unchanged (round to nearest), in every lane -- skipping it is exact.  valid <= sigmoid(alpha (s - 0))
+            // <= exp(alpha s) for s < 0 (and the same beyond 1), fun <= f_max: the window in which on_objects matters
+            // shrinks from 89 / alpha to |zc| / alpha, zc from the smallest sum in the wave (sig_zc).
+            float zc = sig_zc_of(a.sig_l2f, acc);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) zc = fminf(zc, __shfl_xor(zc, off, 64));
+            if (zc > -89.0f) {
+                const float wdn = zc / a.alpha * 1.00001f - 1e-30f;  // (negative) s < wdn or s > 1 - wdn: negligible
+                on_lo = fmaxf(on_lo, wdn);
+                on_hi = fminf(on_hi, 1.0f - wdn);
+            }
+        }
+        unsigned long long mask = cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy, on_lo, on_hi);
         if (STATS) st.c[9] += K;
         D2D_WORK(5 * K);
         int budget = 64;
@@ -2179,7 +2210,7 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
                 const bool have = off + lane < total;
                 const unsigned long long code = buf[have ? off + lane : off];
                 float Ix[K], Iy[K];
-                const unsigned long long mask = cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy);
+                const unsigned long long mask = cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi);
                 emit_batch(em, code, have && ((mask >> lane) & 1ull), mask);
             }
             total = 0;
@@ -2254,7 +2285,7 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
                     image_of(q0, Ix[j - 1], Iy[j - 1], Ix[j], Iy[j]);
                 }
                 const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[wl] : 0ull;
-                if (alive && cull_candidate<K, true>(bx, by, w, Ix, Iy, a, sh0)) alive = false;
+                if (alive && cull_candidate<K, true>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi)) alive = false;
             }
             unsigned long long mask = __ballot(alive);
             D2D_WORK(5 * K);
@@ -2415,7 +2446,7 @@ __global__ void __launch_bounds__(256) patch_cost_kernel(SweepArgs a, unsigned c
         w[0] = make_wallc(r0, r1, fc, wl);
         image_of(r0, a.txx, a.txy, Ix[0], Iy[0]);
         const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[wl] : 0ull;
-        const bool alive = lp < a.Nc && !cull_candidate<1>(bx, by, w, Ix, Iy, a, sh0);
+        const bool alive = lp < a.Nc && !cull_candidate<1>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi);
         alive_n += __builtin_popcountll(__ballot(alive));
     }
     if (lane == 0) key[tile] = (unsigned char)(((long)alive_n * (SCHED_KEYS - 1)) / (a.Nc > 0 ? a.Nc : 1));
