@@ -171,6 +171,7 @@ struct d2d_ctx {
     DevBuf<int> d_sched_override;       // diagnostic: a caller-supplied schedule (d2d_debug_set_schedule)
     long long sched_override_n = 0;
     bool use_cost_history = true;
+    long long sched_key_mode = 0;       // schedule keys: 0 work history if there is one, else list lengths, else the proxy; 1 never the history; 2 never the lists
     bool txg_exhaustive = false;        // TX-grid value sweeps with the exhaustive kernel (A/B and tests)
     long long sched_min_tiles = 2048;   // launches with fewer patches keep the identity schedule
     float grid_absmax = 0.0f;   // max |coordinate| of the grid (host scan at d2d_set_grid)
@@ -206,6 +207,7 @@ struct d2d_ctx {
     long long spill_work = 0;          // work (units of ~25 wave-instructions) after which a patch spills what is left (0: never)
     long long spill_unit = 8;          // candidates per unit
     long long spill_grid = 4096;       // workgroups of spill_eval_kernel
+    long long spill_waves = 1;         // waves per workgroup of spill_eval_kernel (1..4)
     long long spill_cap = 16ll << 20;  // entries the spill buffers hold
     long long spill_recs = 1ll << 20;  // records (non-zero contributions of spilled candidates, 256 bytes each)
     DevBuf<unsigned long long> d_sp_codes;
@@ -1083,14 +1085,17 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         int* hist = reinterpret_cast<int*>(c->d_shadow.p + c->N);  // [SCHED_KEYS] counts, [SCHED_KEYS] cursors
         // cost key: what the patch cost last time, when this context has swept the same grid before (optimisation
         // loops, repeated maps); otherwise a proxy computed from the geometry
-        const bool from_history = c->cost_tiles == tiles && c->use_cost_history;
-        sched_from_history = from_history;
-        if (!from_history)
+        const bool from_history = c->cost_tiles == tiles && c->use_cost_history && c->sched_key_mode != 1;
+        // no (usable) history: the lengths of the region lists this launch has just built, if any, else the geometric proxy
+        const bool from_lists = !from_history && a.rl != nullptr && c->sched_key_mode != 2;
+        sched_from_history = from_history || from_lists;
+        if (!from_history && !from_lists)
             hipLaunchKernelGGL(d2d::patch_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, a, c->d_sched_key.p);
         {
             const unsigned sort_blocks = (unsigned)((tiles + 256 * d2d::SCHED_PER_THREAD - 1) / (256 * d2d::SCHED_PER_THREAD));
             hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p,
-                               from_history ? c->d_cost.p : (const unsigned*)nullptr, hist, (long)tiles);
+                               from_history ? c->d_cost.p : (const unsigned*)nullptr, hist, (long)tiles,
+                               from_lists ? a.rl : (const d2d::RegionLists*)nullptr, tiles_x, c->rl_plan.k_lo, p->max_order);
             hipLaunchKernelGGL(d2d::patch_order_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p, hist,
                                hist + d2d::SCHED_KEYS, c->d_sched.p, (long)tiles);
         }
@@ -1212,7 +1217,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     if (split) HIP_TRY(d2d::launch_fwd_split(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, grid_patches, split_lds, c->stream, a));
     else HIP_TRY(d2d::launch_fwd(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, grid_fwd, tab_lds, c->stream, a));
     if (a.sp) {
-        HIP_TRY(d2d::launch_spill_eval(mode, d_stats != nullptr, p->max_order, dim3((unsigned)c->spill_grid), c->stream, a));
+        HIP_TRY(d2d::launch_spill_eval(mode, d_stats != nullptr, p->max_order, dim3((unsigned)c->spill_grid, (unsigned)c->spill_waves), c->stream, a));
         hipLaunchKernelGGL(d2d::spill_merge_kernel, dim3(1024), dim3(64), 0, c->stream, a);
         HIP_TRY(hipGetLastError());
     }
@@ -1316,6 +1321,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "heavy_split")) c->heavy_split = value;
     else if (!strcmp(name, "time_kernel")) c->time_kernel = value != 0;
     else if (!strcmp(name, "cost_history")) c->use_cost_history = value != 0;
+    else if (!strcmp(name, "sched_key_mode")) c->sched_key_mode = value;
     else if (!strcmp(name, "pair_masks")) c->use_pair_masks = value != 0;
     else if (!strcmp(name, "opt_parallel")) c->opt_parallel = value != 0;
     else if (!strcmp(name, "txg_exhaustive")) c->txg_exhaustive = value != 0;
@@ -1330,6 +1336,9 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     } else if (!strcmp(name, "spill_grid")) {
         if (value < 1 || value > (1 << 20)) return fail(D2D_ERR_INVALID, "spill_grid must lie in 1..2^20, got %lld", (long long)value);
         c->spill_grid = value;
+    } else if (!strcmp(name, "spill_waves")) {
+        if (value < 1 || value > 4) return fail(D2D_ERR_INVALID, "spill_waves must lie in 1..4, got %lld", (long long)value);
+        c->spill_waves = value;
     } else if (!strcmp(name, "spill_cap")) {
         if (value < 1024 || value > (1ll << 30)) return fail(D2D_ERR_INVALID, "spill_cap must lie in 2^10..2^30, got %lld", (long long)value);
         c->spill_cap = value;

@@ -1928,7 +1928,7 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
 // units.  Every candidate is evaluated exactly as the patch itself would have (same op chain); a contribution that is
 // not exactly zero in some lane becomes a record, to be added by spill_merge_kernel in candidate order.
 template <int MODE, bool STATS, int MAXK>
-__global__ void __launch_bounds__(64) spill_eval_kernel(SweepArgs a) {
+__global__ void __launch_bounds__(256) spill_eval_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     const Spill spv = *a.sp;  // (by value: the stores below could alias the descriptor)
     const Spill* sp = &spv;
@@ -1938,7 +1938,8 @@ __global__ void __launch_bounds__(64) spill_eval_kernel(SweepArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.c[i] = 0;
     st.work = 0;
-    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;  // one unit per wave
+    for (int u = blockIdx.x * nw + wv; u < n_units; u += gridDim.x * nw) {
         const int4 unit_v = ldc4i(sp->units, u);
         // (wave-uniform values in scalar registers: everything indexed by them is then fetched with scalar loads)
         const int4 unit = make_int4(__builtin_amdgcn_readfirstlane(unit_v.x), __builtin_amdgcn_readfirstlane(unit_v.y),
@@ -2459,9 +2460,11 @@ __device__ __forceinline__ unsigned char key_from_cost(unsigned cost) {
     return (unsigned char)(k < 0 ? 0 : (k > SCHED_KEYS - 1 ? SCHED_KEYS - 1 : k));
 }
 
-// pass 1: hist[k] = number of patches with key k; with `cost` (work history) the keys are derived here first
+// pass 1: hist[k] = number of patches with key k; with `cost` (work history) or `lists` (the lengths of the region
+// candidate lists the launch has just built: a patch costs about what its region's lists hold) the keys are derived here
 __global__ void __launch_bounds__(256) patch_hist_kernel(unsigned char* __restrict__ key, const unsigned* __restrict__ cost,
-                                                         int* __restrict__ hist, long n_tiles) {
+                                                         int* __restrict__ hist, long n_tiles, const RegionLists* __restrict__ lists,
+                                                         int tiles_x, int k_lo, int k_hi) {
     __shared__ int cnt[SCHED_KEYS];
     if (threadIdx.x < SCHED_KEYS) cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -2470,7 +2473,17 @@ __global__ void __launch_bounds__(256) patch_hist_kernel(unsigned char* __restri
         const long t = base + (long)i * 256 + threadIdx.x;
         if (t < n_tiles) {
             unsigned char k;
-            if (cost) {
+            if (lists) {
+                const int R = lists->leaf.R;
+                const long region = (long)((int)(t / tiles_x) / R) * lists->leaf.regions_x + ((int)(t % tiles_x) / R);
+                unsigned len = 4;
+                for (int o = k_lo; o <= k_hi; ++o) {
+                    const int c = lists->leaf.cnt[o][region];
+                    len += c > 0 ? (unsigned)c : 0u;
+                }
+                k = key_from_cost(len << 4);
+                key[t] = k;
+            } else if (cost) {
                 k = key_from_cost(cost[t]);
                 key[t] = k;
             } else {

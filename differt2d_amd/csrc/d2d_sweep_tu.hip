@@ -99,7 +99,8 @@ hipError_t launch_fwd_listed_m<TU_MODE>(bool stats, int max_order, dim3 grid, si
 template <int MODE> hipError_t launch_spill_eval_m(bool stats, int max_order, dim3 grid, hipStream_t s, const SweepArgs& a);
 template <>
 hipError_t launch_spill_eval_m<TU_MODE>(bool stats, int max_order, dim3 grid, hipStream_t s, const SweepArgs& a) {
-    const dim3 block(64);
+    const dim3 block(grid.y > 1 ? 64 * grid.y : 64);  // (grid.y carries the waves per workgroup)
+    grid.y = 1;
     if (stats) {
         if (max_order <= 2) hipLaunchKernelGGL((spill_eval_kernel<TU_MODE, true, 2>), grid, block, 0, s, a);
         else if (max_order == 3) hipLaunchKernelGGL((spill_eval_kernel<TU_MODE, true, 3>), grid, block, 0, s, a);
