@@ -31,7 +31,6 @@ template <int MODE> hipError_t launch_vg_m(bool txg, bool grad, dim3 grid, size_
 template <int MODE> hipError_t launch_fwd_listed_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <int MODE> hipError_t launch_fwd_grad_listed_m(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <int MODE> hipError_t launch_fwd_split_listed_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
-template <int MODE> hipError_t launch_spill_eval_m(bool stats, int max_order, dim3 grid, hipStream_t s, const SweepArgs& a);
 
 #define D2D_DECLARE_MODE(M)                                                                                   \
     template <> hipError_t launch_fwd_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);           \
@@ -41,8 +40,7 @@ template <int MODE> hipError_t launch_spill_eval_m(bool stats, int max_order, di
     template <> hipError_t launch_vg_m<M>(bool, bool, dim3, size_t, hipStream_t, const SweepArgs&);              \
     template <> hipError_t launch_fwd_listed_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);       \
     template <> hipError_t launch_fwd_grad_listed_m<M>(int, dim3, size_t, hipStream_t, const SweepArgs&);        \
-    template <> hipError_t launch_fwd_split_listed_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);  \
-    template <> hipError_t launch_spill_eval_m<M>(bool, int, dim3, hipStream_t, const SweepArgs&);
+    template <> hipError_t launch_fwd_split_listed_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);
 D2D_DECLARE_MODE(MODE_HARD)
 D2D_DECLARE_MODE(MODE_HSIG)
 D2D_DECLARE_MODE(MODE_SIG)
@@ -66,9 +64,6 @@ hipError_t launch_fwd_grad(int mode, bool listed, int max_order, dim3 grid, size
 hipError_t launch_fwd_split(int mode, bool listed, bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
     if (listed) { D2D_BY_MODE(launch_fwd_split_listed_m, stats, max_order, grid, lds, s, a) }
     D2D_BY_MODE(launch_fwd_split_m, stats, max_order, grid, lds, s, a)
-}
-hipError_t launch_spill_eval(int mode, bool stats, int max_order, dim3 grid, hipStream_t s, const SweepArgs& a) {
-    D2D_BY_MODE(launch_spill_eval_m, stats, max_order, grid, s, a)
 }
 hipError_t launch_txg(int mode, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
     D2D_BY_MODE(launch_txg_m, grad, max_order, grid, lds, s, a)
@@ -202,21 +197,6 @@ struct d2d_ctx {
     DevBuf<int> d_rl_next;             // [max_chunks]
     DevBuf<int> d_rl_idx;              // first / cnt arrays of both levels, all orders
     DevBuf<int> d_rl_meta;             // [0] patches queued for the enumerating kernel, [1] pool head, [2 ..) leaf region flags, then the queue
-    // spilled candidates of the dear patches (spill_eval_kernel / spill_merge_kernel): LISTED forward launches
-    bool use_spill = true;
-    long long spill_work = 0;          // work (units of ~25 wave-instructions) after which a patch spills what is left (0: never)
-    long long spill_unit = 8;          // candidates per unit
-    long long spill_grid = 4096;       // workgroups of spill_eval_kernel
-    long long spill_waves = 1;         // waves per workgroup of spill_eval_kernel (1..4)
-    long long spill_cap = 16ll << 20;  // entries the spill buffers hold
-    long long spill_recs = 1ll << 20;  // records (non-zero contributions of spilled candidates, 256 bytes each)
-    DevBuf<unsigned long long> d_sp_codes;
-    DevBuf<int> d_sp_int;              // rec_of, node_next, tiles, tile_first
-    DevBuf<int4> d_sp_int4;            // nodes, units
-    DevBuf<float> d_sp_f;              // acc, vals
-    DevBuf<d2d::Spill> d_sp;
-    d2d::Spill sp_host;
-    bool sp_host_valid = false;
     DevBuf<d2d::RegionLists> d_rl;     // the descriptor the sweep kernels read
     d2d::RegionLists rl_host;          // what d_rl holds
     d2d_host::RegionPlan rl_plan;      // of the last launch that built lists (rl_plan.on) -- d2d_debug_region_stats
@@ -543,7 +523,6 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_stats.release();
     c->d_shadow.release();
     c->d_sched.release();
-    c->d_sp_codes.release(); c->d_sp_int.release(); c->d_sp_int4.release(); c->d_sp_f.release(); c->d_sp.release();
     c->d_rl_pool.release(); c->d_rl_box.release(); c->d_rl_next.release(); c->d_rl_idx.release(); c->d_rl_meta.release(); c->d_rl.release();
     c->d_sched_key.release();
     c->d_sched_override.release();
@@ -956,7 +935,6 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     }
     // region candidate lists (orders >= 2): the culled RX-grid kernels (forward, instrumented, value+grad) read them
     a.rl = nullptr;
-    a.sp = nullptr;
     a.fb_n = nullptr;
     a.fb_list = nullptr;
     if (!txg && c->use_region_lists && p->max_order >= 2 && c->cw.size() >= 2 && c->N <= 4095 && !(grad_mode && p->strict_nan)) {
@@ -971,10 +949,10 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             if ((rc = c->d_rl_pool.ensure((size_t)rp.max_chunks * d2d::RL_CHUNK))) return rc;
             if ((rc = c->d_rl_next.ensure((size_t)rp.max_chunks))) return rc;
             if ((rc = c->d_rl_idx.ensure(per_order * (size_t)orders))) return rc;
-            // meta: [0] queue length, [1] pool head, [2 .. 10) spill counters, [10 ..) leaf region flags (all zeroed per launch), then the queue
-            if ((rc = c->d_rl_meta.ensure(10 + (size_t)rp.leaf.regions + (size_t)tiles))) return rc;
+            // meta: [0] queue length, [1] pool head, [2 ..) leaf region flags (all zeroed per launch), then the queue
+            if ((rc = c->d_rl_meta.ensure(2 + (size_t)rp.leaf.regions + (size_t)tiles))) return rc;
             if ((rc = c->d_rl.ensure(1))) return rc;
-            HIP_TRY(hipMemsetAsync(c->d_rl_meta.p, 0, (10 + (size_t)rp.leaf.regions) * sizeof(int), c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_rl_meta.p, 0, (2 + (size_t)rp.leaf.regions) * sizeof(int), c->stream));
             {
                 // the regions' bounding boxes depend on the grid only
                 const long long key[4] = {c->grid_version, rp.leaf.R, rp.top.R, (long long)c->m * 0x100000000ll + c->n};
@@ -1016,9 +994,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             rl.lp.head = c->d_rl_meta.p + 1;
             rl.lp.n_static = (int)rp.n_static;
             rl.lp.max_chunks = (int)rp.max_chunks;
-            rl.flag = c->d_rl_meta.p + 10;
+            rl.flag = c->d_rl_meta.p + 2;
             a.fb_n = c->d_rl_meta.p;
-            a.fb_list = c->d_rl_meta.p + 10 + rp.leaf.regions;
+            a.fb_list = c->d_rl_meta.p + 2 + rp.leaf.regions;
             if (!c->rl_host_valid || std::memcmp(&rl, &c->rl_host, sizeof rl) != 0) {
                 c->rl_host = rl;  // (the copy reads rl_host: it stays valid after this call returns)
                 c->rl_host_valid = true;
@@ -1029,41 +1007,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             al.cullq_off = (int)((size_t)(3 * c->N + 1) * sizeof(float4));
             for (int k = rp.k_lo; k <= p->max_order; ++k) {
                 HIP_TRY(d2d::launch_region_lists(k, grad_mode != 0, dim3((unsigned)rp.top.slots), lds_l, c->stream, al, top, rl.lp));
-                HIP_TRY(d2d::launch_region_refine(k, grad_mode != 0, dim3((unsigned)rp.leaf.regions), lds_r, c->stream, al, rl.leaf, top, rl.lp, rl.flag,
-                                                  c->d_rl_meta.p + 2 + 6));
-            }
-            // dear patches spill what they cannot afford to evaluate themselves (forward launches)
-            if (c->use_spill && c->spill_work > 0 && !grad_mode) {
-                const size_t E = (size_t)c->spill_cap, Nn = E / 4 + (size_t)tiles, Un = E / 2 + (size_t)tiles, Rn = (size_t)c->spill_recs;
-                if ((rc = c->d_sp_codes.ensure(E))) return rc;
-                if ((rc = c->d_sp_int.ensure(E + Nn + 2 * (size_t)tiles))) return rc;
-                if ((rc = c->d_sp_int4.ensure(Nn + Un))) return rc;
-                if ((rc = c->d_sp_f.ensure(64 * ((size_t)tiles + Rn)))) return rc;
-                if ((rc = c->d_sp.ensure(1))) return rc;
-                d2d::Spill sp;
-                memset(&sp, 0, sizeof sp);
-                sp.counters = c->d_rl_meta.p + 2;
-                sp.codes = c->d_sp_codes.p;
-                sp.rec_of = c->d_sp_int.p;
-                sp.node_next = c->d_sp_int.p + E;
-                sp.tiles = c->d_sp_int.p + E + Nn;
-                sp.tile_first = c->d_sp_int.p + E + Nn + tiles;
-                sp.nodes = c->d_sp_int4.p;
-                sp.units = c->d_sp_int4.p + Nn;
-                sp.acc = c->d_sp_f.p;
-                sp.vals = c->d_sp_f.p + 64 * (size_t)tiles;
-                sp.cap_entries = (int)E;
-                sp.cap_nodes = (int)Nn;
-                sp.cap_units = (int)Un;
-                sp.cap_recs = (int)Rn;
-                sp.U = (int)c->spill_unit;
-                sp.w0 = (int)c->spill_work;
-                if (!c->sp_host_valid || std::memcmp(&sp, &c->sp_host, sizeof sp) != 0) {
-                    c->sp_host = sp;
-                    c->sp_host_valid = true;
-                    HIP_TRY(hipMemcpyAsync(c->d_sp.p, &c->sp_host, sizeof sp, hipMemcpyHostToDevice, c->stream));
-                }
-                a.sp = c->d_sp.p;
+                HIP_TRY(d2d::launch_region_refine(k, grad_mode != 0, dim3((unsigned)rp.leaf.regions), lds_r, c->stream, al, rl.leaf, top, rl.lp, rl.flag));
             }
             a.rl = c->d_rl.p;
             c->rl_plan = rp;
@@ -1160,7 +1104,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             HIP_TRY(d2d::launch_fwd_grad(mode, a.rl != nullptr, p->max_order, grid_patches, lds2, c->stream, a));
             if (a.rl) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
                 d2d::SweepArgs af = a;
-                af.rl = nullptr; af.sp = nullptr; af.sched = nullptr; af.n_heavy = 0;
+                af.rl = nullptr; af.sched = nullptr; af.n_heavy = 0;
                 HIP_TRY(d2d::launch_fwd_grad(mode, false, p->max_order, dim3((unsigned)std::min<long long>(tiles, 256)), lds2, c->stream, af));
             }
         } else if (txg_culled) {
@@ -1190,10 +1134,10 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     constexpr int D2D_SPLIT_W = d2d::SPLIT_W;
     const d2d_host::SplitLds sl = d2d_host::split_lds_bytes(c->N, D2D_SPLIT_W, d2d::SPLIT_LIST);
     const size_t split_base = sl.base, split_lds = sl.total;  // ... + one culling queue per wave
-    const bool split = !a.sp && p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= d2d_host::LDS_LIMIT && tiles <= c->split_max_tiles;
+    const bool split = p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= d2d_host::LDS_LIMIT && tiles <= c->split_max_tiles;
     // the dearest patches of a bigger launch are cut in four (see power_fwd_kernel); they are only known with a work history
     dim3 grid_fwd = grid_patches;
-    if (!split && !a.sp && !d_stats && p->max_order == 2 && c->cw.size() >= 2 && a.sched == c->d_sched.p && sched_from_history && c->heavy_split > 0) {
+    if (!split && !d_stats && p->max_order == 2 && c->cw.size() >= 2 && a.sched == c->d_sched.p && sched_from_history && c->heavy_split > 0) {
         const long long P = d2d::HEAVY_PARTS;
         const d2d_host::HeavyPlan hp = d2d_host::heavy_plan(tiles, (long long)c->cw.size(), c->heavy_split, P);
         const long long H = hp.H, cap = hp.cap;
@@ -1216,14 +1160,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     a.cullq_off = (int)(split ? split_base : (size_t)(4 * c->N + 1) * sizeof(float4));
     if (split) HIP_TRY(d2d::launch_fwd_split(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, grid_patches, split_lds, c->stream, a));
     else HIP_TRY(d2d::launch_fwd(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, grid_fwd, tab_lds, c->stream, a));
-    if (a.sp) {
-        HIP_TRY(d2d::launch_spill_eval(mode, d_stats != nullptr, p->max_order, dim3((unsigned)c->spill_grid, (unsigned)c->spill_waves), c->stream, a));
-        hipLaunchKernelGGL(d2d::spill_merge_kernel, dim3(1024), dim3(64), 0, c->stream, a);
-        HIP_TRY(hipGetLastError());
-    }
     if (a.rl) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
         d2d::SweepArgs af = a;
-        af.rl = nullptr; af.sp = nullptr; af.sched = nullptr; af.n_heavy = 0;
+        af.rl = nullptr; af.sched = nullptr; af.n_heavy = 0;
         const dim3 gq((unsigned)std::min<long long>(tiles, 256));
         if (split) HIP_TRY(d2d::launch_fwd_split(mode, false, d_stats != nullptr, p->max_order, gq, split_lds, c->stream, af));
         else HIP_TRY(d2d::launch_fwd(mode, false, d_stats != nullptr, p->max_order, gq, tab_lds, c->stream, af));
@@ -1326,26 +1265,6 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "opt_parallel")) c->opt_parallel = value != 0;
     else if (!strcmp(name, "txg_exhaustive")) c->txg_exhaustive = value != 0;
     else if (!strcmp(name, "region_lists")) c->use_region_lists = value != 0;
-    else if (!strcmp(name, "spill")) c->use_spill = value != 0;
-    else if (!strcmp(name, "spill_work")) {
-        if (value < 0 || value > (1 << 30)) return fail(D2D_ERR_INVALID, "spill_work must lie in 0..2^30, got %lld", (long long)value);
-        c->spill_work = value;
-    } else if (!strcmp(name, "spill_unit")) {
-        if (value < 1 || value > 64) return fail(D2D_ERR_INVALID, "spill_unit must lie in 1..64, got %lld", (long long)value);
-        c->spill_unit = value;
-    } else if (!strcmp(name, "spill_grid")) {
-        if (value < 1 || value > (1 << 20)) return fail(D2D_ERR_INVALID, "spill_grid must lie in 1..2^20, got %lld", (long long)value);
-        c->spill_grid = value;
-    } else if (!strcmp(name, "spill_waves")) {
-        if (value < 1 || value > 4) return fail(D2D_ERR_INVALID, "spill_waves must lie in 1..4, got %lld", (long long)value);
-        c->spill_waves = value;
-    } else if (!strcmp(name, "spill_cap")) {
-        if (value < 1024 || value > (1ll << 30)) return fail(D2D_ERR_INVALID, "spill_cap must lie in 2^10..2^30, got %lld", (long long)value);
-        c->spill_cap = value;
-    } else if (!strcmp(name, "spill_recs")) {
-        if (value < 64 || value > (1ll << 26)) return fail(D2D_ERR_INVALID, "spill_recs must lie in 64..2^26, got %lld", (long long)value);
-        c->spill_recs = value;
-    }
     else if (!strcmp(name, "region_size")) {
         if (value < 1 || value > 64) return fail(D2D_ERR_INVALID, "region_size must lie in 1..64, got %lld", (long long)value);
         c->region_size = value;
@@ -1395,10 +1314,10 @@ int d2d_debug_region_stats(d2d_ctx* c, int64_t* out) {
     if (!c || !out) return fail(D2D_ERR_INVALID, "NULL argument");
     int rc = set_device(c);
     if (rc) return rc;
-    for (int i = 0; i < 14; ++i) out[i] = 0;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
     if (!c->rl_plan.on) return D2D_OK;
     const d2d_host::RegionPlan& rp = c->rl_plan;
-    std::vector<int> meta(10 + (size_t)rp.leaf.regions);
+    std::vector<int> meta(2 + (size_t)rp.leaf.regions);
     HIP_TRY(hipMemcpyAsync(meta.data(), c->d_rl_meta.p, meta.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     const int orders = c->rl_max_order - rp.k_lo + 1;
     const size_t per_order = (size_t)rp.leaf.slots + (size_t)rp.top.slots;
@@ -1408,8 +1327,7 @@ int d2d_debug_region_stats(d2d_ctx* c, int64_t* out) {
     out[0] = meta[1] + rp.n_static;
     out[1] = rp.max_chunks;
     out[2] = meta[0];
-    for (long long r = 0; r < rp.leaf.regions; ++r) out[3] += meta[10 + (size_t)r] != 0;
-    for (int i = 0; i < 6; ++i) out[8 + i] = meta[2 + i];
+    for (long long r = 0; r < rp.leaf.regions; ++r) out[3] += meta[2 + (size_t)r] != 0;
     for (int k = rp.k_lo; k <= c->rl_max_order && k <= 4; ++k) {
         const int* cnt = idx.data() + per_order * (size_t)(k - rp.k_lo);
         for (long long i = 0; i < rp.leaf.slots; ++i) out[2 + k] += cnt[i] > 0 ? cnt[i] : 0;

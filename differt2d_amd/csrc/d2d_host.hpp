@@ -195,10 +195,10 @@ inline RegionPlan region_plan(int tiles_x, int tiles_y, long long Nc, int min_or
         RegionLevelPlan l;
         l.R = R;
         l.S = Sl;
-        l.regions_x = (tiles_x + R - 1) / R;
-        l.regions_y = (tiles_y + R - 1) / R;
-        l.regions = (long long)l.regions_x * l.regions_y;
-        l.slots = l.regions * Sl;
+        l.regions_x = (int)(((long long)tiles_x + R - 1) / R);
+        l.regions_y = (int)(((long long)tiles_y + R - 1) / R);
+        l.regions = (long long)l.regions_x * l.regions_y;  // < 2^62
+        l.slots = l.regions > 0x3fffffffLL ? -1 : l.regions * Sl;  // (refused below; S <= 1024: no overflow)
         return l;
     };
     rp.leaf = level(R_leaf, 1);

@@ -82,38 +82,7 @@ struct RegionLists {
     int* flag;         // [leaf regions] != 0: some list of the region is not listed
 };
 
-// Spilled candidates.  A patch evaluates its first `u0` surviving candidates itself; whatever survives the culling
-// beyond that (the dear patches of a launch: next to the transmitter a patch can hold ten times the mean) is handed
-// over, in candidate order, as units of at most U candidates that spill_eval_kernel evaluates one wave per unit; the
-// contributions that are not exactly zero come back as records and spill_merge_kernel adds them, in candidate order, to
-// the sum the patch had reached -- the same left-to-right fp32 sum as the reference's (scene.py:1893-1916), bit for bit.
-struct Spill {
-    int* counters;               // [0] entries, [1] nodes, [2] units, [3] spilled patches, [4] records, [5] patches given up, [6] entries of all leaf lists
-    unsigned long long* codes;   // [cap_entries] candidate (12 bits per wall index, first wall lowest) | order << 56
-    int* rec_of;                 // [cap_entries] the record of an entry's contribution, -1: exactly zero in every lane
-    int4* nodes;                 // [cap_nodes] {first entry, entries (<= 64), -, -}: what one batch of a patch spilled
-    int* node_next;              // [cap_nodes] the patch's next node, -1 at the end
-    int4* units;                 // [cap_units] {patch, first entry, entries (<= U), -}
-    int* tiles;                  // [patches] the spilled patches (-1: given up, the enumerating kernel redoes it)
-    int* tile_first;             // [patches] first node of spilled patch i
-    float* acc;                  // [patches][64] the sum the patch had reached when it began to spill
-    float* vals;                 // [cap_recs][64] records
-    int cap_entries, cap_nodes, cap_units, cap_recs;
-    int U;
-    int w0;            // a patch spills what is left once its work counter has reached this (units of ~25 wave-instructions)
-};
-// wave-uniform state of a patch that may spill
-struct SpillSink {
-    const Spill* sp;  // null: never spills
-    unsigned w0;      // the patch spills what is left once its work counter (WaveStats::work) has reached this
-    int slot;         // index into Spill::tiles once the patch has spilled, else -1
-    int last_node;
-    int tile;
-    bool dead;        // an allocation failed after the patch began to spill: the enumerating kernel redoes the patch
-};
-
 struct SweepArgs {
-    const Spill* __restrict__ sp;        // LISTED forward kernels: where dear patches spill candidates to (or null)
     const RegionLists* __restrict__ rl;  // LISTED kernels: device copy of the lists' descriptor
     // Patches a LISTED kernel cannot take (a list of their region is not listed, or a cell is not comfortably finite) are
     // queued here and swept by the enumerating kernel launched right behind it (fb_n != null there: workgroups walk the queue)
@@ -1143,67 +1112,6 @@ __device__ __forceinline__ void emit_batch(EmitSink& e, unsigned long long code,
     e.n = start + cntm;
 }
 
-// Hands the candidates of the lanes in `mask` (in lane order) over to spill_eval_kernel.  False: nothing could be
-// allocated (the caller then either evaluates them itself or gives the patch up).
-__device__ __forceinline__ bool spill_mask(SpillSink& k, int K, unsigned long long code, unsigned long long mask) {
-    const int lane = threadIdx.x & 63;
-    const Spill* sp = k.sp;
-    const int cnt = __builtin_popcountll(mask);
-    const int U = sp->U;
-    const int nunits = (cnt + U - 1) / U;
-    int base = 0, node = 0, ub = 0, slot = k.slot;
-    if (lane == 0) {
-        base = atomicAdd(&sp->counters[0], cnt);
-        node = atomicAdd(&sp->counters[1], 1);
-        ub = atomicAdd(&sp->counters[2], nunits);
-        if (slot < 0) slot = atomicAdd(&sp->counters[3], 1);
-    }
-    base = __builtin_amdgcn_readfirstlane(base);
-    node = __builtin_amdgcn_readfirstlane(node);
-    ub = __builtin_amdgcn_readfirstlane(ub);
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    const bool ok = base + cnt <= sp->cap_entries && node < sp->cap_nodes && ub + nunits <= sp->cap_units;
-    // slots that were handed out are always filled in (the kernels behind walk all of them)
-    if (lane < nunits && ub + lane < sp->cap_units) {
-        const int c = ok ? min(U, cnt - lane * U) : 0;
-        sp->units[ub + lane] = make_int4(k.tile, base + lane * U, c, slot);
-    }
-    if (lane == 0) {
-        if (node < sp->cap_nodes) {
-            sp->nodes[node] = make_int4(base, ok ? cnt : 0, 0, 0);
-            sp->node_next[node] = -1;
-        }
-        if (k.slot < 0) {
-            sp->tiles[slot] = k.tile;
-            sp->tile_first[slot] = (node < sp->cap_nodes) ? node : -1;
-        } else if (node < sp->cap_nodes && k.last_node >= 0) {
-            sp->node_next[k.last_node] = node;
-        }
-    }
-    k.slot = slot;
-    if (node < sp->cap_nodes) k.last_node = node;
-    if (!ok) return false;
-    if ((mask >> lane) & 1ull) sp->codes[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = code | ((unsigned long long)K << 56);
-    return true;
-}
-
-// Spills the surviving candidates in `mask` (what is left of a batch) when the patch has done its share of work; true:
-// they are gone (spilled -- or the patch is given up because the buffers are full: the enumerating kernel redoes it).
-// Once a patch has spilled, everything behind is spilled too (its own sum must stay a prefix of the whole).
-__device__ __forceinline__ bool spill_rest(SpillSink& k, int K, unsigned long long code, unsigned long long mask, unsigned work) {
-    if (k.sp == nullptr) return false;
-    if (k.dead) return true;
-    if (k.slot < 0 && work < k.w0) return false;
-    if (mask && !spill_mask(k, K, code, mask)) {
-        k.dead = true;
-        if ((threadIdx.x & 63) == 0) {
-            k.sp->tiles[k.slot] = -1;
-            atomicAdd(&k.sp->counters[5], 1);
-        }
-    }
-    return true;
-}
-
 // All candidates of order K >= 1 with tile culling; `tab` = LDS copy of {refl[2N], flt[N]}.
 // K >= 2: only the prefixes whose FIRST position lies in [p_lo, p_hi) (positions into cw[]).  LIST: instead of being
 // added to acc, every contribution that is not exactly zero is appended to `sink` (adding an exact zero never changes
@@ -1214,8 +1122,7 @@ template <int K, int MODE, bool STATS, bool GRAD = false, bool LIST = false, boo
 __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                    const float (&by)[4], float rxx, float rxy, bool lane_bad, float& acc,
                                                    WaveStats& st, GradCtx* g = nullptr, int p_lo = 0,
-                                                   int p_hi = 0x7fffffff, ListSink* sink = nullptr, EmitSink* emit = nullptr,
-                                                   SpillSink* spill = nullptr) {
+                                                   int p_hi = 0x7fffffff, ListSink* sink = nullptr, EmitSink* emit = nullptr) {
     static_assert(!EMIT || K >= 2, "lists exist for orders >= 2");
     const int lane = threadIdx.x & 63;
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
@@ -1450,7 +1357,6 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
             const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
             // ---- lanes = RX cells: survivors in ascending order (= the reference's order)
             while (mask) {
-                if (K == 1 && spill && spill_rest(*spill, 1, (unsigned long long)cmem(a.cw)[lp < Nc ? lp : 0], mask, st.work)) break;
                 const int b = __builtin_ctzll(mask);
                 mask &= mask - 1;
                 cand[K - 1] = cmem(a.cw)[chunk * 64 + b];
@@ -1561,8 +1467,7 @@ __device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, con
 template <int K, int MODE, bool STATS, bool GRAD, bool LIST>
 __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                    const float (&by)[4], float rxx, float rxy, bool lane_bad, float& acc,
-                                                   WaveStats& st, GradCtx* g, long region, int part, int parts, ListSink* sink,
-                                                   SpillSink* spill = nullptr) {
+                                                   WaveStats& st, GradCtx* g, long region, int part, int parts, ListSink* sink) {
     static_assert(K >= 2, "lists exist for orders >= 2");
     const int lane = threadIdx.x & 63;
     const RegionLists* rl = a.rl;
@@ -1620,7 +1525,6 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
         }
         const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
         while (mask && budget > 0) {
-            if (spill && spill_rest(*spill, K, code, mask, st.work)) break;
             const int b = __builtin_ctzll(mask);
             mask &= mask - 1;
             --budget;
@@ -1653,9 +1557,9 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
 template <int K, int MODE, bool STATS, bool GRAD, bool LIST, bool LISTED>
 __device__ __forceinline__ void sweep_order_any(const SweepArgs& a, const float4* tab, const float (&bx)[4], const float (&by)[4],
                                                 float rxx, float rxy, bool lane_bad, float& acc, WaveStats& st, GradCtx* g,
-                                                long region, int part, int parts, ListSink* sink, SpillSink* spill = nullptr) {
+                                                long region, int part, int parts, ListSink* sink) {
     if constexpr (K >= 2 && LISTED) {
-        sweep_order_listed<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, region, part, parts, sink, spill);
+        sweep_order_listed<K, MODE, STATS, GRAD, LIST>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, g, region, part, parts, sink);
     } else {
         int lo = 0, hi = 0x7fffffff;
         if (parts > 1) first_wall_range(a, part, parts, lo, hi);
@@ -1736,14 +1640,6 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, const float4* tab,
             return;
         }
     }
-    constexpr bool SPILL = LISTED && !GRADK;  // (the value+grad sweep keeps every patch in one wave)
-    SpillSink spl;
-    spl.sp = SPILL ? a.sp : nullptr;
-    spl.w0 = SPILL && a.sp ? (unsigned)cmem(a.sp)->w0 : 0xffffffffu;
-    spl.slot = -1;
-    spl.last_node = -1;
-    spl.tile = (int)tile;
-    spl.dead = false;
     float acc = 0.0f;  // scene.py:1893
     GradCtx g;
     g.grx = g.gry = g.tbx = g.tby = 0.0f;
@@ -1838,29 +1734,17 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, const float4* tab,
         st.work = work;
         if (lane == 0) a.heavy_done[tile0] = 0;  // ready for the next launch
     } else {
-    if (a.min_order <= 0 && a.max_order >= 0) {
-        sweep_order<0, MODE, STATS, GRADK>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, &g);
-    }
+    if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, GRADK>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, &g);
     unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[11] += tq1 - tq0;      // order 0
-    if (a.min_order <= 1 && a.max_order >= 1)
-        sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, 0, 0x7fffffff, nullptr, nullptr, SPILL ? &spl : nullptr);
+    if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
     unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[12] += tq2 - tq1;      // order 1
-    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_any<2, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr, SPILL ? &spl : nullptr);
+    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_any<2, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
     if (STATS) st.c[13] += __builtin_amdgcn_s_memtime() - tq2;  // order 2
-    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_any<3, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr, SPILL ? &spl : nullptr);
-    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_any<4, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr, SPILL ? &spl : nullptr);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_any<3, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_any<4, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
     }
-    if (SPILL && spl.dead) {
-        // the spill buffers ran out half way: the enumerating kernel redoes the patch
-        if (lane == 0) a.fb_list[atomicAdd(a.fb_n, 1)] = (int)tile;
-        return;
-    }
-    if (SPILL && spl.slot >= 0) {
-        // spill_merge_kernel finishes the sum and writes the cells
-        spl.sp->acc[(size_t)spl.slot * 64 + lane] = acc;
-    } else
     if (in_range) {
         if (a.out_mode == D2D_OUT_ADD) {
             a.out[idx] = a.out[idx] + acc;
@@ -1922,78 +1806,6 @@ __global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs 
         return;
     }
     fwd_patch<MODE, STATS, MAXK, GRADK, LISTED>(a, tab, wl, (long)blockIdx.x, false);
-}
-
-// The spilled candidates (Spill): one unit (<= U consecutive candidates of one patch) per wave, workgroups stride over the
-// units.  Every candidate is evaluated exactly as the patch itself would have (same op chain); a contribution that is
-// not exactly zero in some lane becomes a record, to be added by spill_merge_kernel in candidate order.
-template <int MODE, bool STATS, int MAXK>
-__global__ void __launch_bounds__(256) spill_eval_kernel(SweepArgs a) {
-    const int lane = threadIdx.x & 63;
-    const Spill spv = *a.sp;  // (by value: the stores below could alias the descriptor)
-    const Spill* sp = &spv;
-    const int n_units = __builtin_amdgcn_readfirstlane(min(sp->counters[2], sp->cap_units));
-    const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
-    WaveStats st;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) st.c[i] = 0;
-    st.work = 0;
-    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;  // one unit per wave
-    for (int u = blockIdx.x * nw + wv; u < n_units; u += gridDim.x * nw) {
-        const int4 unit_v = ldc4i(sp->units, u);
-        // (wave-uniform values in scalar registers: everything indexed by them is then fetched with scalar loads)
-        const int4 unit = make_int4(__builtin_amdgcn_readfirstlane(unit_v.x), __builtin_amdgcn_readfirstlane(unit_v.y),
-                                    __builtin_amdgcn_readfirstlane(unit_v.z), __builtin_amdgcn_readfirstlane(unit_v.w));
-        const int tile = unit.x, start = unit.y, count = unit.z;
-        const int tcol = tile % tiles_x, trow = tile / tiles_x;
-        const int col = tcol * TILE_W + (lane & (TILE_W - 1));
-        const int row = trow * TILE_H + (lane / TILE_W);
-        const int ccol = col < a.n ? col : a.n - 1;
-        const int crow = row < a.m ? row : a.m - 1;
-        const long idx = (long)crow * a.n + ccol;
-        const float rxx = a.X[idx], rxy = a.Y[idx];  // comfortably finite: the patch checked before it spilled
-        st.shadow = -1;
-        for (int i = 0; i < count; ++i) {
-            const unsigned long long cu_v = cmem(sp->codes)[start + i];
-            const unsigned long long cu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cu_v >> 32)) << 32) |
-                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(cu_v & 0xffffffffull));
-            const int K = (int)((cu >> 56) & 7ull);
-            int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
-            float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
-#pragma unroll
-            for (int d = 0; d < MAXK; ++d) {
-                if (d < K) {
-                    ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
-                    image_of(ldc4(a.refl, 2 * ce[d]), d == 0 ? a.txx : ex[d > 0 ? d - 1 : 0], d == 0 ? a.txy : ey[d > 0 ? d - 1 : 0], ex[d], ey[d]);
-                }
-            }
-            float t = 0.0f;
-            if (K == 1) eval_candidate<1, MODE, STATS, false, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, false, t, st, nullptr);
-            else if (K == 2) eval_candidate<2, MODE, STATS, false, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, false, t, st, nullptr);
-            else if (MAXK >= 3 && K == 3) eval_candidate<(MAXK >= 3 ? 3 : 2), MODE, STATS, false, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, false, t, st, nullptr);
-            else if (MAXK >= 4 && K == 4) eval_candidate<(MAXK >= 4 ? 4 : 2), MODE, STATS, false, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, false, t, st, nullptr);
-            int rec = -1;
-            if (wave_any(!(t == 0.0f))) {  // non-zero or NaN somewhere
-                if (lane == 0) rec = atomicAdd(&sp->counters[4], 1);
-                rec = __builtin_amdgcn_readfirstlane(rec);
-                if (rec < sp->cap_recs) {
-                    sp->vals[(size_t)rec * 64 + lane] = t;
-                } else {
-                    // no room for the record: the patch is given up (once) and redone by the enumerating kernel
-                    if (lane == 0 && atomicExch(&sp->tiles[unit.w], -1) >= 0) {
-                        a.fb_list[atomicAdd(a.fb_n, 1)] = tile;
-                        atomicAdd(&sp->counters[5], 1);
-                    }
-                    rec = -1;
-                }
-            }
-            if (lane == 0) sp->rec_of[start + i] = rec;
-        }
-    }
-    if (STATS && lane == 0 && a.stats) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) atomicAdd(&a.stats[i], st.c[i]);
-    }
 }
 
 // Forward sweep with every 8 x 8 patch shared by W waves (one workgroup).  Patches differ a lot in cost and the dearest
@@ -2183,7 +1995,7 @@ __global__ void __launch_bounds__(64) region_list_kernel(SweepArgs a, RegionLeve
 // keeps what the tile culling cannot drop for its own, smaller box.  `flag`: raised when the list is not listed.
 constexpr int RL_GATHER = 512;  // entries of the gather buffer (LDS)
 template <int K, bool GRAD>
-__global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLevel lv, RegionLevel parent, ListPool lp, int* flag, int* total_out) {
+__global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLevel lv, RegionLevel parent, ListPool lp, int* flag) {
     const int lane = threadIdx.x & 63;
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then the gather buffer
     for (int i = lane; i < 2 * a.N; i += 64) tab[i] = ldc4(a.refl, i);
@@ -2233,7 +2045,6 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
     if (lane == 0) {
         lv.cnt[K][region] = em.over ? -1 : em.n;
         if (em.over) flag[region] = 1;
-        else if (total_out) atomicAdd(total_out, em.n);
     }
 }
 
@@ -2566,39 +2377,6 @@ __global__ void __launch_bounds__(256) region_box_kernel(const float* __restrict
         }
         const bool anybad = sbad[0] | sbad[1] | sbad[2] | sbad[3];
         box[region] = make_float4(anybad ? __builtin_nanf("") : x0, x1, y0, y1);
-    }
-}
-
-// Finishes the spilled patches: adds the recorded contributions of a patch's spilled candidates, in candidate order, to
-// the sum the patch had reached, and writes the cells (scene.py:1909, 1934-1953).  One wave per spilled patch (strided).
-__global__ void __launch_bounds__(64) spill_merge_kernel(SweepArgs a) {
-    const int lane = threadIdx.x & 63;
-    const Spill* sp = a.sp;
-    const int n = sp->counters[3];
-    const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
-    for (int slot = blockIdx.x; slot < n; slot += gridDim.x) {
-        const int tile = sp->tiles[slot];
-        if (tile < 0) continue;  // given up: the enumerating kernel redoes it
-        float acc = sp->acc[(size_t)slot * 64 + lane];
-        for (int node = sp->tile_first[slot]; node >= 0; node = sp->node_next[node]) {
-            const int4 nd = sp->nodes[node];
-            const int r = lane < nd.y ? sp->rec_of[nd.x + lane] : -1;
-            unsigned long long m = __ballot(r >= 0);
-            while (m) {
-                const int b = __builtin_ctzll(m);
-                m &= m - 1;
-                const int rr = __builtin_amdgcn_readlane(r, b);
-                acc = acc + sp->vals[(size_t)rr * 64 + lane];
-            }
-        }
-        const int tcol = tile % tiles_x, trow = tile / tiles_x;
-        const int col = tcol * TILE_W + (lane & (TILE_W - 1));
-        const int row = trow * TILE_H + (lane / TILE_W);
-        if (col < a.n && row < a.m) {
-            const long idx = (long)row * a.n + col;
-            if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
-            else a.out[idx] = acc;
-        }
     }
 }
 

@@ -23,13 +23,11 @@ hipError_t launch_txg(int mode, bool grad, int max_order, dim3 grid, size_t lds,
 // power_vg_kernel<MODE, TXG, GRADK>: exhaustive sweeps (strict_nan value+grad; "txg_exhaustive" values)
 hipError_t launch_vg(int mode, bool txg, bool grad, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a);
 
-// spill_eval_kernel<MODE, STATS, MAXK>: the candidates the dear patches of a LISTED forward launch handed over (a.sp)
-hipError_t launch_spill_eval(int mode, bool stats, int max_order, dim3 grid, hipStream_t stream, const SweepArgs& a);
 // region_list_kernel<K, GRAD>: candidate lists of order K (2..4) of level `lv` by enumeration; grid = regions x slices
 hipError_t launch_region_lists(int K, bool grad, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a, const RegionLevel& lv,
                                const ListPool& lp);
 // region_refine_kernel<K, GRAD>: the lists of level `lv` (one per region) from those of `parent`; grid = regions of `lv`
 hipError_t launch_region_refine(int K, bool grad, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a, const RegionLevel& lv,
-                                const RegionLevel& parent, const ListPool& lp, int* flag, int* total_out);
+                                const RegionLevel& parent, const ListPool& lp, int* flag);
 
 }  // namespace d2d

@@ -96,22 +96,6 @@ hipError_t launch_fwd_listed_m<TU_MODE>(bool stats, int max_order, dim3 grid, si
     }
     return hipGetLastError();
 }
-template <int MODE> hipError_t launch_spill_eval_m(bool stats, int max_order, dim3 grid, hipStream_t s, const SweepArgs& a);
-template <>
-hipError_t launch_spill_eval_m<TU_MODE>(bool stats, int max_order, dim3 grid, hipStream_t s, const SweepArgs& a) {
-    const dim3 block(grid.y > 1 ? 64 * grid.y : 64);  // (grid.y carries the waves per workgroup)
-    grid.y = 1;
-    if (stats) {
-        if (max_order <= 2) hipLaunchKernelGGL((spill_eval_kernel<TU_MODE, true, 2>), grid, block, 0, s, a);
-        else if (max_order == 3) hipLaunchKernelGGL((spill_eval_kernel<TU_MODE, true, 3>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((spill_eval_kernel<TU_MODE, true, 4>), grid, block, 0, s, a);
-    } else {
-        if (max_order <= 2) hipLaunchKernelGGL((spill_eval_kernel<TU_MODE, false, 2>), grid, block, 0, s, a);
-        else if (max_order == 3) hipLaunchKernelGGL((spill_eval_kernel<TU_MODE, false, 3>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((spill_eval_kernel<TU_MODE, false, 4>), grid, block, 0, s, a);
-    }
-    return hipGetLastError();
-}
 #elif D2D_TU_FAMILY == 7
 template <int MODE> hipError_t launch_fwd_grad_listed_m(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <>
@@ -155,16 +139,16 @@ hipError_t launch_region_lists(int K, bool grad, dim3 grid, size_t lds, hipStrea
     return hipGetLastError();
 }
 hipError_t launch_region_refine(int K, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a, const RegionLevel& lv,
-                                const RegionLevel& parent, const ListPool& lp, int* flag, int* total_out) {
+                                const RegionLevel& parent, const ListPool& lp, int* flag) {
     const dim3 block(64);
     if (grad) {
-        if (K == 2) hipLaunchKernelGGL((region_refine_kernel<2, true>), grid, block, lds, s, a, lv, parent, lp, flag, total_out);
-        else if (K == 3) hipLaunchKernelGGL((region_refine_kernel<3, true>), grid, block, lds, s, a, lv, parent, lp, flag, total_out);
-        else hipLaunchKernelGGL((region_refine_kernel<4, true>), grid, block, lds, s, a, lv, parent, lp, flag, total_out);
+        if (K == 2) hipLaunchKernelGGL((region_refine_kernel<2, true>), grid, block, lds, s, a, lv, parent, lp, flag);
+        else if (K == 3) hipLaunchKernelGGL((region_refine_kernel<3, true>), grid, block, lds, s, a, lv, parent, lp, flag);
+        else hipLaunchKernelGGL((region_refine_kernel<4, true>), grid, block, lds, s, a, lv, parent, lp, flag);
     } else {
-        if (K == 2) hipLaunchKernelGGL((region_refine_kernel<2, false>), grid, block, lds, s, a, lv, parent, lp, flag, total_out);
-        else if (K == 3) hipLaunchKernelGGL((region_refine_kernel<3, false>), grid, block, lds, s, a, lv, parent, lp, flag, total_out);
-        else hipLaunchKernelGGL((region_refine_kernel<4, false>), grid, block, lds, s, a, lv, parent, lp, flag, total_out);
+        if (K == 2) hipLaunchKernelGGL((region_refine_kernel<2, false>), grid, block, lds, s, a, lv, parent, lp, flag);
+        else if (K == 3) hipLaunchKernelGGL((region_refine_kernel<3, false>), grid, block, lds, s, a, lv, parent, lp, flag);
+        else hipLaunchKernelGGL((region_refine_kernel<4, false>), grid, block, lds, s, a, lv, parent, lp, flag);
     }
     return hipGetLastError();
 }

@@ -233,12 +233,10 @@ class Context:
 
     def debug_region_stats(self) -> dict:
         """Diagnostic: the region candidate lists of the last launch that built any (include/d2d.h)."""
-        o = np.zeros(14, np.int64)
+        o = np.zeros(8, np.int64)
         L.check(self._lib.d2d_debug_region_stats(self._ctx, o))
         return {"pool_chunks_used": int(o[0]), "pool_chunks": int(o[1]), "patches_enumerated": int(o[2]), "regions_not_listed": int(o[3]),
-                "leaf_entries": {2: int(o[4]), 3: int(o[5]), 4: int(o[6])}, "leaf_regions": int(o[7]),
-                "spill": {"entries": int(o[8]), "nodes": int(o[9]), "units": int(o[10]), "patches": int(o[11]), "records": int(o[12]),
-                          "given_up": int(o[13])}}
+                "leaf_entries": {2: int(o[4]), 3: int(o[5]), 4: int(o[6])}, "leaf_regions": int(o[7])}
 
     def last_kernel_ms(self) -> float:
         """Duration of the sweep kernel of the last launch (needs ``set_option("time_kernel", 1)``)."""

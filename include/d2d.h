@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define D2D_MAX_ORDER 4 /* highest interaction order a sweep accepts */
-#define D2D_ABI_VERSION 4
+#define D2D_ABI_VERSION 5
 
 typedef enum d2d_status {
     D2D_OK = 0,
@@ -208,6 +208,18 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *   "pair_masks": zero = do not build / use the wall-to-wall occlusion masks (A/B and tests; same results)
  *   "opt_parallel": zero = MinPath / FermatPath sweeps walk the candidates one after the other in every lane (same results)
  *   "txg_exhaustive": non-zero = TX-grid value sweeps use the exhaustive kernel instead of the culled one (same results)
+ *   "region_lists": zero = no region candidate lists: every patch enumerates the prefixes of its candidates itself
+ *                   (default non-zero: culled RX-grid launches of max_order >= 2 build, per launch, for every region of
+ *                   patches the list of candidates that the tile culling cannot drop for the region's bounding box, and
+ *                   the patches only test and evaluate those; same results)
+ *   "region_size" / "region_size_top": leaf regions are region_size x region_size patches (default 4, 1..64); their
+ *                   lists are refined from those of regions of region_size_top patches a side (default 16, rounded down to
+ *                   a multiple of region_size), which are built by enumeration
+ *   "region_slices": lists per top region = slices of first walls = waves that enumerate it (default 0: a quarter of
+ *                   the allowed objects); "region_budget_mb": device memory of the list pool (default 512); a list
+ *                   that does not fit is marked as not listed and the patches of its region enumerate (same results)
+ *   "sched_key_mode": schedule keys from 0 (default) the work history if there is one, else the lengths of the region
+ *                   lists, else the geometric proxy; 1 never the history; 2 never the lists
  *   "time_kernel": non-zero = bracket the sweep kernel of every launch with HIP events (see d2d_last_kernel_ms)
  * Also read once at d2d_create from the environment: D2D_SPLIT_MAX_TILES, D2D_SCHED_MIN_TILES. No reference counterpart
  * (XLA picks its own launch shapes). Returns D2D_ERR_INVALID for an unknown name. */
@@ -221,9 +233,8 @@ int d2d_debug_set_schedule(d2d_ctx* ctx, const int32_t* order, int64_t n);
 int d2d_debug_get_schedule(d2d_ctx* ctx, int32_t* order, uint8_t* key, int64_t n);
 /* Region candidate lists of the last launch that built any (all zeros otherwise): out[0] pool chunks handed out,
  * [1] pool chunks available, [2] patches left to the enumerating kernel, [3] leaf regions with a list that is not listed,
- * [4] / [5] / [6] entries of the leaf lists of order 2 / 3 / 4, [7] leaf regions; spilled candidates: [8] entries,
- * [9] nodes, [10] units, [11] patches that spilled, [12] records, [13] patches given up.  Waits for the stream. */
-int d2d_debug_region_stats(d2d_ctx* ctx, int64_t* out /* [14] */);
+ * [4] / [5] / [6] entries of the leaf lists of order 2 / 3 / 4, [7] leaf regions.  Waits for the stream. */
+int d2d_debug_region_stats(d2d_ctx* ctx, int64_t* out /* [8] */);
 
 /* The work history behind the schedule: what each of the n patches took in the last culled sweep (units of ~25
  * wave-instructions, counted by the kernels). */

@@ -45,4 +45,14 @@ void san_heavy_plan(long long tiles, long long Nc, long long heavy_split, long l
     out4[3] = hp.cnt_ints;
 }
 
+// out: on, top.R, top.S, top.regions, top.slots, leaf.R, leaf.S, leaf.regions, leaf.slots, n_static, max_chunks, k_lo
+void san_region_plan(int tiles_x, int tiles_y, long long Nc, int min_order, int max_order, int R_leaf, int R_top, int S_req,
+                     long long budget_bytes, int chunk, long long* out12) {
+    const d2d_host::RegionPlan rp = d2d_host::region_plan(tiles_x, tiles_y, Nc, min_order, max_order, R_leaf, R_top, S_req, budget_bytes, chunk);
+    out12[0] = rp.on ? 1 : 0;
+    out12[1] = rp.top.R; out12[2] = rp.top.S; out12[3] = rp.top.regions; out12[4] = rp.top.slots;
+    out12[5] = rp.leaf.R; out12[6] = rp.leaf.S; out12[7] = rp.leaf.regions; out12[8] = rp.leaf.slots;
+    out12[9] = rp.n_static; out12[10] = rp.max_chunks; out12[11] = rp.k_lo;
+}
+
 }  // extern "C"

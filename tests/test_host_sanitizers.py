@@ -173,6 +173,29 @@ def test_libd2d_host_logic_under_asan_and_ubsan(asan, tmp_path):
         assert out[0] == 64 and out[1] == (13 + 2) * 50 + 52          # the benchmark's own launch
         L.san_heavy_plan(2**31 - 1, 256, 2**40, 4, out)
         assert out[0] == 0                                            # 2^27 patches x 4 x 17 154 x 256 B: refused
+        # ---- region-list plan: every list owns a chunk, the levels nest, absurd sizes switch the lists off
+        L.san_region_plan.argtypes = [C.c_int, C.c_int, C.c_longlong] + [C.c_int] * 5 + [C.c_longlong, C.c_int, C.POINTER(C.c_longlong)]
+        L.san_region_plan.restype = None
+        o = (C.c_longlong * 12)()
+        for tx_, ty_, Nc, lo, hi, Rl, Rt, S, budget in ((128, 128, 50, 0, 2, 4, 16, 0, 512 << 20), (256, 256, 200, 0, 3, 4, 16, 0, 512 << 20),
+                                                      (1, 1, 2, 2, 2, 4, 16, 0, 1 << 20), (128, 128, 50, 3, 4, 4, 6, 7, 512 << 20),
+                                                      (128, 128, 1, 0, 2, 4, 16, 0, 512 << 20), (128, 128, 50, 0, 1, 4, 16, 0, 512 << 20),
+                                                      (2**31 - 1, 2**31 - 1, 50, 0, 2, 1, 1, 0, 2**62), (128, 128, 50, 0, 2, 4, 16, 0, 1024),
+                                                      (128, 128, 2**40, 0, 4, 4, 16, 0, 2**40), (0, 5, 50, 0, 2, 4, 16, 0, 1 << 30),
+                                                      (128, 128, 50, 0, 2, 0, 16, 0, 1 << 30), (128, 128, 50, 0, 2, 4, 16, 5000, 1 << 30)):
+            L.san_region_plan(tx_, ty_, Nc, lo, hi, Rl, Rt, S, budget, 128, o)
+            if not o[0]:
+                continue
+            tR, tS, tr, ts, lR, lS, lr, ls, nst, mc, klo = [o[i] for i in range(1, 12)]
+            assert lR == Rl and lS == 1 and tR % lR == 0 and tR >= lR and 1 <= tS <= 1024
+            assert lr == -(-tx_ // lR) * -(-ty_ // lR) == ls and tr == -(-tx_ // tR) * -(-ty_ // tR) and ts == tr * tS
+            assert klo == max(2, lo) <= hi and nst == (ls + ts) * (hi - klo + 1) and 2 * nst <= mc <= 2**31 - 1 and mc * 128 * 8 <= budget
+        L.san_region_plan(128, 128, 50, 0, 2, 4, 16, 0, 512 << 20, 128, o)
+        assert list(o) == [1, 16, 13, 64, 832, 4, 1, 1024, 1024, 1856, 524288, 2]   # the benchmark's own launch
+        L.san_region_plan(128, 128, 50, 0, 1, 4, 16, 0, 512 << 20, 128, o)
+        assert o[0] == 0                                                            # orders <= 1: no lists
+        L.san_region_plan(2**31 - 1, 2**31 - 1, 50, 0, 2, 1, 1, 0, 2**62, 128, o)
+        assert o[0] == 0                                                            # 2^62 regions: refused
         print("HOST-SAN-OK")
     """
     out = _run_child(code, asan)
