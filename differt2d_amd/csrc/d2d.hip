@@ -166,6 +166,7 @@ struct d2d_ctx {
     DevBuf<int> d_sched_override;       // diagnostic: a caller-supplied schedule (d2d_debug_set_schedule)
     long long sched_override_n = 0;
     bool use_cost_history = true;
+    long long fwd_waves = 0;            // patches (= waves) per workgroup of the LISTED forward sweep kernel: 1, 4, or 0 = by the table's size
     long long sched_key_mode = 0;       // schedule keys: 0 work history if there is one, else list lengths, else the proxy; 1 never the history; 2 never the lists
     bool txg_exhaustive = false;        // TX-grid value sweeps with the exhaustive kernel (A/B and tests)
     long long sched_min_tiles = 2048;   // launches with fewer patches keep the identity schedule
@@ -189,7 +190,14 @@ struct d2d_ctx {
     long long region_size = 4;         // leaf regions (what the sweep kernels read) are region_size x region_size patches
     long long region_size_top = 16;    // regions listed by enumeration (a multiple of region_size; equal: one level only)
     long long region_slices = 0;       // slices of first walls per enumerated region (0: chosen from the number of allowed walls)
-    long long region_budget_mb = 512;  // device memory of the list pool
+    long long region_budget_mb = 8192; // device memory the list pool may grow to
+    long long rl_pool_mb = 256;        // its current size: quadrupled (up to the budget) after a launch whose lists did not fit
+    int* h_meta = nullptr;             // pinned: {patches left to the enumerating kernel, pool chunks handed out} of the last launch with lists
+    hipEvent_t ev_meta = nullptr;
+    bool meta_pending = false;
+    long long rl_meta_static = 0, rl_meta_chunks = 0;  // n_static / max_chunks of the launch h_meta describes
+    long long fb_hint = 0;             // patches the last such launch left to the enumerating kernel
+    long long rl_launches = 0;         // launches with lists since the plan last changed (the read-back thins out: 1, 2, 3, then every 16th)
     DevBuf<unsigned long long> d_rl_pool;
     DevBuf<float4> d_rl_box;           // bounding boxes of the leaf regions, then of the top regions (region_box_kernel)
     long long rl_box_key[4] = {-1, 0, 0, 0};  // grid version, leaf R, top R (0: one level) the boxes were built for
@@ -487,6 +495,8 @@ int d2d_create(int device, d2d_ctx** out) {
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->ev1);
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->evk0);
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->evk1);
+    if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_meta, hipEventDisableTiming);
+    if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void**>(&c->h_meta), 2 * sizeof(int), hipHostMallocDefault);
     if (e1 != hipSuccess) {
         delete c;
         return fail(D2D_ERR_HIP, "context creation failed: %s", hipGetErrorString(e1));
@@ -539,6 +549,8 @@ void d2d_destroy(d2d_ctx* c) {
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->evk0) (void)hipEventDestroy(c->evk0);
     if (c->evk1) (void)hipEventDestroy(c->evk1);
+    if (c->ev_meta) (void)hipEventDestroy(c->ev_meta);
+    if (c->h_meta) (void)hipHostFree(c->h_meta);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -938,9 +950,17 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     a.fb_n = nullptr;
     a.fb_list = nullptr;
     if (!txg && c->use_region_lists && p->max_order >= 2 && c->cw.size() >= 2 && c->N <= 4095 && !(grad_mode && p->strict_nan)) {
+        // how the previous launch's lists fared (read back without waiting: a launch or two late is early enough)
+        if (c->meta_pending && hipEventQuery(c->ev_meta) == hipSuccess) {
+            c->meta_pending = false;
+            c->fb_hint = c->h_meta[0];
+            if ((long long)c->h_meta[1] + c->rl_meta_static > c->rl_meta_chunks && c->rl_pool_mb < c->region_budget_mb)
+                c->rl_pool_mb = std::min(c->region_budget_mb, c->rl_pool_mb * 4);  // the pool ran out: a bigger one from now on
+        }
+        if (c->rl_pool_mb > c->region_budget_mb) c->rl_pool_mb = c->region_budget_mb;
         const d2d_host::RegionPlan rp =
             d2d_host::region_plan(tiles_x, tiles_y, (long long)c->cw.size(), p->min_order, p->max_order, (int)c->region_size,
-                                  (int)c->region_size_top, (int)c->region_slices, c->region_budget_mb << 20, d2d::RL_CHUNK);
+                                  (int)c->region_size_top, (int)c->region_slices, c->rl_pool_mb << 20, d2d::RL_CHUNK);
         const size_t lds_l = (size_t)(3 * c->N + 1) * sizeof(float4) + 512;                                         // tables + culling queue
         const size_t lds_r = (size_t)(3 * c->N + 1) * sizeof(float4) + (size_t)d2d::RL_GATHER * sizeof(unsigned long long);  // tables + gather buffer
         if (rp.on && lds_l <= d2d_host::LDS_LIMIT && lds_r <= d2d_host::LDS_LIMIT) {
@@ -1012,6 +1032,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             a.rl = c->d_rl.p;
             c->rl_plan = rp;
             c->rl_max_order = p->max_order;
+            c->rl_launches = (c->rl_meta_static == rp.n_static && c->rl_meta_chunks == rp.max_chunks) ? c->rl_launches + 1 : 1;
+            c->rl_meta_static = rp.n_static;
+            c->rl_meta_chunks = rp.max_chunks;
         }
     }
     if (!a.rl) c->rl_plan.on = false;
@@ -1105,7 +1128,13 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             if (a.rl) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
                 d2d::SweepArgs af = a;
                 af.rl = nullptr; af.sched = nullptr; af.n_heavy = 0;
-                HIP_TRY(d2d::launch_fwd_grad(mode, false, p->max_order, dim3((unsigned)std::min<long long>(tiles, 256)), lds2, c->stream, af));
+                HIP_TRY(d2d::launch_fwd_grad(mode, false, p->max_order, dim3((unsigned)std::min<long long>(tiles, std::max<long long>(256, c->fb_hint))),
+                                             lds2, c->stream, af));
+                if (!c->meta_pending && c->h_meta && (c->rl_launches <= 3 || c->rl_launches % 16 == 0)) {
+                    HIP_TRY(hipMemcpyAsync(c->h_meta, c->d_rl_meta.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(hipEventRecord(c->ev_meta, c->stream));
+                    c->meta_pending = true;
+                }
             }
         } else if (txg_culled) {
             // TX grid, culled value+grad sweep
@@ -1159,13 +1188,25 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     }
     a.cullq_off = (int)(split ? split_base : (size_t)(4 * c->N + 1) * sizeof(float4));
     if (split) HIP_TRY(d2d::launch_fwd_split(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, grid_patches, split_lds, c->stream, a));
-    else HIP_TRY(d2d::launch_fwd(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, grid_fwd, tab_lds, c->stream, a));
+    else {
+        // one patch per wave, fwd_waves waves per workgroup (fewer, bigger workgroups are dispatched faster)
+        // (0: 4 when a single-wave workgroup's LDS would keep a CU below 32 waves, else 1; STATS and the enumerating build: 1)
+        unsigned wpb = c->fwd_waves > 0 ? (unsigned)c->fwd_waves : ((tab_lds * 32 > 160 * 1024) ? 4u : 1u);
+        if (!a.rl || d_stats) wpb = 1;
+        const dim3 g((grid_fwd.x + wpb - 1) / wpb, wpb);
+        HIP_TRY(d2d::launch_fwd(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, g, tab_lds + (wpb - 1) * 512, c->stream, a));
+    }
     if (a.rl) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
         d2d::SweepArgs af = a;
         af.rl = nullptr; af.sched = nullptr; af.n_heavy = 0;
-        const dim3 gq((unsigned)std::min<long long>(tiles, 256));
+        const dim3 gq((unsigned)std::min<long long>(tiles, std::max<long long>(256, c->fb_hint)));
         if (split) HIP_TRY(d2d::launch_fwd_split(mode, false, d_stats != nullptr, p->max_order, gq, split_lds, c->stream, af));
         else HIP_TRY(d2d::launch_fwd(mode, false, d_stats != nullptr, p->max_order, gq, tab_lds, c->stream, af));
+        if (!c->meta_pending && c->h_meta && (c->rl_launches <= 3 || c->rl_launches % 16 == 0)) {
+            HIP_TRY(hipMemcpyAsync(c->h_meta, c->d_rl_meta.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(c->ev_meta, c->stream));
+            c->meta_pending = true;
+        }
     }
     D2D_KERNEL_DONE();
     return D2D_OK;
@@ -1261,6 +1302,10 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "time_kernel")) c->time_kernel = value != 0;
     else if (!strcmp(name, "cost_history")) c->use_cost_history = value != 0;
     else if (!strcmp(name, "sched_key_mode")) c->sched_key_mode = value;
+    else if (!strcmp(name, "fwd_waves")) {
+        if (value != 0 && value != 1 && value != 4) return fail(D2D_ERR_INVALID, "fwd_waves must be 0, 1 or 4, got %lld", (long long)value);
+        c->fwd_waves = value;
+    }
     else if (!strcmp(name, "pair_masks")) c->use_pair_masks = value != 0;
     else if (!strcmp(name, "opt_parallel")) c->opt_parallel = value != 0;
     else if (!strcmp(name, "txg_exhaustive")) c->txg_exhaustive = value != 0;
@@ -1277,6 +1322,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     } else if (!strcmp(name, "region_budget_mb")) {
         if (value < 1 || value > (64ll << 10)) return fail(D2D_ERR_INVALID, "region_budget_mb must lie in 1..65536, got %lld", (long long)value);
         c->region_budget_mb = value;
+        c->rl_pool_mb = std::min<long long>(256, value);
     }
     else return fail(D2D_ERR_INVALID, "d2d_set_option: unknown option '%s'", name);
     return D2D_OK;

@@ -396,12 +396,14 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     float on_c = 6.0f;    // MODE_HSIG: min of clamped pre-activations (true_value = 6/6)
     float on_z = 3.0e38f; // MODE_SIG: min of alpha*x (true_value = 1.0 handled at the end)
     bool nanflag = false;
+    float sv[K + 1];  // parametric coordinates of the interaction points on their walls (fp32, as on_objects computes them)
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         const float4 r0 = ldc4(a.refl, 2 * cand[i]);
         const float4 r1 = ldc4(a.refl, 2 * cand[i] + 1);
         float dx = px[i + 1] - r0.x, dy = py[i + 1] - r0.y;
         float s = div1_exact(r1.x * dx + r1.y * dy, r1.z);
+        sv[i] = s;
         if (MODE == MODE_HARD) {
             on_b = on_b && (s >= 0.0f) && (s <= 1.0f);
         } else if (MODE == MODE_HSIG) {
@@ -434,7 +436,6 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // Lanes for which the occlusion result can still change the output.  (is_valid = all(on_objects,
     // not intersects, loss < tol): the three terms commute, so the cheap-to-refute occlusion comes before the loss.)
     const bool live = !on_zero || bad;
-    if (STATS) st.c[2] += 1;
     D2D_WORK(1);
 
     // ---- intersects_with_objects, geometry.py:856-906 / 623-639 / 82-173 -------------------
@@ -449,6 +450,68 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     float hit_z = -3.0e38f; // MODE_SIG: max over tests of min(z1..z4); "no test yet" = false_value handled below
     bool any_test = false;
     bool active = live;     // lanes still undecided
+    // ---- per-lane look-up in the occlusion masks --------------------------------------------------------------------
+    // The first-segment shadow masks and the wall-to-wall masks say, bin by bin, where a segment is CERTAINLY reported
+    // as intersecting some object by the exact path (hard: hit; approx: exactly saturated) -- for every point within
+    // dperp of the bin.  The tile culling consults them with the ranges a whole patch can reach; here each lane consults
+    // them with the point it has actually computed (its fp32 parametric coordinate +- the rounding of that coordinate's
+    // own evaluation, both neighbours when the pad straddles a bin boundary).  A lane they settle is occluded exactly as
+    // if the wall loop had found its occluder; when they settle every lane, the wall loop is not entered at all.
+    if (!GRAD && !TXG && K >= 1 && a.shadow != nullptr) {  // (TX grids: the masks belong to the other end of the path)
+        const float eps = 1.1920929e-07f;
+        bool occl = false;
+        float Ei[K + 1];   // magnitudes that entered point i (how far its fp32 value may sit off its wall's line: 128 eps Ei)
+        float padv[K + 1];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const float4 r0 = ldc4(a.refl, 2 * cand[i]);
+            const float4 r1 = ldc4(a.refl, 2 * cand[i] + 1);
+            const float4 fc = ldc4(a.flt, cand[i]);
+            const float ex = fabsf(px[i + 1] - px[i + 2]) + fabsf(r0.x - px[i + 2]) + fabsf(r0.x) + fabsf(imgx[i]);
+            const float ey = fabsf(py[i + 1] - py[i + 2]) + fabsf(r0.y - py[i + 2]) + fabsf(r0.y) + fabsf(imgy[i]);
+            Ei[i] = ex + ey;
+            padv[i] = __builtin_fmaf(__builtin_fmaf(fabsf(r1.y), ey, fabsf(r1.x) * ex), fc.y, 1e-4f);
+        }
+        {
+            const unsigned long long sh = cmem(a.shadow)[cand[0]];  // wave-uniform
+            if (sh != 0ull) {
+                const float fa_ = (sv[0] - padv[0] - a.shadow_lo) * a.shadow_inv, fb_ = (sv[0] + padv[0] - a.shadow_lo) * a.shadow_inv;
+                const bool ok = fa_ >= 0.0f && fb_ < 64.0f && 256.0f * eps * Ei[0] <= a.shadow_dperp;
+                const int ka = ok ? (int)fa_ : 0, kb = ok ? (int)fb_ : 0;
+                occl = ok && (kb - ka <= 1) && ((sh >> ka) & 1ull) && ((sh >> kb) & 1ull);
+            }
+        }
+        if (K >= 2 && a.pair != nullptr) {
+#pragma unroll
+            for (int i = 0; i + 1 < K; ++i) {
+                // in path order the earlier point is P3 (rows of 8 bits), the later P4 (geometry.py:881-904)
+                const unsigned long long m = cmem(a.pair)[(size_t)cand[i] * a.N + cand[i + 1]];  // wave-uniform
+                if (m != 0ull) {
+                    const float k8 = 0.125f * a.shadow_inv;
+                    const float ea_ = (sv[i] - padv[i] - a.shadow_lo) * k8, eb_ = (sv[i] + padv[i] - a.shadow_lo) * k8;
+                    const float la_ = (sv[i + 1] - padv[i + 1] - a.shadow_lo) * k8, lb_ = (sv[i + 1] + padv[i + 1] - a.shadow_lo) * k8;
+                    const bool ok = ea_ >= 0.0f && eb_ < 8.0f && la_ >= 0.0f && lb_ < 8.0f && 512.0f * eps * Ei[i] <= a.pair_dperp &&
+                                    512.0f * eps * Ei[i + 1] <= a.pair_dperp;
+                    const int ea = ok ? (int)ea_ : 0, eb = ok ? (int)eb_ : 0, la = ok ? (int)la_ : 0, lb = ok ? (int)lb_ : 0;
+                    const bool all4 = ((m >> (ea + 8 * la)) & 1ull) && ((m >> (eb + 8 * la)) & 1ull) && ((m >> (ea + 8 * lb)) & 1ull) &&
+                                      ((m >> (eb + 8 * lb)) & 1ull);
+                    occl = occl || (ok && all4 && (eb - ea <= 1) && (lb - la <= 1));
+                }
+            }
+        }
+        if (wave_any(occl)) {
+            if (MODE == MODE_HARD) hit_b = hit_b || occl;
+            else if (MODE == MODE_HSIG) hit_c = occl ? 6.0f : hit_c;
+            else {
+                hit_z = occl ? 1.0e30f : hit_z;
+                any_test = true;
+            }
+            active = active && (!occl || bad);
+            D2D_WORK(2);
+            if (!wave_any(active)) return;  // every lane occluded (or off its walls): valid == 0 whatever the loss is
+        }
+    }
+    if (STATS) st.c[2] += 1;  // candidates that enter the wall loop
     // The wall that finished off the previous candidate of this wave is tried first ("shadow cache"): or / max
     // do not depend on the order of the tests, and neighbouring candidates tend to share their occluder.
     // (the next wall's data are fetched while this one is tested: a lone wave would otherwise sit out one scalar-load
@@ -1591,15 +1654,11 @@ constexpr int TILE_H = 8;
 // covered by the exhaustive power_vg_kernel (d2d_params.strict_nan).
 // LISTED: the orders >= 2 come from the region candidate lists (a.rl); a patch that cannot use them is queued for the
 // enumerating build of the same kernel (LISTED = false), which is launched right behind with a.fb_n set.
-template <int MODE, bool STATS, int MAXK, bool GRADK, bool LISTED>
-__device__ __forceinline__ void fwd_patch(const SweepArgs& a, const float4* tab, float* wl, const long b0, const bool from_queue) {
+template <int MODE, bool STATS, int MAXK, bool GRADK, bool LISTED, bool SPARE = false>
+__device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float* wl, const long b0_in, const bool from_queue) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
     const bool scene = GRADK && a.partial != nullptr;
-    if (scene) {
-        for (int i = lane; i < 4 * a.N; i += 64) wl[i] = 0.0f;
-        __syncthreads();
-    }
     float tbx_sum = 0.0f, tby_sum = 0.0f;  // scene VJP w.r.t. the fixed end point (wave sum)
     WaveStats st;
 #pragma unroll
@@ -1614,6 +1673,9 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, const float4* tab,
     // four quarters of first walls, swept by four single-wave workgroups that leave their non-zero contributions as
     // ordered lists in global memory; the quarter that finishes last adds them up in candidate order (bit for bit the
     // reference's sum) and writes the cell.  A list cannot overflow: it holds as many entries as the quarter has candidates.
+    const long n_items = (long)tiles_x * ((a.m + TILE_H - 1) / TILE_H) + (long)(HEAVY_PARTS - 1) * a.n_heavy;
+    const bool exists = !SPARE || b0_in < n_items;  // (the last workgroup of a launch of several waves per workgroup may have spare waves)
+    const long b0 = exists ? b0_in : 0;
     const bool quarter = !STATS && !GRADK && MAXK == 2 && !from_queue && (b0 < (long)HEAVY_PARTS * a.n_heavy);  // wave-uniform
     const long tile0 = quarter ? (b0 / HEAVY_PARTS) : (b0 - (long)(HEAVY_PARTS - 1) * a.n_heavy);
     const int part = quarter ? (int)(b0 % HEAVY_PARTS) : 0;
@@ -1631,6 +1693,11 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, const float4* tab,
     const int crow = row < a.m ? row : a.m - 1;
     const long idx = (long)crow * a.n + ccol;
     const float rxx = a.X[idx], rxy = a.Y[idx];
+    if (scene) {
+        for (int i = lane; i < 4 * a.N; i += 64) wl[i] = 0.0f;
+        __syncthreads();
+    }
+    if (!exists) return;
     const bool lane_bad = !(fabsf(rxx) < 1e18f) || !(fabsf(rxy) < 1e18f) || !(fabsf(a.txx) < 1e18f) ||
                           !(fabsf(a.txy) < 1e18f);
     if (LISTED) {
@@ -1787,25 +1854,33 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, const float4* tab,
     }
 }
 
-template <int MODE, bool STATS, int MAXK, bool GRADK = false, bool LISTED = false>
-__global__ void __launch_bounds__(64, D2D_FWD_WAVES) power_fwd_kernel(SweepArgs a) {
+// WPB: waves (= patches) per workgroup.  1: the register allocation that serves small scenes best; 4: the waves share
+// the staged tables, which is what keeps big scenes (a 13 KB table at 200 walls) from running out of LDS at 3 waves per SIMD.
+template <int MODE, bool STATS, int MAXK, bool GRADK = false, bool LISTED = false, int WPB = 1>
+__global__ void __launch_bounds__(64 * WPB, WPB == 1 ? D2D_FWD_WAVES : 1) power_fwd_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index), staged once per wave
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
-    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = ldc4(a.refl, i);
-    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = ldc4(a.flt, i);
     float* wl = reinterpret_cast<float*>(tab + 3 * a.N);
-    __syncthreads();
     if (!LISTED && a.fb_n != nullptr) {
         // the patches the LISTED launch in front of this one left behind (usually none)
         const int n = *a.fb_n;
+        if (n > 0) {
+            for (int i = lane; i < 2 * a.N; i += 64) tab[i] = ldc4(a.refl, i);
+            for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = ldc4(a.flt, i);
+            __syncthreads();
+        }
         for (int i = blockIdx.x; i < n; i += gridDim.x) {
             fwd_patch<MODE, STATS, MAXK, GRADK, false>(a, tab, wl, (long)a.fb_list[i], true);
             __syncthreads();
         }
         return;
     }
-    fwd_patch<MODE, STATS, MAXK, GRADK, LISTED>(a, tab, wl, (long)blockIdx.x, false);
+    // one patch per wave; the waves of a workgroup (WPB) stage the tables together
+    for (int i = threadIdx.x; i < 2 * a.N; i += 64 * WPB) tab[i] = ldc4(a.refl, i);
+    for (int i = threadIdx.x; i < a.N; i += 64 * WPB) tab[2 * a.N + i] = ldc4(a.flt, i);
+    __syncthreads();
+    fwd_patch<MODE, STATS, MAXK, GRADK, LISTED, (WPB > 1)>(a, tab, wl, WPB == 1 ? (long)blockIdx.x : (long)blockIdx.x * WPB + (threadIdx.x >> 6), false);
 }
 
 // Forward sweep with every 8 x 8 patch shared by W waves (one workgroup).  Patches differ a lot in cost and the dearest

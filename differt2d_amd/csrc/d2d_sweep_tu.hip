@@ -84,11 +84,17 @@ hipError_t launch_vg_m<TU_MODE>(bool txg, bool grad, dim3 grid, size_t lds, hipS
 template <int MODE> hipError_t launch_fwd_listed_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <>
 hipError_t launch_fwd_listed_m<TU_MODE>(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
-    const dim3 block(64);
+    const bool wide = grid.y == 4;  // (grid.y carries the waves per workgroup: 1 or 4)
+    const dim3 block(wide ? 256 : 64);
+    grid.y = 1;
     if (stats) {
         if (max_order <= 2) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, true, 2, false, true>), grid, block, lds, s, a);
         else if (max_order == 3) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, true, 3, false, true>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, true, 4, false, true>), grid, block, lds, s, a);
+    } else if (wide) {
+        if (max_order <= 2) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 2, false, true, 4>), grid, block, lds, s, a);
+        else if (max_order == 3) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 3, false, true, 4>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 4, false, true, 4>), grid, block, lds, s, a);
     } else {
         if (max_order <= 2) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 2, false, true>), grid, block, lds, s, a);
         else if (max_order == 3) hipLaunchKernelGGL((power_fwd_kernel<TU_MODE, false, 3, false, true>), grid, block, lds, s, a);

@@ -22,6 +22,7 @@ ap.add_argument("--approx", type=int, default=0)
 ap.add_argument("--function", default="hard_sigmoid")
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--grad", type=int, default=0)
+ap.add_argument("--orders", default=None, help="min,max")
 ap.add_argument("settings", nargs="*", default=["-"])
 args = ap.parse_args()
 
@@ -37,7 +38,8 @@ for setting in args.settings:
             for kv in setting.split(","):
                 k, v = kv.split("=")
                 ctx.set_option(k, int(v))
-        p = make_params(max_order=max_order, approx=bool(args.approx), function=args.function)
+        lo, hi = (int(x) for x in args.orders.split(",")) if args.orders else (0, max_order)
+        p = make_params(min_order=lo, max_order=hi, approx=bool(args.approx), function=args.function)
         launch = (lambda: ctx.launch_vg(p, tx, scene_vjp=True)) if args.grad else (lambda: ctx.launch(p, tx))
         for _ in range(3):
             launch()
