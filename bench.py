@@ -345,6 +345,7 @@ def main():
         ctx.launch(params, tx)
         final_map = ctx.get_map()  # rank 0's shard of the timed configuration (N = 1: the whole map)
         stats = ctx.launch_stats(params, tx)  # instrumented build, outside the timed region (deterministic counts)
+        list_stats = ctx.debug_region_stats()  # the region candidate lists of that launch (none for orders < 2)
         flop_ref, flop_cull = executed_flop(stats, approx)
         flop_unpruned = unpruned_flop_per_rx(n_walls, 0, max_order, approx) * cells_local
         per_s = 1.0 / (kernel_ms * 1e-3) / 1e12
@@ -368,7 +369,8 @@ def main():
                             f"unit square ({Xl.shape[0]}x{Xl.shape[1]} per GPU), orders 0..{max_order} (C={C} candidates per "
                             f"cell), {timed_mode} validity, received_power; BASELINE.json {wl_cfg}",
                 "setup": "scene and grid resident in HBM; 1 untimed launch (buffer allocation, scene-only masks) before the warmup "
-                         "steps; every timed step sweeps the same transmitter (see moving_tx for a different one every step)",
+                         "steps; every timed step sweeps the same transmitter (see moving_tx for a different one every step) and "
+                         "rebuilds everything that depends on it: shadow masks, region candidate lists, patch schedule",
                 "sharding": f"{world} rank(s), 8-row blocks round-robin"
                             + (f"; 1 RCCL {'gather to rank 0 (ncclSend/ncclRecv)' if args.gather == 'root' else 'all-gather'} of the "
                                f"value map per step, overlapped with the next step's sweep" if gather else ""),
@@ -390,7 +392,10 @@ def main():
                 "traffic": None,
                 "kernel": "d2d::power_fwd_split_kernel" if small else "d2d::power_fwd_kernel",
                 "kernel_ms": kernel_ms,
-                "launch_sequence_ms": sequence_ms,  # + shadow masks, patch schedule (4 small kernels, 2 memsets)
+                # + shadow masks, region candidate lists (region_list_kernel, region_refine_kernel), patch schedule, the
+                # (normally empty) queue of patches left to the enumerating kernel: 7 small kernels, 2 memsets
+                "launch_sequence_ms": sequence_ms,
+                "region_lists": list_stats,
                 "algorithmic_flop_per_launch": flop_ref + flop_cull,
                 "reference_work_flop_per_launch": flop_ref,
                 "culling_flop_per_launch": flop_cull,

@@ -336,6 +336,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         st.c[0] += 1;
         st.c[6] += K;
     }
+    float sv[K + 1];  // parametric coordinates of the interaction points on their walls (fp32, as on_objects computes them)
     // ---- backward scan of the image method, geometry.py:1093-1110 -------------------------
     {
         float ptx = rxx, pty = rxy;
@@ -359,6 +360,24 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             // jnp.where(un == 0, 0, vn*u/un): reverse mode sends a zero cotangent through the untaken
             // division by zero -> 0/0 = NaN (geometry.py:1105)
             if (GRAD) znan = znan || z;
+            if (!GRAD) {
+                // This wall's parametric coordinate (on_objects, geometry.py:589-621) right away: a candidate whose point
+                // is exactly off this wall in every lane is invalid whatever its other walls say, and most candidates
+                // that reach this function die so -- the remaining steps of the scan are then never computed.  (The
+                // value+grad build must see every interaction point: its NaN artefacts depend on all of them.)
+                const float4 r1 = ldc4(a.refl, 2 * cand[i] + 1);
+                const float dx = ptx - r0.x, dy = pty - r0.y;
+                const float sw = div1_exact(r1.x * dx + r1.y * dy, r1.z);
+                sv[i] = sw;
+                if (i > 0) {
+                    bool off;
+                    if (MODE == MODE_HARD) off = !((sw >= 0.0f) && (sw <= 1.0f));
+                    else if (MODE == MODE_HSIG) off = fminf(clampact(sw - 0.0f, a.alpha), clampact(1.0f - sw, a.alpha)) == 0.0f;
+                    else off = fminf(a.alpha * (sw - 0.0f), a.alpha * (1.0f - sw)) <= fmaxf(-89.0f, sig_zc_of(a.sig_l2f, acc));
+                    const bool pt_bad = lane_bad || !(fabsf(ptx) < 1e18f) || !(fabsf(pty) < 1e18f);
+                    if (!wave_any(!off || pt_bad)) return;
+                }
+            }
         }
     }
     if (GRAD && MODE != MODE_HARD && K > 0) {
@@ -396,14 +415,18 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     float on_c = 6.0f;    // MODE_HSIG: min of clamped pre-activations (true_value = 6/6)
     float on_z = 3.0e38f; // MODE_SIG: min of alpha*x (true_value = 1.0 handled at the end)
     bool nanflag = false;
-    float sv[K + 1];  // parametric coordinates of the interaction points on their walls (fp32, as on_objects computes them)
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        const float4 r0 = ldc4(a.refl, 2 * cand[i]);
-        const float4 r1 = ldc4(a.refl, 2 * cand[i] + 1);
-        float dx = px[i + 1] - r0.x, dy = py[i + 1] - r0.y;
-        float s = div1_exact(r1.x * dx + r1.y * dy, r1.z);
-        sv[i] = s;
+        float s;
+        if (GRAD) {
+            const float4 r0 = ldc4(a.refl, 2 * cand[i]);
+            const float4 r1 = ldc4(a.refl, 2 * cand[i] + 1);
+            float dx = px[i + 1] - r0.x, dy = py[i + 1] - r0.y;
+            s = div1_exact(r1.x * dx + r1.y * dy, r1.z);
+            sv[i] = s;
+        } else {
+            s = sv[i];  // (computed in the backward scan)
+        }
         if (MODE == MODE_HARD) {
             on_b = on_b && (s >= 0.0f) && (s <= 1.0f);
         } else if (MODE == MODE_HSIG) {
@@ -2061,6 +2084,8 @@ __global__ void __launch_bounds__(64) region_list_kernel(SweepArgs a, RegionLeve
         st.work = 0;
         float dummy = 0.0f;
         sweep_order_culled<K, MODE_HARD, false, GRAD, false, true>(a, tab, bx, by, 0.0f, 0.0f, false, dummy, st, nullptr, lo, hi, nullptr, &em);
+        // instrumented launches: the culling levels evaluated here count as executed work too (5 work units per level)
+        if (a.stats && lane == 0) atomicAdd(&a.stats[9], (unsigned long long)(st.work / 5));
     }
     if (lane == 0) lv.cnt[K][rs] = em.over ? -1 : em.n;
 }
@@ -2092,9 +2117,11 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
     em.over = !ok;
     if (ok) {
         int total = 0;
+        unsigned levels = 0;
         auto process = [&]() {
             __builtin_amdgcn_wave_barrier();
             for (int off = 0; off < total; off += 64) {
+                levels += K;
                 const bool have = off + lane < total;
                 const unsigned long long code = buf[have ? off + lane : off];
                 float Ix[K], Iy[K];
@@ -2116,6 +2143,7 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
             }
         }
         process();
+        if (a.stats && lane == 0) atomicAdd(&a.stats[9], (unsigned long long)levels);
     }
     if (lane == 0) {
         lv.cnt[K][region] = em.over ? -1 : em.n;
