@@ -181,7 +181,7 @@ struct d2d_ctx {
     bool have_grad = false;  // d_grad holds the per-cell gradient map of a sweep of the CURRENT grid (2 m n values)
     bool want_wave_cycles = false;
     long long split_max_tiles = 8192;   // launches up to this many patches share every patch between 4 waves
-    long long heavy_split = 64;        // bigger launches with a work history: this many of the dearest patches are cut in four
+    long long heavy_split = -1;        // bigger launches with a work history: this many of the dearest patches are cut in four (-1: by the launch's size)
     DevBuf<float> d_heavy_list;
     DevBuf<int> d_heavy_cnt, d_heavy_done;
     long long heavy_done_n = 0;
@@ -192,6 +192,9 @@ struct d2d_ctx {
     long long region_slices = 0;       // slices of first walls per enumerated region (0: chosen from the number of allowed walls)
     long long region_budget_mb = 8192; // device memory the list pool may grow to
     long long rl_pool_mb = 256;        // its current size: quadrupled (up to the budget) after a launch whose lists did not fit
+    hipStream_t aux_stream = nullptr;  // the patch schedule's sort runs here, beside the shadow masks and the region lists
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool use_aux = true;
     int* h_meta = nullptr;             // pinned: {patches left to the enumerating kernel, pool chunks handed out} of the last launch with lists
     hipEvent_t ev_meta = nullptr;
     bool meta_pending = false;
@@ -204,7 +207,8 @@ struct d2d_ctx {
     long long grid_version = 0;        // bumped by d2d_set_grid
     DevBuf<int> d_rl_next;             // [max_chunks]
     DevBuf<int> d_rl_idx;              // first / cnt arrays of both levels, all orders
-    DevBuf<int> d_rl_meta;             // [0] patches queued for the enumerating kernel, [1] pool head, [2 ..) leaf region flags, then the queue
+    DevBuf<int> d_rl_meta;             // the queue of patches left to the enumerating kernel
+    int* rl_meta_ptr = nullptr;        // (inside d_shadow) [0] queue length, [1] pool head, [2 ..) leaf region flags
     DevBuf<d2d::RegionLists> d_rl;     // the descriptor the sweep kernels read
     d2d::RegionLists rl_host;          // what d_rl holds
     d2d_host::RegionPlan rl_plan;      // of the last launch that built lists (rl_plan.on) -- d2d_debug_region_stats
@@ -496,6 +500,9 @@ int d2d_create(int device, d2d_ctx** out) {
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->evk0);
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->evk1);
     if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_meta, hipEventDisableTiming);
+    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void**>(&c->h_meta), 2 * sizeof(int), hipHostMallocDefault);
     if (e1 != hipSuccess) {
         delete c;
@@ -550,6 +557,9 @@ void d2d_destroy(d2d_ctx* c) {
     if (c->evk0) (void)hipEventDestroy(c->evk0);
     if (c->evk1) (void)hipEventDestroy(c->evk1);
     if (c->ev_meta) (void)hipEventDestroy(c->ev_meta);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->h_meta) (void)hipHostFree(c->h_meta);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -894,9 +904,13 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     bool prep_zeroed = false;
     const bool txg_culled = txg && !c->txg_exhaustive && !(grad_mode && p->strict_nan);  // TX grid: culled kernels
     if ((!txg || txg_culled) && c->N >= 2 && p->max_order >= 1) {
-        // [N] masks, then the {histogram, cursors} of the patch schedule's counting sort: one memset for both
-        if ((rc = c->d_shadow.ensure((size_t)c->N + d2d::SCHED_KEYS))) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_shadow.p, 0, ((size_t)c->N + d2d::SCHED_KEYS) * sizeof(unsigned long long), c->stream));
+        // [N] masks, then the {histogram, cursors} of the patch schedule's counting sort, then what the region lists need
+        // zeroed per launch ({queue length, pool head}, one flag per leaf region): one memset for all of it
+        const size_t rl_regions = (size_t)((tiles_x + c->region_size - 1) / c->region_size) * (size_t)((tiles_y + c->region_size - 1) / c->region_size);
+        const size_t zero_words = (size_t)c->N + d2d::SCHED_KEYS + (2 + rl_regions + 1) / 2;
+        if ((rc = c->d_shadow.ensure(zero_words))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_shadow.p, 0, zero_words * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));  // (the schedule's sort may start here, on the side stream)
         prep_zeroed = true;
         // window where a test is certainly "hit" (hard) / exactly saturated to 1 (approx): shrink [-tol, 1+tol] by widen
         const double in_lo = -(double)p->seg_tol + widen_in, in_hi = 1.0 + (double)p->seg_tol - widen_in;
@@ -969,10 +983,11 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             if ((rc = c->d_rl_pool.ensure((size_t)rp.max_chunks * d2d::RL_CHUNK))) return rc;
             if ((rc = c->d_rl_next.ensure((size_t)rp.max_chunks))) return rc;
             if ((rc = c->d_rl_idx.ensure(per_order * (size_t)orders))) return rc;
-            // meta: [0] queue length, [1] pool head, [2 ..) leaf region flags (all zeroed per launch), then the queue
-            if ((rc = c->d_rl_meta.ensure(2 + (size_t)rp.leaf.regions + (size_t)tiles))) return rc;
+            // meta (zeroed with the shadow masks above): [0] queue length, [1] pool head, [2 ..) leaf region flags
+            int* const meta = reinterpret_cast<int*>(c->d_shadow.p + c->N + d2d::SCHED_KEYS);
+            c->rl_meta_ptr = meta;
+            if ((rc = c->d_rl_meta.ensure((size_t)tiles))) return rc;  // the queue of patches left to the enumerating kernel
             if ((rc = c->d_rl.ensure(1))) return rc;
-            HIP_TRY(hipMemsetAsync(c->d_rl_meta.p, 0, (2 + (size_t)rp.leaf.regions) * sizeof(int), c->stream));
             {
                 // the regions' bounding boxes depend on the grid only
                 const long long key[4] = {c->grid_version, rp.leaf.R, rp.top.R, (long long)c->m * 0x100000000ll + c->n};
@@ -1011,12 +1026,12 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             }
             rl.lp.pool = c->d_rl_pool.p;
             rl.lp.next = c->d_rl_next.p;
-            rl.lp.head = c->d_rl_meta.p + 1;
+            rl.lp.head = meta + 1;
             rl.lp.n_static = (int)rp.n_static;
             rl.lp.max_chunks = (int)rp.max_chunks;
-            rl.flag = c->d_rl_meta.p + 2;
-            a.fb_n = c->d_rl_meta.p;
-            a.fb_list = c->d_rl_meta.p + 2 + rp.leaf.regions;
+            rl.flag = meta + 2;
+            a.fb_n = meta;
+            a.fb_list = c->d_rl_meta.p;
             if (!c->rl_host_valid || std::memcmp(&rl, &c->rl_host, sizeof rl) != 0) {
                 c->rl_host = rl;  // (the copy reads rl_host: it stays valid after this call returns)
                 c->rl_host_valid = true;
@@ -1059,12 +1074,21 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         if (!from_history && !from_lists)
             hipLaunchKernelGGL(d2d::patch_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, a, c->d_sched_key.p);
         {
+            // keys from the work history depend on nothing this launch has built: the sort then runs on the side stream,
+            // beside the shadow masks and the region lists, behind the memset of its counters
+            const bool side = from_history && prep_zeroed && c->use_aux && c->aux_stream != nullptr;
+            hipStream_t ss = side ? c->aux_stream : c->stream;
+            if (side) HIP_TRY(hipStreamWaitEvent(ss, c->ev_fork, 0));
             const unsigned sort_blocks = (unsigned)((tiles + 256 * d2d::SCHED_PER_THREAD - 1) / (256 * d2d::SCHED_PER_THREAD));
-            hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p,
+            hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, ss, c->d_sched_key.p,
                                from_history ? c->d_cost.p : (const unsigned*)nullptr, hist, (long)tiles,
                                from_lists ? a.rl : (const d2d::RegionLists*)nullptr, tiles_x, c->rl_plan.k_lo, p->max_order);
-            hipLaunchKernelGGL(d2d::patch_order_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, c->d_sched_key.p, hist,
+            hipLaunchKernelGGL(d2d::patch_order_kernel, dim3(sort_blocks), dim3(256), 0, ss, c->d_sched_key.p, hist,
                                hist + d2d::SCHED_KEYS, c->d_sched.p, (long)tiles);
+            if (side) {
+                HIP_TRY(hipEventRecord(c->ev_join, ss));
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            }
         }
         HIP_TRY(hipGetLastError());
         a.sched = c->d_sched.p;
@@ -1131,7 +1155,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
                 HIP_TRY(d2d::launch_fwd_grad(mode, false, p->max_order, dim3((unsigned)std::min<long long>(tiles, std::max<long long>(256, c->fb_hint))),
                                              lds2, c->stream, af));
                 if (!c->meta_pending && c->h_meta && (c->rl_launches <= 3 || c->rl_launches % 16 == 0)) {
-                    HIP_TRY(hipMemcpyAsync(c->h_meta, c->d_rl_meta.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(hipMemcpyAsync(c->h_meta, c->rl_meta_ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(hipEventRecord(c->ev_meta, c->stream));
                     c->meta_pending = true;
                 }
@@ -1166,9 +1190,17 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     const bool split = p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= d2d_host::LDS_LIMIT && tiles <= c->split_max_tiles;
     // the dearest patches of a bigger launch are cut in four (see power_fwd_kernel); they are only known with a work history
     dim3 grid_fwd = grid_patches;
-    if (!split && !d_stats && p->max_order == 2 && c->cw.size() >= 2 && a.sched == c->d_sched.p && sched_from_history && c->heavy_split > 0) {
+    if (!split && !d_stats && p->max_order == 2 && c->cw.size() >= 2 && a.sched == c->d_sched.p && sched_from_history && c->heavy_split != 0) {
         const long long P = d2d::HEAVY_PARTS;
-        const d2d_host::HeavyPlan hp = d2d_host::heavy_plan(tiles, (long long)c->cw.size(), c->heavy_split, P);
+        // -1 (default): launches that are only a few patch latencies long (fewer than 4 patches per wave slot of the chip)
+        // are bound by their dearest patches: one patch in 93 is cut there (measured best at 1024^2), else 64 patches
+        long long hs = c->heavy_split;
+        if (hs < 0) {
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            hs = (tiles < 4ll * cus * 4 * 6) ? std::max<long long>(64, tiles / 93) : 64;
+        }
+        const d2d_host::HeavyPlan hp = d2d_host::heavy_plan(tiles, (long long)c->cw.size(), hs, P);
         const long long H = hp.H, cap = hp.cap;
         if (H > 0) {
             if ((rc = c->d_heavy_list.ensure((size_t)hp.list_floats))) return rc;
@@ -1203,7 +1235,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         if (split) HIP_TRY(d2d::launch_fwd_split(mode, false, d_stats != nullptr, p->max_order, gq, split_lds, c->stream, af));
         else HIP_TRY(d2d::launch_fwd(mode, false, d_stats != nullptr, p->max_order, gq, tab_lds, c->stream, af));
         if (!c->meta_pending && c->h_meta && (c->rl_launches <= 3 || c->rl_launches % 16 == 0)) {
-            HIP_TRY(hipMemcpyAsync(c->h_meta, c->d_rl_meta.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->h_meta, c->rl_meta_ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipEventRecord(c->ev_meta, c->stream));
             c->meta_pending = true;
         }
@@ -1302,6 +1334,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "time_kernel")) c->time_kernel = value != 0;
     else if (!strcmp(name, "cost_history")) c->use_cost_history = value != 0;
     else if (!strcmp(name, "sched_key_mode")) c->sched_key_mode = value;
+    else if (!strcmp(name, "side_stream")) c->use_aux = value != 0;
     else if (!strcmp(name, "fwd_waves")) {
         if (value != 0 && value != 1 && value != 4) return fail(D2D_ERR_INVALID, "fwd_waves must be 0, 1 or 4, got %lld", (long long)value);
         c->fwd_waves = value;
@@ -1364,7 +1397,7 @@ int d2d_debug_region_stats(d2d_ctx* c, int64_t* out) {
     if (!c->rl_plan.on) return D2D_OK;
     const d2d_host::RegionPlan& rp = c->rl_plan;
     std::vector<int> meta(2 + (size_t)rp.leaf.regions);
-    HIP_TRY(hipMemcpyAsync(meta.data(), c->d_rl_meta.p, meta.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(meta.data(), c->rl_meta_ptr, meta.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     const int orders = c->rl_max_order - rp.k_lo + 1;
     const size_t per_order = (size_t)rp.leaf.slots + (size_t)rp.top.slots;
     std::vector<int> idx(per_order * (size_t)orders);
