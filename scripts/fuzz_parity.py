@@ -74,6 +74,12 @@ def main():
             # every launch shape: patches shared between 4 waves or one wave each, identity or dearest-first order
             ctx.set_option("split_max_tiles", 8192 if case % 2 == 0 else 0)
             ctx.set_option("sched_min_tiles", 1 if case % 4 < 2 else 1 << 40)
+            # region candidate lists: on (leaf regions of 4, 2 or 1 patches a side) or off (every patch enumerates)
+            ctx.set_option("region_lists", 0 if case % 7 == 6 else 1)
+            ctx.set_option("region_size", (4, 2, 1)[case % 3])
+            ctx.set_option("region_size_top", (16, 4, 3)[(case // 3) % 3])
+            if case % 200 == 199:
+                print(f"  .. {case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
             role_tx = case % 3 == 2  # every third case sweeps a TX grid (the cells are transmitters, `tx` the receiver)
             got = ctx.power_map(tx, X, Y, grid_role=L.GRID_TX if role_tx else L.GRID_RX, **kw)
             want = CO.power_map(walls, tx, X, Y, allowed=allowed, prune=True, grid_role="tx" if role_tx else "rx", **kw)
