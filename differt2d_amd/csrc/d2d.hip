@@ -171,6 +171,7 @@ struct d2d_ctx {
     bool txg_exhaustive = false;        // TX-grid value sweeps with the exhaustive kernel (A/B and tests)
     long long sched_min_tiles = 2048;   // launches with fewer patches keep the identity schedule
     float grid_absmax = 0.0f;   // max |coordinate| of the grid (host scan at d2d_set_grid)
+    bool grid_all_finite = false;  // every cell coordinate is below 1e18 in magnitude (what the kernels call comfortably finite)
     float scene_absmax = 0.0f;  // max |coordinate| of the objects
     // value+grad
     DevBuf<float> d_grad, d_cot, d_partial;
@@ -668,8 +669,10 @@ int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t 
     HIP_TRY(hipMemsetAsync(c->d_out.p, 0, cells * sizeof(float), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->grid_absmax = 0.0f;
+    c->grid_all_finite = true;
     for (size_t i = 0; i < cells; ++i) {
         const float ax = std::fabs(X[i]), ay = std::fabs(Y[i]);
+        c->grid_all_finite = c->grid_all_finite && (ax < 1e18f) && (ay < 1e18f);
         if (ax > c->grid_absmax) c->grid_absmax = ax;  // NaN compares false: such cells are handled by the kernel
         if (ay > c->grid_absmax) c->grid_absmax = ay;
     }
@@ -907,7 +910,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         // [N] masks, then the {histogram, cursors} of the patch schedule's counting sort, then what the region lists need
         // zeroed per launch ({queue length, pool head}, one flag per leaf region): one memset for all of it
         const size_t rl_regions = (size_t)((tiles_x + c->region_size - 1) / c->region_size) * (size_t)((tiles_y + c->region_size - 1) / c->region_size);
-        const size_t zero_words = (size_t)c->N + d2d::SCHED_KEYS + (2 + rl_regions + 1) / 2;
+        // (a multiple of 256 bytes: the runtime fills odd tails with a second kernel)
+        const size_t zero_words = ((size_t)c->N + d2d::SCHED_KEYS + (2 + rl_regions + 1) / 2 + 31) & ~(size_t)31;
         if ((rc = c->d_shadow.ensure(zero_words))) return rc;
         HIP_TRY(hipMemsetAsync(c->d_shadow.p, 0, zero_words * sizeof(unsigned long long), c->stream));
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));  // (the schedule's sort may start here, on the side stream)
@@ -963,6 +967,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     a.rl = nullptr;
     a.fb_n = nullptr;
     a.fb_list = nullptr;
+    bool queue_impossible = false;
     if (!txg && c->use_region_lists && p->max_order >= 2 && c->cw.size() >= 2 && c->N <= 4095 && !(grad_mode && p->strict_nan)) {
         // how the previous launch's lists fared (read back without waiting: a launch or two late is early enough)
         if (c->meta_pending && hipEventQuery(c->ev_meta) == hipSuccess) {
@@ -1050,6 +1055,16 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             c->rl_launches = (c->rl_meta_static == rp.n_static && c->rl_meta_chunks == rp.max_chunks) ? c->rl_launches + 1 : 1;
             c->rl_meta_static = rp.n_static;
             c->rl_meta_chunks = rp.max_chunks;
+            {
+                // Can a patch be left to the enumerating kernel at all?  Only a cell or end point that is not comfortably
+                // finite or a list that does not fit can do that; if even "every candidate survives everywhere" fits the
+                // pool, the queue stays empty and the launch that would walk it is not made.
+                double worst = 0.0;  // entries of all lists of one region
+                for (int k = rp.k_lo; k <= p->max_order; ++k) worst += (double)c->cw.size() * std::pow((double)c->cw.size() - 1.0, k - 1);
+                const double worst_chunks = worst * (double)(rp.leaf.regions + rp.top.regions) / d2d::RL_CHUNK + 2.0 * (double)rp.n_static;
+                queue_impossible = c->grid_all_finite && std::fabs(tx[0]) < 1e18f && std::fabs(tx[1]) < 1e18f &&
+                                   worst_chunks < (double)rp.max_chunks;
+            }
         }
     }
     if (!a.rl) c->rl_plan.on = false;
@@ -1149,7 +1164,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
             a.cullq_off = (int)((size_t)(4 * c->N + 1) * sizeof(float4));
             HIP_TRY(d2d::launch_fwd_grad(mode, a.rl != nullptr, p->max_order, grid_patches, lds2, c->stream, a));
-            if (a.rl) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
+            if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
                 d2d::SweepArgs af = a;
                 af.rl = nullptr; af.sched = nullptr; af.n_heavy = 0;
                 HIP_TRY(d2d::launch_fwd_grad(mode, false, p->max_order, dim3((unsigned)std::min<long long>(tiles, std::max<long long>(256, c->fb_hint))),
@@ -1228,7 +1243,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         const dim3 g((grid_fwd.x + wpb - 1) / wpb, wpb);
         HIP_TRY(d2d::launch_fwd(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, g, tab_lds + (wpb - 1) * 512, c->stream, a));
     }
-    if (a.rl) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
+    if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
         d2d::SweepArgs af = a;
         af.rl = nullptr; af.sched = nullptr; af.n_heavy = 0;
         const dim3 gq((unsigned)std::min<long long>(tiles, std::max<long long>(256, c->fb_hint)));

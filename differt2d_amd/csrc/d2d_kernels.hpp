@@ -375,7 +375,10 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     else if (MODE == MODE_HSIG) off = fminf(clampact(sw - 0.0f, a.alpha), clampact(1.0f - sw, a.alpha)) == 0.0f;
                     else off = fminf(a.alpha * (sw - 0.0f), a.alpha * (1.0f - sw)) <= fmaxf(-89.0f, sig_zc_of(a.sig_l2f, acc));
                     const bool pt_bad = lane_bad || !(fabsf(ptx) < 1e18f) || !(fabsf(pty) < 1e18f);
-                    if (!wave_any(!off || pt_bad)) return;
+                    if (!wave_any(!off || pt_bad)) {
+                        if (STATS && i == K - 1) st.c[15] += 1;  // died at the last wall (the first the scan reaches)
+                        return;
+                    }
                 }
             }
         }
@@ -2131,7 +2134,37 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
             total = 0;
             __builtin_amdgcn_wave_barrier();
         };
-        for (int ps = 0; ps < parent.S; ++ps) {
+        // Small lists (every slice of the parent fits one batch and all of them fit the buffer -- small scenes): the slices'
+        // lengths come with one vector load, their places in the buffer from a prefix sum, and the entries of four slices
+        // are in flight at a time instead of one dependent round trip per slice.
+        const int myn = (parent.S <= 64 && lane < parent.S) ? pcnt[lane] : 0;
+        int incl = myn;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const int sum_all = __builtin_amdgcn_readlane(incl, 63);
+        const bool small = parent.S <= 64 && !wave_any(myn > 64) && sum_all <= RL_GATHER;
+        if (small) {
+            const int excl = incl - myn;
+            for (int ps0 = 0; ps0 < parent.S; ps0 += 4) {
+                unsigned long long v[4];
+                int n4[4], o4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ps = ps0 + j < parent.S ? ps0 + j : parent.S - 1;
+                    n4[j] = ps0 + j < parent.S ? __builtin_amdgcn_readlane(myn, ps) : 0;
+                    o4[j] = __builtin_amdgcn_readlane(excl, ps);
+                    v[j] = lp.pool[(size_t)(parent.chunk0[K] + (int)(pslot0 + ps)) * RL_CHUNK + (lane < n4[j] ? lane : 0)];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (lane < n4[j]) buf[o4[j] + lane] = v[j];
+            }
+            total = sum_all;
+        }
+        for (int ps = 0; ps < (small ? 0 : parent.S); ++ps) {
             const int n = pcnt[ps];
             int chunk = parent.chunk0[K] + (int)(pslot0 + ps);
             for (int off = 0; off < n; off += 64) {
