@@ -550,11 +550,17 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     for (bool more = a.N > 0; more;) {
         const bool has_next = nxt < a.N;
         const float4 wn = ldc4(a.occl, has_next ? nxt : j);
+        // The K + 1 segments against this wall: first the divide-free filter of all of them (pure vector work, no branch:
+        // a segment that ends on this very wall is computed and masked, that is rarer than a branch is dear), then ONE
+        // wave-level decision whether any lane needs an exact test at all (9 % of the tests at cfg2), and only then the
+        // segments that do, one by one.
+        float fa_[K + 1], fb_[K + 1], fd_[K + 1];
+        unsigned wbits = 0u;  // bit i: this lane needs the exact test of segment i
 #pragma unroll
         for (int i = 0; i <= K; ++i) {
             const int ig0 = (i == 0) ? -1 : cand[i - 1];
             const int ig1 = (i == K) ? -1 : cand[i];
-            if (j == ig0 || j == ig1) continue;  // wave-uniform
+            const bool skip = (j == ig0 || j == ig1);  // wave-uniform: a segment ignores the walls it joins
             float Cx = w.x - px[i], Cy = w.y - py[i];
             float fa = by[i] * Cx - bx[i] * Cy;   // geometry.py:157
             float fb = w.z * Cy - w.w * Cx;       // geometry.py:158
@@ -565,12 +571,21 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             float ub = (fd < 0.0f) ? -fb : fb;
             float lo = a.flt_lo * D, hi = a.flt_hi * D;
             bool miss = (fd == 0.0f) || ((D >= 1e-30f) && ((ua < lo) || (ua > hi) || (ub < lo) || (ub > hi)));
-            if (MODE == MODE_SIG) any_test = true;
-            if (STATS) st.c[4] += 1;
-            const bool need = wave_any(active && (!miss || bad));
-            if (STATS && need) st.c[5] += 1;
-            D2D_WORK(need ? 3 : 1);
-            if (need) {
+            if (MODE == MODE_SIG && !skip) any_test = true;
+            if (STATS && !skip) st.c[4] += 1;
+            wbits |= (!skip && active && (!miss || bad)) ? (1u << i) : 0u;
+            fa_[i] = fa;
+            fb_[i] = fb;
+            fd_[i] = fd;
+        }
+        D2D_WORK(K + 1);
+        if (wave_any(wbits != 0u)) {
+#pragma unroll
+            for (int i = 0; i <= K; ++i) {
+                if (!wave_any((wbits >> i) & 1u)) continue;
+                if (STATS) st.c[5] += 1;
+                D2D_WORK(2);
+                const float fa = fa_[i], fb = fb_[i], fd = fd_[i];
                 // exact path, geometry.py:163-171
                 bool dz = (fd == 0.0f);
                 float dd = dz ? 1.0f : fd;
