@@ -175,8 +175,12 @@ __device__ __forceinline__ bool wave_any(bool p) { return __any(p); }
 // are 1 and the fixup is the identity, so the bare fma chain below returns the same correctly rounded
 // quotient; it costs 8 VALU ops instead of 11 and lets several numerators share one refined reciprocal.
 // d2d_selftest_div checks bit-equality with x / y on the GPU (tests/test_gpu_selftest.py).
+// Measured again in round 2 (scripts/ab_build.sh "nofastdiv:-DD2D_FAST_DIV=0"), now that the kernel is bound by its
+// compare -> lane-mask -> branch round trips rather than by vector issue: the wave-uniform range check and branch in front
+// of the bare chain cost more than the three instructions it saves -- the generic expansion is faster (hard_sigmoid -5 %,
+// cfg4 -15 %, cfg2 hard +-0).  Off by default; the bare chain and its self-test stay for A/B.
 #ifndef D2D_FAST_DIV
-#define D2D_FAST_DIV 1
+#define D2D_FAST_DIV 0
 #endif
 __device__ __forceinline__ bool div_in_range(float x) {
     float ax = fabsf(x);
@@ -337,6 +341,20 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         st.c[6] += K;
     }
     float sv[K + 1];  // parametric coordinates of the interaction points on their walls (fp32, as on_objects computes them)
+    // What the later stages will want from memory is asked for now (scalar loads, wave-uniform): the masks of the candidate's
+    // first wall and wall pairs and the first wall of the occlusion loop.  A candidate is one dependent chain; a round trip
+    // that is in flight during the scan is a round trip the wave does not sit out later.
+    constexpr bool PRE = !GRAD && !TXG && K >= 1;
+    unsigned long long sh_pre = 0ull, pm_pre[K + 1];
+    constexpr bool HOIST = PRE && K <= 2;  // (orders >= 3: the extra live scalars cost more than the waits: cfg4 +5 %)
+    if (HOIST) {
+        if (a.shadow != nullptr) sh_pre = cmem(a.shadow)[cand[0]];
+#pragma unroll
+        for (int i = 0; i + 1 < K; ++i) pm_pre[i] = (a.pair != nullptr) ? cmem(a.pair)[(size_t)cand[i] * a.N + cand[i + 1]] : 0ull;
+    }
+    const int sh = (st.shadow >= 0 && st.shadow < a.N) ? st.shadow : -1;
+    int j = sh >= 0 ? sh : 0;
+    float4 w = ldc4(a.occl, a.N > 0 ? j : 0);
     // ---- backward scan of the image method, geometry.py:1093-1110 -------------------------
     {
         float ptx = rxx, pty = rxy;
@@ -499,19 +517,19 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             padv[i] = __builtin_fmaf(__builtin_fmaf(fabsf(r1.y), ey, fabsf(r1.x) * ex), fc.y, 1e-4f);
         }
         {
-            const unsigned long long sh = cmem(a.shadow)[cand[0]];  // wave-uniform
-            if (sh != 0ull) {
+            const unsigned long long shm = HOIST ? sh_pre : cmem(a.shadow)[cand[0]];  // wave-uniform (asked for at the top)
+            if (shm != 0ull) {
                 const float fa_ = (sv[0] - padv[0] - a.shadow_lo) * a.shadow_inv, fb_ = (sv[0] + padv[0] - a.shadow_lo) * a.shadow_inv;
                 const bool ok = fa_ >= 0.0f && fb_ < 64.0f && 256.0f * eps * Ei[0] <= a.shadow_dperp;
                 const int ka = ok ? (int)fa_ : 0, kb = ok ? (int)fb_ : 0;
-                occl = ok && (kb - ka <= 1) && ((sh >> ka) & 1ull) && ((sh >> kb) & 1ull);
+                occl = ok && (kb - ka <= 1) && ((shm >> ka) & 1ull) && ((shm >> kb) & 1ull);
             }
         }
         if (K >= 2 && a.pair != nullptr) {
 #pragma unroll
             for (int i = 0; i + 1 < K; ++i) {
                 // in path order the earlier point is P3 (rows of 8 bits), the later P4 (geometry.py:881-904)
-                const unsigned long long m = cmem(a.pair)[(size_t)cand[i] * a.N + cand[i + 1]];  // wave-uniform
+                const unsigned long long m = HOIST ? pm_pre[i] : cmem(a.pair)[(size_t)cand[i] * a.N + cand[i + 1]];  // wave-uniform
                 if (m != 0ull) {
                     const float k8 = 0.125f * a.shadow_inv;
                     const float ea_ = (sv[i] - padv[i] - a.shadow_lo) * k8, eb_ = (sv[i] + padv[i] - a.shadow_lo) * k8;
@@ -542,11 +560,8 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // do not depend on the order of the tests, and neighbouring candidates tend to share their occluder.
     // (the next wall's data are fetched while this one is tested: a lone wave would otherwise sit out one scalar-load
     // latency per wall)
-    const int sh = (st.shadow >= 0 && st.shadow < a.N) ? st.shadow : -1;
-    int j = sh >= 0 ? sh : 0;
     int nxt = sh >= 0 ? 0 : 1;
     if (nxt == sh) ++nxt;
-    float4 w = ldc4(a.occl, a.N > 0 ? j : 0);
     for (bool more = a.N > 0; more;) {
         const bool has_next = nxt < a.N;
         const float4 wn = ldc4(a.occl, has_next ? nxt : j);
