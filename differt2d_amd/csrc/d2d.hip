@@ -26,7 +26,7 @@ namespace d2d {
 template <int MODE> hipError_t launch_fwd_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <int MODE> hipError_t launch_fwd_grad_m(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <int MODE> hipError_t launch_fwd_split_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
-template <int MODE> hipError_t launch_txg_m(bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <int MODE> hipError_t launch_txg_m(bool listed, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <int MODE> hipError_t launch_vg_m(bool txg, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <int MODE> hipError_t launch_fwd_listed_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <int MODE> hipError_t launch_fwd_grad_listed_m(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
@@ -36,7 +36,7 @@ template <int MODE> hipError_t launch_fwd_split_listed_m(bool stats, int max_ord
     template <> hipError_t launch_fwd_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);           \
     template <> hipError_t launch_fwd_grad_m<M>(int, dim3, size_t, hipStream_t, const SweepArgs&);            \
     template <> hipError_t launch_fwd_split_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);     \
-    template <> hipError_t launch_txg_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);           \
+    template <> hipError_t launch_txg_m<M>(bool, bool, int, dim3, size_t, hipStream_t, const SweepArgs&);           \
     template <> hipError_t launch_vg_m<M>(bool, bool, dim3, size_t, hipStream_t, const SweepArgs&);              \
     template <> hipError_t launch_fwd_listed_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);       \
     template <> hipError_t launch_fwd_grad_listed_m<M>(int, dim3, size_t, hipStream_t, const SweepArgs&);        \
@@ -65,8 +65,8 @@ hipError_t launch_fwd_split(int mode, bool listed, bool stats, int max_order, di
     if (listed) { D2D_BY_MODE(launch_fwd_split_listed_m, stats, max_order, grid, lds, s, a) }
     D2D_BY_MODE(launch_fwd_split_m, stats, max_order, grid, lds, s, a)
 }
-hipError_t launch_txg(int mode, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
-    D2D_BY_MODE(launch_txg_m, grad, max_order, grid, lds, s, a)
+hipError_t launch_txg(int mode, bool listed, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    D2D_BY_MODE(launch_txg_m, listed, grad, max_order, grid, lds, s, a)
 }
 hipError_t launch_vg(int mode, bool txg, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
     D2D_BY_MODE(launch_vg_m, txg, grad, grid, lds, s, a)
@@ -968,7 +968,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     a.fb_n = nullptr;
     a.fb_list = nullptr;
     bool queue_impossible = false;
-    if (!txg && c->use_region_lists && p->max_order >= 2 && c->cw.size() >= 2 && c->N <= 4095 && !(grad_mode && p->strict_nan)) {
+    if ((!txg || txg_culled) && c->use_region_lists && p->max_order >= 2 && c->cw.size() >= 2 && c->N <= 4095 && !(grad_mode && p->strict_nan)) {
         // how the previous launch's lists fared (read back without waiting: a launch or two late is early enough)
         if (c->meta_pending && hipEventQuery(c->ev_meta) == hipSuccess) {
             c->meta_pending = false;
@@ -1046,8 +1046,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             al.fb_n = nullptr;
             al.cullq_off = (int)((size_t)(3 * c->N + 1) * sizeof(float4));
             for (int k = rp.k_lo; k <= p->max_order; ++k) {
-                HIP_TRY(d2d::launch_region_lists(k, grad_mode != 0, dim3((unsigned)rp.top.slots), lds_l, c->stream, al, top, rl.lp));
-                HIP_TRY(d2d::launch_region_refine(k, grad_mode != 0, dim3((unsigned)rp.leaf.regions), lds_r, c->stream, al, rl.leaf, top, rl.lp, rl.flag));
+                HIP_TRY(d2d::launch_region_lists(k, grad_mode != 0, txg, dim3((unsigned)rp.top.slots), lds_l, c->stream, al, top, rl.lp));
+                HIP_TRY(d2d::launch_region_refine(k, grad_mode != 0, txg, dim3((unsigned)rp.leaf.regions), lds_r, c->stream, al, rl.leaf, top, rl.lp, rl.flag));
             }
             a.rl = c->d_rl.p;
             c->rl_plan = rp;
@@ -1126,11 +1126,27 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             c->have_kernel_time = true;                          \
         }                                                        \
     } while (0)
+    // behind a LISTED launch: how the lists fared, read back without waiting (see above)
+    auto read_back_meta = [&]() -> int {
+        if (!c->meta_pending && c->h_meta && (c->rl_launches <= 3 || c->rl_launches % 16 == 0)) {
+            HIP_TRY(hipMemcpyAsync(c->h_meta, c->rl_meta_ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(c->ev_meta, c->stream));
+            c->meta_pending = true;
+        }
+        return D2D_OK;
+    };
+    const dim3 grid_queue((unsigned)std::min<long long>(tiles, std::max<long long>(256, c->fb_hint)));
     if (txg_culled && !grad_mode) {
         const size_t lds_t = (size_t)(3 * c->N + 1) * sizeof(float4);
         if (lds_t > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
         a.grad = nullptr; a.cot = nullptr; a.partial = nullptr;
-        HIP_TRY(d2d::launch_txg(mode, false, p->max_order, grid, lds_t, c->stream, a));
+        HIP_TRY(d2d::launch_txg(mode, a.rl != nullptr, false, p->max_order, grid, lds_t, c->stream, a));
+        if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none)
+            d2d::SweepArgs af = a;
+            af.rl = nullptr; af.sched = nullptr;
+            HIP_TRY(d2d::launch_txg(mode, false, false, p->max_order, grid_queue, lds_t, c->stream, af));
+            if ((rc = read_back_meta())) return rc;
+        }
         D2D_KERNEL_DONE();
         return D2D_OK;
     }
@@ -1179,7 +1195,13 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             // TX grid, culled value+grad sweep
             const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4);
             if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
-            HIP_TRY(d2d::launch_txg(mode, true, p->max_order, grid_patches, lds2, c->stream, a));
+            HIP_TRY(d2d::launch_txg(mode, a.rl != nullptr, true, p->max_order, grid_patches, lds2, c->stream, a));
+            if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none)
+                d2d::SweepArgs af = a;
+                af.rl = nullptr; af.sched = nullptr;
+                HIP_TRY(d2d::launch_txg(mode, false, true, p->max_order, grid_queue, lds2, c->stream, af));
+                if ((rc = read_back_meta())) return rc;
+            }
         } else {
             HIP_TRY(d2d::launch_vg(mode, txg, true, grid, lds, c->stream, a));
         }

@@ -1554,13 +1554,31 @@ __device__ __forceinline__ void first_wall_range(const SweepArgs& a, int part, i
 
 // One batch of a candidate list, lanes = candidates: decodes the lane's entry, builds its image chain and runs the full
 // tile-culling test against the box (bx, by).  Returns the ballot of the entries that cannot be dropped.
-template <int K, bool GRAD>
+// TXG (TX grids): the chain is the fixed end point's through the walls in REVERSE order (sweep_order_culled_txg), with the
+// wider bound of cull_candidate<K, true>; Ix / Iy are then that chain's images, of no use to the evaluation.
+template <int K, bool GRAD, bool TXG = false>
 __device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, const float4* tab, const float (&bx)[4], const float (&by)[4],
                                                          unsigned long long code, bool have, float (&Ix)[K], float (&Iy)[K], float on_lo,
                                                          float on_hi) {
     bool alive = have;
     WallC w[K];
     float ix = a.txx, iy = a.txy;
+    if constexpr (TXG) {
+#pragma unroll
+        for (int jx = 0; jx < K; ++jx) {
+            const int wd = (int)((code >> (12 * (K - 1 - jx))) & 0xfffull);
+            const float4 r0 = tab[2 * wd], r1 = tab[2 * wd + 1], fc = tab[2 * a.N + wd];
+            w[jx] = make_wallc(r0, r1, fc, wd);
+            image_of(r0, ix, iy, Ix[jx], Iy[jx]);
+            ix = Ix[jx];
+            iy = Iy[jx];
+        }
+        if (alive) {
+            const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[w[0].idx] : 0ull;
+            if (cull_candidate<K, true>(bx, by, w, Ix, Iy, a, sh0, on_lo, on_hi)) alive = false;
+        }
+        return __ballot(alive);
+    }
 #pragma unroll
     for (int d = 0; d < K; ++d) {
         const int wd = (int)((code >> (12 * d)) & 0xfffull);
@@ -1912,8 +1930,13 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
 
 // WPB: waves (= patches) per workgroup.  1: the register allocation that serves small scenes best; 4: the waves share
 // the staged tables, which is what keeps big scenes (a 13 KB table at 200 walls) from running out of LDS at 3 waves per SIMD.
+#ifdef D2D_NUM_SGPR  // A/B: cap the scalar registers (96 -> 7 waves per SIMD, 80 -> 8 by MI355X_MICROARCH.md's residency formula)
+#define D2D_SGPR_ATTR __attribute__((amdgpu_num_sgpr(D2D_NUM_SGPR)))
+#else
+#define D2D_SGPR_ATTR
+#endif
 template <int MODE, bool STATS, int MAXK, bool GRADK = false, bool LISTED = false, int WPB = 1>
-__global__ void __launch_bounds__(64 * WPB, WPB == 1 ? D2D_FWD_WAVES : 1) power_fwd_kernel(SweepArgs a) {
+__global__ void __launch_bounds__(64 * WPB, WPB == 1 ? D2D_FWD_WAVES : 1) D2D_SGPR_ATTR power_fwd_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index), staged once per wave
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
@@ -2090,7 +2113,7 @@ __device__ __forceinline__ bool region_box(const SweepArgs& a, const float4* __r
 // the survivors, in candidate order, to the slice's list.  What holds for the box holds for everything inside it, so
 // whoever only looks at the listed candidates skips nothing but exact zeros.  A list is marked "not listed" (count -1)
 // when the pool runs out or when a cell of the region is not comfortably finite.
-template <int K, bool GRAD>
+template <int K, bool GRAD, bool TXG = false>
 __global__ void __launch_bounds__(64) region_list_kernel(SweepArgs a, RegionLevel lv, ListPool lp) {
     const int lane = threadIdx.x & 63;
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, the culling queue
@@ -2116,7 +2139,8 @@ __global__ void __launch_bounds__(64) region_list_kernel(SweepArgs a, RegionLeve
         st.shadow = -1;
         st.work = 0;
         float dummy = 0.0f;
-        sweep_order_culled<K, MODE_HARD, false, GRAD, false, true>(a, tab, bx, by, 0.0f, 0.0f, false, dummy, st, nullptr, lo, hi, nullptr, &em);
+        if constexpr (TXG) sweep_order_culled_txg<K, MODE_HARD, GRAD, true>(a, tab, bx, by, 0.0f, 0.0f, false, dummy, st, nullptr, lo, hi, &em);
+        else sweep_order_culled<K, MODE_HARD, false, GRAD, false, true>(a, tab, bx, by, 0.0f, 0.0f, false, dummy, st, nullptr, lo, hi, nullptr, &em);
         // instrumented launches: the culling levels evaluated here count as executed work too (5 work units per level)
         if (a.stats && lane == 0) atomicAdd(&a.stats[9], (unsigned long long)(st.work / 5));
     }
@@ -2127,7 +2151,7 @@ __global__ void __launch_bounds__(64) region_list_kernel(SweepArgs a, RegionLeve
 // parent level's.  The wave gathers the parent region's lists (all slices, in order) through LDS into full batches and
 // keeps what the tile culling cannot drop for its own, smaller box.  `flag`: raised when the list is not listed.
 constexpr int RL_GATHER = 512;  // entries of the gather buffer (LDS)
-template <int K, bool GRAD>
+template <int K, bool GRAD, bool TXG = false>
 __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLevel lv, RegionLevel parent, ListPool lp, int* flag) {
     const int lane = threadIdx.x & 63;
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then the gather buffer
@@ -2158,7 +2182,7 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
                 const bool have = off + lane < total;
                 const unsigned long long code = buf[have ? off + lane : off];
                 float Ix[K], Iy[K];
-                const unsigned long long mask = cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi);
+                const unsigned long long mask = cull_batch<K, GRAD, TXG>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi);
                 emit_batch(em, code, have && ((mask >> lane) & 1ull), mask);
             }
             total = 0;
@@ -2219,25 +2243,31 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
 // the same geometric interaction points, and a path is its own reverse: the candidate (w_0 .. w_{K-1}) is culled as the
 // chain of F through (w_{K-1} .. w_0) towards the patch, with F's shadow masks on w_{K-1} (the segment w_{K-1} -> F).
 // Prefix = (w_0 .. w_{K-2}) wave-uniform, lanes = last wall, survivors in ascending order: the reference's order.
-template <int K, int MODE, bool GRAD = false>
+// EMIT (K >= 2; region_list_kernel): first-wall positions [p_lo, p_hi) only, the box is a region's, and the survivors are
+// appended to `emit` (in candidate order: prefix-major, last walls ascending) instead of being evaluated.
+template <int K, int MODE, bool GRAD = false, bool EMIT = false>
 __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                        const float (&by)[4], float cx, float cy, bool lane_bad, float& acc,
-                                                       WaveStats& st, GradCtx* g = nullptr) {
+                                                       WaveStats& st, GradCtx* g = nullptr, int p_lo = 0, int p_hi = 0x7fffffff,
+                                                       EmitSink* emit = nullptr) {
+    static_assert(!EMIT || K >= 2, "lists exist for orders >= 2");
     const int lane = threadIdx.x & 63;
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
     float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];  // images of the lane's cell (per lane)
     const int Nc = a.Nc;
     int pos[D2D_MAX_ORDER] = {0, 0, 0, 0};
     const int n_chunks = (Nc + 63) >> 6;
+    const int p_end = p_hi < Nc ? p_hi : Nc;
+    if (K >= 2) pos[0] = p_lo;
 #pragma unroll
     for (int d = 1; d < K - 1; ++d) pos[d] = (pos[d - 1] == 0) ? 1 : 0;
-    if (K - 1 > 0 && Nc < 2) return;
+    if (K - 1 > 0 && (Nc < 2 || p_lo >= p_end)) return;
     if (Nc < 1) return;
     while (true) {
 #pragma unroll
         for (int d = 0; d < K - 1; ++d) {
             cand[d] = cmem(a.cw)[pos[d]];
-            image_of(ldc4(a.refl, 2 * cand[d]), d == 0 ? cx : imgx[d > 0 ? d - 1 : 0], d == 0 ? cy : imgy[d > 0 ? d - 1 : 0], imgx[d], imgy[d]);
+            if (!EMIT) image_of(ldc4(a.refl, 2 * cand[d]), d == 0 ? cx : imgx[d > 0 ? d - 1 : 0], d == 0 ? cy : imgy[d > 0 ? d - 1 : 0], imgx[d], imgy[d]);
         }
         const int last_prefix_pos = (K == 1) ? -1 : pos[K >= 2 ? K - 2 : 0];
         bool prefix_dead = false;
@@ -2267,6 +2297,12 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
             }
             unsigned long long mask = __ballot(alive);
             D2D_WORK(5 * K);
+            if constexpr (EMIT) {
+                unsigned long long code = (unsigned long long)cmem(a.cw)[lp < Nc ? lp : 0] << (12 * (K - 1));
+#pragma unroll
+                for (int d = 0; d < K - 1; ++d) code |= (unsigned long long)cand[d] << (12 * d);
+                emit_batch(*emit, code, alive, mask);
+            } else
             while (mask) {
                 const int b = __builtin_ctzll(mask);
                 mask &= mask - 1;
@@ -2283,7 +2319,7 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
             if (carry) {
                 pos[d] += 1;
                 if (d > 0 && pos[d] == pos[d - 1]) pos[d] += 1;
-                if (pos[d] < Nc) {
+                if (pos[d] < (d == 0 ? p_end : Nc)) {
                     carry = false;
                     stop = d;
                 }
@@ -2296,28 +2332,65 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
     }
 }
 
+// Order K >= 2 of a TX-grid patch from its leaf region's candidate list (built by region_list_kernel / region_refine_kernel
+// <K, GRAD, TXG = true> with the reversed chain): 64 entries per batch, lanes = candidates, the full culling test against
+// the patch, survivors evaluated exactly in list order with the images of every lane's own cell.
+template <int K, int MODE, bool GRAD>
+__device__ __forceinline__ void sweep_order_listed_txg(const SweepArgs& a, const float4* tab, const float (&bx)[4], const float (&by)[4],
+                                                       float cx, float cy, bool lane_bad, float& acc, WaveStats& st, GradCtx* g, long region) {
+    static_assert(K >= 2, "lists exist for orders >= 2");
+    const int lane = threadIdx.x & 63;
+    const auto* rlc = cmem(a.rl);
+    const int n = cmem(rlc->leaf.cnt[K])[region];
+    int chunk = rlc->leaf.chunk0[K] + (int)region;
+    const auto* pool = cmem(rlc->lp.pool);
+    const auto* next = cmem(rlc->lp.next);
+    for (int off = 0; off < n; off += 64) {
+        const bool have = off + lane < n;
+        const unsigned long long code = pool[(size_t)chunk * RL_CHUNK + (off & (RL_CHUNK - 1)) + (have ? lane : 0)];
+        if ((off & (RL_CHUNK - 1)) == RL_CHUNK - 64 && off + 64 < n) chunk = next[chunk];
+        float Ix[K], Iy[K];
+        unsigned long long mask = cull_batch<K, GRAD, true>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi);
+        D2D_WORK(5 * K);
+        while (mask) {
+            const int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(code & 0xffffffffull), b);
+            const unsigned hi32 = (K >= 3) ? (unsigned)__builtin_amdgcn_readlane((int)(code >> 32), b) : 0u;
+            const unsigned long long cu = ((unsigned long long)hi32 << 32) | lo32;
+            int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+            float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];  // images of the lane's cell (per lane)
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+                ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
+                image_of(ldc4(a.refl, 2 * ce[d]), d == 0 ? cx : ex[d > 0 ? d - 1 : 0], d == 0 ? cy : ey[d > 0 ? d - 1 : 0], ex[d], ey[d]);
+            }
+            eval_candidate<K, MODE, false, GRAD, false, true>(a, ce, ex, ey, cx, cy, a.txx, a.txy, lane_bad, acc, st, g);
+        }
+    }
+}
+
 // GRADK: value + gradient (per cell w.r.t. the transmitter = the cell, scene.py:1617-1620; scene VJP w.r.t. the fixed
 // receiver and the walls) of the candidates the culling cannot drop.  The reference's autodiff NaN artefacts are
 // reproduced for those candidates only (the culling reasons about the reversed chain, whose poles are not the exact
 // chain's): d2d_params.strict_nan selects the exhaustive power_vg_kernel.
-template <int MODE, int MAXK, bool GRADK = false>
-__global__ void __launch_bounds__(64) power_fwd_txg_kernel(SweepArgs a) {
+// One TX-grid patch.  LISTED: the orders >= 2 come from the region candidate lists; a patch that cannot use them is queued
+// for the enumerating build (LISTED = false), launched right behind with a.fb_n set.
+template <int MODE, int MAXK, bool GRADK, bool LISTED>
+__device__ __forceinline__ void txg_patch(const SweepArgs& a, const float4* tab, float* wl, const long b0, const bool from_queue) {
     const int lane = threadIdx.x & 63;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
-    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
-    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = ldc4(a.refl, i);
-    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = ldc4(a.flt, i);
-    float* wl = reinterpret_cast<float*>(tab + 3 * a.N);
     const bool scene = GRADK && a.partial != nullptr;
-    if (scene)
+    if (scene) {
         for (int i = lane; i < 4 * a.N; i += 64) wl[i] = 0.0f;
-    __syncthreads();
+        __syncthreads();
+    }
     WaveStats st;
 #pragma unroll
     for (int i = 0; i < 16; ++i) st.c[i] = 0;
     st.shadow = -1;
     st.work = 0;
-    const long tile = a.sched ? (long)a.sched[blockIdx.x] : (long)blockIdx.x;
+    const long tile = from_queue ? b0 : (a.sched ? (long)a.sched[b0] : b0);
     const int tcol = (int)(tile % tiles_x), trow = (int)(tile / tiles_x);
     const int col = tcol * TILE_W + (lane & (TILE_W - 1));
     const int row = trow * TILE_H + (lane / TILE_W);
@@ -2327,6 +2400,14 @@ __global__ void __launch_bounds__(64) power_fwd_txg_kernel(SweepArgs a) {
     const long idx = (long)crow * a.n + ccol;
     const float cx = a.X[idx], cy = a.Y[idx];
     const bool lane_bad = !(fabsf(cx) < 1e18f) || !(fabsf(cy) < 1e18f) || !(fabsf(a.txx) < 1e18f) || !(fabsf(a.txy) < 1e18f);
+    const long region = LISTED ? region_of(a, tcol, trow) : 0;
+    if (LISTED) {
+        // not this kernel's patch: leave it to the enumerating kernel
+        if (cmem(cmem(a.rl)->flag)[region] != 0 || wave_any(lane_bad)) {
+            if (lane == 0) a.fb_list[atomicAdd(a.fb_n, 1)] = (int)tile;
+            return;
+        }
+    }
     float acc = 0.0f;  // scene.py:1593
     GradCtx g;
     g.grx = g.gry = g.tbx = g.tby = 0.0f;
@@ -2347,9 +2428,15 @@ __global__ void __launch_bounds__(64) power_fwd_txg_kernel(SweepArgs a) {
     const float by[4] = {y0, y0, y1, y1};
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, GRADK, true>(a, cx, cy, a.txx, a.txy, lane_bad, acc, st, &g);
     if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled_txg<1, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
-    if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled_txg<2, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
-    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled_txg<3, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
-    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_culled_txg<4, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
+    if constexpr (LISTED) {
+        if (a.min_order <= 2 && a.max_order >= 2) sweep_order_listed_txg<2, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g, region);
+        if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_listed_txg<3, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g, region);
+        if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_listed_txg<4, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g, region);
+    } else {
+        if (a.min_order <= 2 && a.max_order >= 2) sweep_order_culled_txg<2, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
+        if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_culled_txg<3, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
+        if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_culled_txg<4, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
+    }
     if (in_range) {
         if (a.out_mode == D2D_OUT_ADD) {
             a.out[idx] = a.out[idx] + acc;
@@ -2376,6 +2463,30 @@ __global__ void __launch_bounds__(64) power_fwd_txg_kernel(SweepArgs a) {
             dst[4 * a.N + 1] = sy;
         }
     }
+}
+
+template <int MODE, int MAXK, bool GRADK = false, bool LISTED = false>
+__global__ void __launch_bounds__(64) power_fwd_txg_kernel(SweepArgs a) {
+    const int lane = threadIdx.x & 63;
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
+    float* wl = reinterpret_cast<float*>(tab + 3 * a.N);
+    if (!LISTED && a.fb_n != nullptr) {
+        const int n = *a.fb_n;  // the patches the LISTED launch in front of this one left behind (usually none)
+        if (n > 0) {
+            for (int i = lane; i < 2 * a.N; i += 64) tab[i] = ldc4(a.refl, i);
+            for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = ldc4(a.flt, i);
+            __syncthreads();
+        }
+        for (int i = blockIdx.x; i < n; i += gridDim.x) {
+            txg_patch<MODE, MAXK, GRADK, false>(a, tab, wl, (long)a.fb_list[i], true);
+            __syncthreads();
+        }
+        return;
+    }
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = ldc4(a.refl, i);
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = ldc4(a.flt, i);
+    __syncthreads();
+    txg_patch<MODE, MAXK, GRADK, LISTED>(a, tab, wl, (long)blockIdx.x, false);
 }
 
 // Patch schedule.  The hardware starts workgroups in blockIdx order, and a dear patch that starts late is the tail of the

@@ -19,15 +19,15 @@ hipError_t launch_fwd_grad(int mode, bool listed, int max_order, dim3 grid, size
 constexpr int SPLIT_W = 4;
 hipError_t launch_fwd_split(int mode, bool listed, bool stats, int max_order, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a);
 // power_fwd_txg_kernel<MODE, MAXK, GRADK>: TX grids, culled
-hipError_t launch_txg(int mode, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a);
+hipError_t launch_txg(int mode, bool listed, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a);
 // power_vg_kernel<MODE, TXG, GRADK>: exhaustive sweeps (strict_nan value+grad; "txg_exhaustive" values)
 hipError_t launch_vg(int mode, bool txg, bool grad, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a);
 
 // region_list_kernel<K, GRAD>: candidate lists of order K (2..4) of level `lv` by enumeration; grid = regions x slices
-hipError_t launch_region_lists(int K, bool grad, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a, const RegionLevel& lv,
+hipError_t launch_region_lists(int K, bool grad, bool txg, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a, const RegionLevel& lv,
                                const ListPool& lp);
 // region_refine_kernel<K, GRAD>: the lists of level `lv` (one per region) from those of `parent`; grid = regions of `lv`
-hipError_t launch_region_refine(int K, bool grad, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a, const RegionLevel& lv,
+hipError_t launch_region_refine(int K, bool grad, bool txg, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a, const RegionLevel& lv,
                                 const RegionLevel& parent, const ListPool& lp, int* flag);
 
 }  // namespace d2d

@@ -55,11 +55,21 @@ hipError_t launch_fwd_split_m<TU_MODE>(bool stats, int max_order, dim3 grid, siz
     return hipGetLastError();
 }
 #elif D2D_TU_FAMILY == 3
-template <int MODE> hipError_t launch_txg_m(bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <int MODE> hipError_t launch_txg_m(bool listed, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <>
-hipError_t launch_txg_m<TU_MODE>(bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+hipError_t launch_txg_m<TU_MODE>(bool listed, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
     const dim3 block(64);
-    if (grad) {
+    if (listed) {
+        if (grad) {
+            if (max_order <= 2) hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 2, true, true>), grid, block, lds, s, a);
+            else if (max_order == 3) hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 3, true, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 4, true, true>), grid, block, lds, s, a);
+        } else {
+            if (max_order <= 2) hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 2, false, true>), grid, block, lds, s, a);
+            else if (max_order == 3) hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 3, false, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 4, false, true>), grid, block, lds, s, a);
+        }
+    } else if (grad) {
         if (max_order <= 2) hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 2, true>), grid, block, lds, s, a);
         else if (max_order == 3) hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 3, true>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((power_fwd_txg_kernel<TU_MODE, 4, true>), grid, block, lds, s, a);
@@ -130,32 +140,46 @@ hipError_t launch_fwd_split_listed_m<TU_MODE>(bool stats, int max_order, dim3 gr
 }
 #elif D2D_TU_FAMILY == 5
 // region_list_kernel / region_refine_kernel <K, GRAD>: independent of the validity mode (compiled once, -DD2D_TU_MODE=0)
-hipError_t launch_region_lists(int K, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a, const RegionLevel& lv,
+hipError_t launch_region_lists(int K, bool grad, bool txg, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a, const RegionLevel& lv,
                                const ListPool& lp) {
     const dim3 block(64);
-    if (grad) {
-        if (K == 2) hipLaunchKernelGGL((region_list_kernel<2, true>), grid, block, lds, s, a, lv, lp);
-        else if (K == 3) hipLaunchKernelGGL((region_list_kernel<3, true>), grid, block, lds, s, a, lv, lp);
-        else hipLaunchKernelGGL((region_list_kernel<4, true>), grid, block, lds, s, a, lv, lp);
+#define D2D_RL(KK, G, T) hipLaunchKernelGGL((region_list_kernel<KK, G, T>), grid, block, lds, s, a, lv, lp)
+#define D2D_RL_K(G, T)            \
+    do {                          \
+        if (K == 2) D2D_RL(2, G, T);      \
+        else if (K == 3) D2D_RL(3, G, T); \
+        else D2D_RL(4, G, T);             \
+    } while (0)
+    if (txg) {
+        if (grad) D2D_RL_K(true, true);
+        else D2D_RL_K(false, true);
     } else {
-        if (K == 2) hipLaunchKernelGGL((region_list_kernel<2, false>), grid, block, lds, s, a, lv, lp);
-        else if (K == 3) hipLaunchKernelGGL((region_list_kernel<3, false>), grid, block, lds, s, a, lv, lp);
-        else hipLaunchKernelGGL((region_list_kernel<4, false>), grid, block, lds, s, a, lv, lp);
+        if (grad) D2D_RL_K(true, false);
+        else D2D_RL_K(false, false);
     }
+#undef D2D_RL_K
+#undef D2D_RL
     return hipGetLastError();
 }
-hipError_t launch_region_refine(int K, bool grad, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a, const RegionLevel& lv,
+hipError_t launch_region_refine(int K, bool grad, bool txg, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a, const RegionLevel& lv,
                                 const RegionLevel& parent, const ListPool& lp, int* flag) {
     const dim3 block(64);
-    if (grad) {
-        if (K == 2) hipLaunchKernelGGL((region_refine_kernel<2, true>), grid, block, lds, s, a, lv, parent, lp, flag);
-        else if (K == 3) hipLaunchKernelGGL((region_refine_kernel<3, true>), grid, block, lds, s, a, lv, parent, lp, flag);
-        else hipLaunchKernelGGL((region_refine_kernel<4, true>), grid, block, lds, s, a, lv, parent, lp, flag);
+#define D2D_RR(KK, G, T) hipLaunchKernelGGL((region_refine_kernel<KK, G, T>), grid, block, lds, s, a, lv, parent, lp, flag)
+#define D2D_RR_K(G, T)            \
+    do {                          \
+        if (K == 2) D2D_RR(2, G, T);      \
+        else if (K == 3) D2D_RR(3, G, T); \
+        else D2D_RR(4, G, T);             \
+    } while (0)
+    if (txg) {
+        if (grad) D2D_RR_K(true, true);
+        else D2D_RR_K(false, true);
     } else {
-        if (K == 2) hipLaunchKernelGGL((region_refine_kernel<2, false>), grid, block, lds, s, a, lv, parent, lp, flag);
-        else if (K == 3) hipLaunchKernelGGL((region_refine_kernel<3, false>), grid, block, lds, s, a, lv, parent, lp, flag);
-        else hipLaunchKernelGGL((region_refine_kernel<4, false>), grid, block, lds, s, a, lv, parent, lp, flag);
+        if (grad) D2D_RR_K(true, false);
+        else D2D_RR_K(false, false);
     }
+#undef D2D_RR_K
+#undef D2D_RR
     return hipGetLastError();
 }
 #else

@@ -4,7 +4,7 @@ never a bit.  Every case compares a launch that reads the lists with the same la
 patch (option region_lists = 0) and, at sizes the oracle finishes in seconds, with the oracle itself.  Covered: all
 validity modes, orders 2..4, both launch shapes (patches shared by 4 waves / one wave per patch with the dearest ones cut
 in parts), region sizes, a list pool that is too small (the patches of the lists that did not fit are handed to the
-enumerating kernel), non-finite cells (their patches never use lists), ragged grids, the value+grad sweep.
+enumerating kernel), non-finite cells (their patches never use lists), ragged grids, the value+grad sweep, TX grids.
 """
 
 import numpy as np
@@ -128,3 +128,42 @@ def test_value_and_grad_with_lists():
             both = np.isfinite(a[k]) & np.isfinite(b[k])
             assert np.array_equal(a[k][both], b[k][both]), k
             assert both.mean() > 0.9, k
+
+
+@pytest.mark.parametrize("approx", [False, True])
+def test_tx_grid_lists_change_no_bit(approx):
+    """accumulate_on_transmitters_grid_over_paths: the lists are built for the reversed chain (region_list_kernel<.., TXG>)."""
+    from differt2d_amd import _lib as L
+    from oracle import c_oracle as CO
+
+    rx, walls = random_scene(16, seed=9)
+    X, Y = unit_grid(90, 70)
+    X, Y = X.copy(), Y.copy()
+    for lo, hi in [(0, 2), (2, 3)]:
+        kw = dict(min_order=lo, max_order=hi, approx=approx, function="hard_sigmoid")
+        with _ctx(sched_min_tiles=1) as on, _ctx(region_lists=0) as off:
+            on.set_scene(walls)
+            off.set_scene(walls)
+            a = on.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
+            b = off.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
+            st = on.debug_region_stats()
+            assert st["leaf_regions"] > 0 and sum(st["leaf_entries"].values()) > 0 and st["patches_enumerated"] == 0
+            # value + per-cell d/d tx + scene VJP through the lists
+            ga = on.value_and_grads(rx, X, Y, grid_role=L.GRID_TX, **kw)
+            gb = off.value_and_grads(rx, X, Y, grid_role=L.GRID_TX, **kw)
+        want = CO.power_map(walls, rx, X, Y, prune=True, grid_role="tx", **kw)
+        assert _same(a, b) and _same(a, want), (lo, hi)
+        assert _same(ga["value"], a)
+        for k in ("grad_rx", "tx_bar", "walls_bar"):
+            both = np.isfinite(ga[k]) & np.isfinite(gb[k])
+            assert np.array_equal(ga[k][both], gb[k][both]) and both.mean() > 0.9, k
+    # a cell that is not finite: its patch (and its region's) go to the enumerating TX-grid kernel
+    X[3, 4] = np.nan
+    with _ctx() as on, _ctx(region_lists=0) as off:
+        on.set_scene(walls)
+        off.set_scene(walls)
+        kw = dict(min_order=0, max_order=2, approx=approx, function="hard_sigmoid")
+        a = on.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
+        b = off.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
+        assert on.debug_region_stats()["patches_enumerated"] > 0
+    assert _same(a, b)
