@@ -580,12 +580,13 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             float fa = by[i] * Cx - bx[i] * Cy;   // geometry.py:157
             float fb = w.z * Cy - w.w * Cx;       // geometry.py:158
             float fd = w.w * bx[i] - w.z * by[i]; // geometry.py:159
-            // divide-free filter: t = fl(num/fd) certainly outside [flt_lo, flt_hi]?
-            float D = fabsf(fd);
-            float ua = (fd < 0.0f) ? -fa : fa;
-            float ub = (fd < 0.0f) ? -fb : fb;
-            float lo = a.flt_lo * D, hi = a.flt_hi * D;
-            bool miss = (fd == 0.0f) || ((D >= 1e-30f) && ((ua < lo) || (ua > hi) || (ub < lo) || (ub > hi)));
+            // divide-free filter: t = fl(num/fd) certainly outside [flt_lo, flt_hi]?  num/fd lies outside iff
+            // (num - lo fd)(num - hi fd) > 0, whatever the sign of fd; each factor is one fma, so its sign is the exact
+            // difference's, and a product that underflows to 0 (tiny fd, or a numerator on a window edge) counts as "not
+            // certainly outside": the exact test decides.  One compare per segment instead of six and their mask algebra.
+            float pa = __builtin_fmaf(-a.flt_lo, fd, fa) * __builtin_fmaf(-a.flt_hi, fd, fa);
+            float pb = __builtin_fmaf(-a.flt_lo, fd, fb) * __builtin_fmaf(-a.flt_hi, fd, fb);
+            bool miss = fmaxf(pa, pb) > 0.0f;
             if (MODE == MODE_SIG && !skip) any_test = true;
             if (STATS && !skip) st.c[4] += 1;
             wbits |= (!skip && active && (!miss || bad)) ? (1u << i) : 0u;
