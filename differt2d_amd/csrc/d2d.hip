@@ -215,6 +215,34 @@ struct d2d_ctx {
     d2d_host::RegionPlan rl_plan;      // of the last launch that built lists (rl_plan.on) -- d2d_debug_region_stats
     int rl_max_order = 0;
     bool rl_host_valid = false;
+    // Pipelined preparation.  Everything a launch rebuilds before its sweep kernel (shadow masks, region lists, patch
+    // schedule) lives in two sets; the members above are the set of the current launch, `spare` is the other one (they
+    // are swapped at the start of every sweep launch).  The preparation of launch k+1 runs on aux_stream into set
+    // (k+1) mod 2 while the sweep kernel of launch k still reads set k mod 2 on the main stream: back-to-back launches
+    // (many transmitters, the benchmark) hide it completely.  The work history a schedule is sorted by is then two
+    // launches old instead of one.
+    struct PrepSet {
+        DevBuf<unsigned long long> d_shadow, d_rl_pool;
+        DevBuf<int> d_sched, d_rl_next, d_rl_idx, d_rl_meta;
+        DevBuf<unsigned char> d_sched_key;
+        DevBuf<unsigned> d_cost;
+        DevBuf<d2d::RegionLists> d_rl;
+        d2d::RegionLists rl_host;
+        bool rl_host_valid = false;
+        long long cost_tiles = 0;
+        int* rl_meta_ptr = nullptr;
+        hipEvent_t ev_swept = nullptr;  // recorded on the main stream behind the sweep that read this set
+        bool swept_pending = false;
+    };
+    static constexpr int N_SPARE = 1;   // two sets in all: a preparation runs beside the previous launch's sweep (a third set was
+                                        // measured and bought nothing: beside a sweep that fills the chip the 35 us chain of small
+                                        // kernels takes as long as the sweep itself, and it is the chain that bounds the step)
+    PrepSet spare_sets[N_SPARE];        // [0] the oldest (next to be reused) .. [N_SPARE - 1] the previous launch's
+    PrepSet& spare = spare_sets[N_SPARE - 1];
+    hipEvent_t ev_swept = nullptr;      // (the current set's)
+    bool swept_pending = false;
+    hipEvent_t ev_prep = nullptr;       // recorded on aux_stream behind a launch's preparation
+    bool pipeline = true;
     // RCCL (one communicator per ctx, collectives run on the ctx stream)
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -501,9 +529,18 @@ int d2d_create(int device, d2d_ctx** out) {
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->evk0);
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->evk1);
     if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_meta, hipEventDisableTiming);
-    if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
-    if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e1 == hipSuccess) {
+        // the side stream carries short dependent chains that run beside a sweep kernel which fills the chip: highest priority
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        e1 = hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, getenv("D2D_AUX_PRIO_OFF") ? prio_lo : prio_hi);
+    }
+    if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence);
+    if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence);
+    if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_prep, hipEventDisableTiming | hipEventDisableSystemFence);
+    if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_swept, hipEventDisableTiming | hipEventDisableSystemFence);
+    for (int i = 0; i < d2d_ctx::N_SPARE; ++i)
+        if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->spare_sets[i].ev_swept, hipEventDisableTiming | hipEventDisableSystemFence);
     if (e1 == hipSuccess) e1 = hipHostMalloc(reinterpret_cast<void**>(&c->h_meta), 2 * sizeof(int), hipHostMallocDefault);
     if (e1 != hipSuccess) {
         delete c;
@@ -516,6 +553,7 @@ int d2d_create(int device, d2d_ctx** out) {
 void d2d_destroy(d2d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
@@ -560,6 +598,15 @@ void d2d_destroy(d2d_ctx* c) {
     if (c->ev_meta) (void)hipEventDestroy(c->ev_meta);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_prep) (void)hipEventDestroy(c->ev_prep);
+    if (c->ev_swept) (void)hipEventDestroy(c->ev_swept);
+    for (int i = 0; i < d2d_ctx::N_SPARE; ++i) {
+        d2d_ctx::PrepSet& sp = c->spare_sets[i];
+        if (sp.ev_swept) (void)hipEventDestroy(sp.ev_swept);
+        sp.d_shadow.release(); sp.d_rl_pool.release(); sp.d_sched.release(); sp.d_rl_next.release();
+        sp.d_rl_idx.release(); sp.d_rl_meta.release(); sp.d_sched_key.release(); sp.d_cost.release();
+        sp.d_rl.release();
+    }
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->h_meta) (void)hipHostFree(c->h_meta);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -597,7 +644,8 @@ int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float
     c->have_scene = false;
     c->have_vjp = false;          // d_vjp was sized for (and computed from) the previous scene
     c->have_kernel_time = false;
-    c->cost_tiles = 0;            // the patch-cost history describes another sweep
+    c->cost_tiles = 0;  // the patch-cost history describes another sweep
+    for (int i = 0; i < d2d_ctx::N_SPARE; ++i) c->spare_sets[i].cost_tiles = 0;
     c->pair_valid = false;
     c->occl_patch = NAN;
     c->N = n_objects;
@@ -620,6 +668,7 @@ int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float
 int d2d_set_candidate_mask(d2d_ctx* c, const uint8_t* allowed) {
     if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
     c->cost_tiles = 0;  // the patch-cost history describes another sweep
+    for (int i = 0; i < d2d_ctx::N_SPARE; ++i) c->spare_sets[i].cost_tiles = 0;
     if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
     int rc = set_device(c);
     if (rc) return rc;
@@ -656,6 +705,7 @@ int d2d_list_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int32_
 int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t n) {
     if (!c || !X || !Y) return fail(D2D_ERR_INVALID, "NULL argument");
     c->cost_tiles = 0;  // the patch-cost history describes another sweep
+    for (int i = 0; i < d2d_ctx::N_SPARE; ++i) c->spare_sets[i].cost_tiles = 0;
     c->grid_version += 1;  // ... and the regions' bounding boxes another grid
     if (m <= 0 || n <= 0) return fail(D2D_ERR_INVALID, "grid must be at least 1 x 1, got %d x %d", m, n);
     int rc = set_device(c);
@@ -821,6 +871,35 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     if ((rc = set_device(c))) return rc;
     if ((rc = upload_occl(c, p->patch))) return rc;
 
+    // Pipelined preparation (see d2d_ctx::PrepSet): this launch takes the set the launch before the previous one used,
+    // and builds into it on the side stream, which first waits for the sweep that read it last.
+    const bool piped = c->pipeline && c->aux_stream != nullptr;
+    if (piped) {
+        // rotate: the oldest set becomes the current one, the current one the newest spare
+        auto swap_with = [&](d2d_ctx::PrepSet& o) {
+            std::swap(c->d_shadow, o.d_shadow);
+            std::swap(c->d_rl_pool, o.d_rl_pool);
+            std::swap(c->d_sched, o.d_sched);
+            std::swap(c->d_rl_next, o.d_rl_next);
+            std::swap(c->d_rl_idx, o.d_rl_idx);
+            std::swap(c->d_rl_meta, o.d_rl_meta);
+            std::swap(c->d_sched_key, o.d_sched_key);
+            std::swap(c->d_cost, o.d_cost);
+            std::swap(c->d_rl, o.d_rl);
+            std::swap(c->rl_host, o.rl_host);
+            std::swap(c->rl_host_valid, o.rl_host_valid);
+            std::swap(c->cost_tiles, o.cost_tiles);
+            std::swap(c->rl_meta_ptr, o.rl_meta_ptr);
+            std::swap(c->ev_swept, o.ev_swept);
+            std::swap(c->swept_pending, o.swept_pending);
+        };
+        swap_with(c->spare_sets[0]);                                   // cur <- [0] (the oldest), [0] <- cur
+        for (int i = 0; i + 1 < d2d_ctx::N_SPARE; ++i) std::swap(c->spare_sets[i], c->spare_sets[i + 1]);  // .. which moves to the newest place
+        if (c->swept_pending) HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_swept, 0));
+        c->swept_pending = false;
+    }
+    hipStream_t const ps = piped ? c->aux_stream : c->stream;  // where this launch's preparation runs
+
     d2d::SweepArgs a;
     memset(&a, 0, sizeof a);
     a.occl = c->d_occl.p;
@@ -913,8 +992,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         // (a multiple of 256 bytes: the runtime fills odd tails with a second kernel)
         const size_t zero_words = ((size_t)c->N + d2d::SCHED_KEYS + (2 + rl_regions + 1) / 2 + 31) & ~(size_t)31;
         if ((rc = c->d_shadow.ensure(zero_words))) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_shadow.p, 0, zero_words * sizeof(unsigned long long), c->stream));
-        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));  // (the schedule's sort may start here, on the side stream)
+        hipLaunchKernelGGL(d2d::zero_words_kernel, dim3((unsigned)((zero_words + 255) / 256)), dim3(256), 0, ps, c->d_shadow.p, (long)zero_words);
+        if (!piped) HIP_TRY(hipEventRecord(c->ev_fork, c->stream));  // (the schedule's sort may start here, on the side stream)
         prep_zeroed = true;
         // window where a test is certainly "hit" (hard) / exactly saturated to 1 (approx): shrink [-tol, 1+tol] by widen
         const double in_lo = -(double)p->seg_tol + widen_in, in_hi = 1.0 + (double)p->seg_tol - widen_in;
@@ -926,7 +1005,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             // bins span the parametric window in which on_objects is not exactly 0 (+ a little)
             const double dom_lo = (double)a.on_lo - 2e-3, dom_hi = (double)a.on_hi + 2e-3;
             const double dom_w = (dom_hi - dom_lo) / 64.0;
-            hipLaunchKernelGGL(d2d::shadow_tx_kernel, dim3((unsigned)pairs), dim3(64), 0, c->stream, c->d_occl.p,
+            hipLaunchKernelGGL(d2d::shadow_tx_kernel, dim3((unsigned)pairs), dim3(64), 0, ps, c->d_occl.p,
                                c->d_refl.p, c->d_kind.p, c->N, tx[0], tx[1], (float)(in_lo + 1e-4), (float)(in_hi - 1e-4), dperp,
                                (float)dom_lo, (float)dom_w, c->d_shadow.p);
             HIP_TRY(hipGetLastError());
@@ -942,9 +1021,12 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
                 if (!c->pair_valid || std::memcmp(key, c->pair_key, sizeof(key)) != 0) {
                     const size_t n2 = (size_t)c->N * c->N;
                     if ((rc = c->d_pair.ensure(n2))) return rc;
-                    HIP_TRY(hipMemsetAsync(c->d_pair.p, 0, n2 * sizeof(unsigned long long), c->stream));
+                    // (a sweep that reads the old masks may still be in flight on the main stream)
+                    for (int i = 0; piped && i < d2d_ctx::N_SPARE; ++i)
+                        if (c->spare_sets[i].swept_pending) HIP_TRY(hipStreamWaitEvent(ps, c->spare_sets[i].ev_swept, 0));
+                    HIP_TRY(hipMemsetAsync(c->d_pair.p, 0, n2 * sizeof(unsigned long long), ps));
                     const long long waves = (long long)c->N * c->N * c->N;
-                    hipLaunchKernelGGL(d2d::pair_shadow_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c->stream, c->d_occl.p,
+                    hipLaunchKernelGGL(d2d::pair_shadow_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ps, c->d_occl.p,
                                        c->d_refl.p, c->d_kind.p, c->N, (float)(in_lo + 1e-4), (float)(in_hi - 1e-4), pdperp,
                                        (float)dom_lo, (float)(dom_w * 8.0), c->d_pair.p);
                     HIP_TRY(hipGetLastError());
@@ -999,9 +1081,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
                 const size_t nbox = (size_t)rp.leaf.regions + (size_t)rp.top.regions;
                 if (std::memcmp(key, c->rl_box_key, sizeof key) != 0 || c->d_rl_box.n < nbox) {
                     if ((rc = c->d_rl_box.ensure(nbox))) return rc;
-                    hipLaunchKernelGGL(d2d::region_box_kernel, dim3((unsigned)rp.leaf.regions), dim3(256), 0, c->stream, c->d_X.p, c->d_Y.p,
+                    hipLaunchKernelGGL(d2d::region_box_kernel, dim3((unsigned)rp.leaf.regions), dim3(256), 0, ps, c->d_X.p, c->d_Y.p,
                                        c->m, c->n, rp.leaf.R, rp.leaf.regions_x, c->d_rl_box.p);
-                    hipLaunchKernelGGL(d2d::region_box_kernel, dim3((unsigned)rp.top.regions), dim3(256), 0, c->stream, c->d_X.p, c->d_Y.p,
+                    hipLaunchKernelGGL(d2d::region_box_kernel, dim3((unsigned)rp.top.regions), dim3(256), 0, ps, c->d_X.p, c->d_Y.p,
                                        c->m, c->n, rp.top.R, rp.top.regions_x, c->d_rl_box.p + rp.leaf.regions);
                     HIP_TRY(hipGetLastError());
                     std::memcpy(c->rl_box_key, key, sizeof key);
@@ -1040,14 +1122,14 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             if (!c->rl_host_valid || std::memcmp(&rl, &c->rl_host, sizeof rl) != 0) {
                 c->rl_host = rl;  // (the copy reads rl_host: it stays valid after this call returns)
                 c->rl_host_valid = true;
-                HIP_TRY(hipMemcpyAsync(c->d_rl.p, &c->rl_host, sizeof rl, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipMemcpyAsync(c->d_rl.p, &c->rl_host, sizeof rl, hipMemcpyHostToDevice, ps));
             }
             d2d::SweepArgs al = a;
             al.fb_n = nullptr;
             al.cullq_off = (int)((size_t)(3 * c->N + 1) * sizeof(float4));
             for (int k = rp.k_lo; k <= p->max_order; ++k) {
-                HIP_TRY(d2d::launch_region_lists(k, grad_mode != 0, txg, dim3((unsigned)rp.top.slots), lds_l, c->stream, al, top, rl.lp));
-                HIP_TRY(d2d::launch_region_refine(k, grad_mode != 0, txg, dim3((unsigned)rp.leaf.regions), lds_r, c->stream, al, rl.leaf, top, rl.lp, rl.flag));
+                HIP_TRY(d2d::launch_region_lists(k, grad_mode != 0, txg, dim3((unsigned)rp.top.slots), lds_l, ps, al, top, rl.lp));
+                HIP_TRY(d2d::launch_region_refine(k, grad_mode != 0, txg, dim3((unsigned)rp.leaf.regions), lds_r, ps, al, rl.leaf, top, rl.lp, rl.flag));
             }
             a.rl = c->d_rl.p;
             c->rl_plan = rp;
@@ -1077,7 +1159,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         if ((rc = c->d_sched_key.ensure((size_t)tiles))) return rc;
         if (!prep_zeroed) {
             if ((rc = c->d_shadow.ensure((size_t)c->N + d2d::SCHED_KEYS))) return rc;
-            HIP_TRY(hipMemsetAsync(c->d_shadow.p + c->N, 0, d2d::SCHED_KEYS * sizeof(unsigned long long), c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_shadow.p + c->N, 0, d2d::SCHED_KEYS * sizeof(unsigned long long), ps));
         }
         int* hist = reinterpret_cast<int*>(c->d_shadow.p + c->N);  // [SCHED_KEYS] counts, [SCHED_KEYS] cursors
         // cost key: what the patch cost last time, when this context has swept the same grid before (optimisation
@@ -1087,12 +1169,12 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         const bool from_lists = !from_history && a.rl != nullptr && c->sched_key_mode != 2;
         sched_from_history = from_history || from_lists;
         if (!from_history && !from_lists)
-            hipLaunchKernelGGL(d2d::patch_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, a, c->d_sched_key.p);
+            hipLaunchKernelGGL(d2d::patch_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, ps, a, c->d_sched_key.p);
         {
             // keys from the work history depend on nothing this launch has built: the sort then runs on the side stream,
             // beside the shadow masks and the region lists, behind the memset of its counters
-            const bool side = from_history && prep_zeroed && c->use_aux && c->aux_stream != nullptr;
-            hipStream_t ss = side ? c->aux_stream : c->stream;
+            const bool side = !piped && from_history && prep_zeroed && c->use_aux && c->aux_stream != nullptr;
+            hipStream_t ss = side ? c->aux_stream : ps;
             if (side) HIP_TRY(hipStreamWaitEvent(ss, c->ev_fork, 0));
             const unsigned sort_blocks = (unsigned)((tiles + 256 * d2d::SCHED_PER_THREAD - 1) / (256 * d2d::SCHED_PER_THREAD));
             hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, ss, c->d_sched_key.p,
@@ -1116,6 +1198,11 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         c->cost_tiles = tiles;     // (stream order: the next launch's key kernel runs after this sweep)
     }
     if (txg && d_stats) return fail(D2D_ERR_UNSUPPORTED, "the instrumented build covers the RX-grid kernel only");
+    if (piped) {
+        // the sweep waits for this launch's preparation; the set is busy until the sweep is through (d2d_swept below)
+        HIP_TRY(hipEventRecord(c->ev_prep, ps));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_prep, 0));
+    }
     // everything above is preparation (memsets, shadow masks, schedule); what follows is the sweep kernel itself
     c->have_kernel_time = false;
     if (c->time_kernel) HIP_TRY(hipEventRecord(c->evk0, c->stream));
@@ -1124,6 +1211,10 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         if (c->time_kernel) {                                    \
             HIP_TRY(hipEventRecord(c->evk1, c->stream));         \
             c->have_kernel_time = true;                          \
+        }                                                        \
+        if (piped) {                                             \
+            HIP_TRY(hipEventRecord(c->ev_swept, c->stream));     \
+            c->swept_pending = true;                             \
         }                                                        \
     } while (0)
     // behind a LISTED launch: how the lists fared, read back without waiting (see above)
@@ -1372,6 +1463,14 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     else if (!strcmp(name, "cost_history")) c->use_cost_history = value != 0;
     else if (!strcmp(name, "sched_key_mode")) c->sched_key_mode = value;
     else if (!strcmp(name, "side_stream")) c->use_aux = value != 0;
+    else if (!strcmp(name, "pipeline")) {
+        // (the two sets must not be mixed up by a switch in mid-flight)
+        if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->aux_stream) HIP_TRY(hipStreamSynchronize(c->aux_stream));
+        c->swept_pending = false;
+        for (int i = 0; i < d2d_ctx::N_SPARE; ++i) c->spare_sets[i].swept_pending = false;
+        c->pipeline = value != 0;
+    }
     else if (!strcmp(name, "fwd_waves")) {
         if (value != 0 && value != 1 && value != 4) return fail(D2D_ERR_INVALID, "fwd_waves must be 0, 1 or 4, got %lld", (long long)value);
         c->fwd_waves = value;

@@ -633,14 +633,15 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     hit_z = fmaxf(hit_z, z);
                 }
             }
-        }
-        // decided lanes: occlusion already makes valid exactly 0
-        if (MODE == MODE_HARD) active = active && (!hit_b || bad);
-        else if (MODE == MODE_HSIG) active = active && (hit_c != 6.0f || bad);
-        else active = active && (hit_z < 17.5f || bad);
-        if (!wave_any(active)) {
-            st.shadow = j;
-            break;
+            // decided lanes: occlusion already makes valid exactly 0 (only an exact test can change that: a wall whose
+            // filters settle every lane costs one wave-level decision, not two)
+            if (MODE == MODE_HARD) active = active && (!hit_b || bad);
+            else if (MODE == MODE_HSIG) active = active && (hit_c != 6.0f || bad);
+            else active = active && (hit_z < 17.5f || bad);
+            if (!wave_any(active)) {
+                st.shadow = j;
+                break;
+            }
         }
         more = has_next;
         j = nxt;
@@ -1932,7 +1933,11 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
 // WPB: waves (= patches) per workgroup.  1: the register allocation that serves small scenes best; 4: the waves share
 // the staged tables, which is what keeps big scenes (a 13 KB table at 200 walls) from running out of LDS at 3 waves per SIMD.
 #ifdef D2D_NUM_SGPR  // A/B: cap the scalar registers (96 -> 7 waves per SIMD, 80 -> 8 by MI355X_MICROARCH.md's residency formula)
+#ifdef D2D_NUM_VGPR
+#define D2D_SGPR_ATTR __attribute__((amdgpu_num_sgpr(D2D_NUM_SGPR), amdgpu_num_vgpr(D2D_NUM_VGPR)))
+#else
 #define D2D_SGPR_ATTR __attribute__((amdgpu_num_sgpr(D2D_NUM_SGPR)))
+#endif
 #else
 #define D2D_SGPR_ATTR
 #endif
@@ -2656,6 +2661,13 @@ __global__ void __launch_bounds__(256) region_box_kernel(const float* __restrict
         const bool anybad = sbad[0] | sbad[1] | sbad[2] | sbad[3];
         box[region] = make_float4(anybad ? __builtin_nanf("") : x0, x1, y0, y1);
     }
+}
+
+// What a launch needs zeroed (shadow masks, sort counters, list bookkeeping): a kernel of its own rather than
+// hipMemsetAsync, which the runtime does not let run ahead on the side stream.
+__global__ void __launch_bounds__(256) zero_words_kernel(unsigned long long* __restrict__ p, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0ull;
 }
 
 // Self-test of the bare division chain against the compiler's generic expansion (bit equality expected).
