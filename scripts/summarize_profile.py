@@ -25,13 +25,19 @@ def is_main(name):
 
 for approx in (0, 1):
     base = os.path.join(root, "gpurun_out", f"prof_{tag}_a{approx}")
-    stats = glob.glob(base + "_trace/*/*_kernel_stats.csv")
+    # gpurun merges every call's output into gpurun_out/: keep the newest run of each pass only
+    stats = sorted(glob.glob(base + "_trace/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)
     if not stats:
         continue
     dst = os.path.join(root, "profiles", f"{tag}_a{approx}_kernel_stats.csv")
     shutil.copy(stats[0], dst)
     pmc = {}
+    newest = {}
     for f in glob.glob(base + "_pmc*/*/*_counter_collection.csv"):
+        d = os.path.dirname(f)
+        if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+            newest[d] = f
+    for f in newest.values():
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if is_main(r["Kernel_Name"]):
