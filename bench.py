@@ -370,7 +370,8 @@ def main():
                             f"cell), {timed_mode} validity, received_power; BASELINE.json {wl_cfg}",
                 "setup": "scene and grid resident in HBM; 1 untimed launch (buffer allocation, scene-only masks) before the warmup "
                          "steps; every timed step sweeps the same transmitter (see moving_tx for a different one every step) and "
-                         "rebuilds everything that depends on it: shadow masks, region candidate lists, patch schedule",
+                         "rebuilds everything that depends on it: shadow masks, region candidate lists, patch schedule (on a side "
+                         "stream beside the previous step's sweep, as in any back-to-back sequence of launches: DESIGN.md section 4)",
                 "sharding": f"{world} rank(s), 8-row blocks round-robin"
                             + (f"; 1 RCCL {'gather to rank 0 (ncclSend/ncclRecv)' if args.gather == 'root' else 'all-gather'} of the "
                                f"value map per step, overlapped with the next step's sweep" if gather else ""),
