@@ -161,6 +161,10 @@ struct d2d_ctx {
     DevBuf<unsigned long long> d_stats, d_shadow;
     DevBuf<int> d_sched;                // patch schedule (its sort's histogram and cursors live behind d_shadow)
     DevBuf<unsigned char> d_sched_key;
+#ifdef D2D_AB_TIMELINE
+    DevBuf<unsigned> d_timeline;
+    long long timeline_n = 0;
+#endif
     DevBuf<unsigned> d_cost;            // what every patch cost in the last culled sweep of this grid (ticks >> 6)
     long long cost_tiles = 0;           // 0 = no history (scene, grid or candidate mask changed since)
     DevBuf<int> d_sched_override;       // diagnostic: a caller-supplied schedule (d2d_debug_set_schedule)
@@ -1354,6 +1358,12 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         unsigned wpb = c->fwd_waves > 0 ? (unsigned)c->fwd_waves : ((tab_lds * 32 > 160 * 1024) ? 4u : 1u);
         if (!a.rl || d_stats) wpb = 1;
         const dim3 g((grid_fwd.x + wpb - 1) / wpb, wpb);
+#ifdef D2D_AB_TIMELINE  // diagnostic build: one start / end stamp per workgroup, read back by d2d_debug_get_work
+        if ((rc = c->d_timeline.ensure(2 * (size_t)grid_fwd.x + 64))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_timeline.p, 0, (2 * (size_t)grid_fwd.x + 64) * sizeof(unsigned), c->stream));
+        c->timeline_n = 2 * (long long)grid_fwd.x;
+        if (!d_stats) a.grad = reinterpret_cast<float*>(c->d_timeline.p);
+#endif
         HIP_TRY(d2d::launch_fwd(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, g, tab_lds + (wpb - 1) * 512, c->stream, a));
     }
     if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
@@ -1519,6 +1529,14 @@ int d2d_debug_get_work(d2d_ctx* c, uint32_t* work, int64_t n) {
     if (!c || !work) return fail(D2D_ERR_INVALID, "NULL argument");
     int rc = set_device(c);
     if (rc) return rc;
+#ifdef D2D_AB_TIMELINE
+    if (n < 0) {  // the stamps of the last forward launch's workgroups (work[0 .. min(-n, timeline_n))
+        const long long m = std::min<long long>(-n, c->timeline_n);
+        HIP_TRY(hipMemcpyAsync(work, c->d_timeline.p, (size_t)m * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return (int)0;
+    }
+#endif
     if (!c->d_cost.p || c->cost_tiles != n) return fail(D2D_ERR_STATE, "no work history of %lld patches", (long long)n);
     HIP_TRY(hipMemcpyAsync(work, c->d_cost.p, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -1185,9 +1185,11 @@ struct ListSink {
     int cnt;
     bool over;
     int cap = SPLIT_LIST;
+    bool through = false;  // the list is read by another workgroup: store past this XCD's L2 (agent scope, sc1)
     __device__ __forceinline__ void push(float v) {
         if (cnt < cap) {
-            col[cnt * 64] = v;
+            if (through) __hip_atomic_store(reinterpret_cast<int*>(col + cnt * 64), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else col[cnt * 64] = v;
             ++cnt;
         } else {
             over = true;
@@ -1626,8 +1628,16 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
             T += __builtin_popcountll(cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi));
             D2D_WORK(5 * K);
         }
-        r_lo = (int)(((long)T * part) / parts);
-        r_hi = (int)(((long)T * (part + 1)) / parts);
+        if (K == 2 && a.min_order <= 1) {
+            // part 0 has swept orders 0 and 1 on its way here -- at cfg2 as much work as a quarter of a dear patch's order 2
+            // (scripts/timeline.py: 36 us of part 0's 71, the other parts 33) -- and takes 1 / (4 parts) of the ranks only
+            const int T0 = T / (4 * parts);
+            r_lo = part == 0 ? 0 : T0 + (int)(((long)(T - T0) * (part - 1)) / (parts - 1));
+            r_hi = part == 0 ? T0 : T0 + (int)(((long)(T - T0) * part) / (parts - 1));
+        } else {
+            r_lo = (int)(((long)T * part) / parts);
+            r_hi = (int)(((long)T * (part + 1)) / parts);
+        }
     }
     int ord = 0, chunk = chunk0;
     for (int off = 0; off < n && ord < r_hi; off += 64) {
@@ -1835,6 +1845,10 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
     const float by[4] = {y0, y0, y1, y1};
     unsigned long long tq0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[10] += tq0 - t_start;  // prologue of the patch
+#ifdef D2D_AB_TIMELINE
+    const unsigned t_lineB = (unsigned)(__builtin_amdgcn_s_memrealtime() & 0xffffull);
+    unsigned t_lineC = t_lineB;
+#endif
     if (quarter) {
         const long hq = tile0 * HEAVY_PARTS + part;
         ListSink sink;
@@ -1842,6 +1856,7 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
         sink.cnt = 0;
         sink.over = false;
         sink.cap = a.heavy_cap;
+        sink.through = true;
         float dummy = 0.0f;
         if (part == 0) {
             if (a.min_order <= 0 && a.max_order >= 0) {
@@ -1852,27 +1867,46 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
             if (a.min_order <= 1 && a.max_order >= 1)
                 sweep_order_culled<1, MODE, false, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, 0, 0x7fffffff, &sink);
         }
+#ifdef D2D_AB_TIMELINE
+        t_lineC = (unsigned)(__builtin_amdgcn_s_memrealtime() & 0xffffull);
+#endif
         if (a.min_order <= 2 && a.max_order >= 2)
             sweep_order_any<2, MODE, false, false, true, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, region, part, HEAVY_PARTS, &sink);
-        a.heavy_cnt[hq * 64 + lane] = sink.over ? -1 : sink.cnt;
-        if (lane == 0) a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq] = (int)st.work;
-        __threadfence();
+        // Hand-over to the part that finishes last, without cache maintenance: a release / acquire fence pair at agent
+        // scope is buffer_wbl2 + buffer_inv on gfx950, and the invalidate drops every line of the XCD's L2, the tables of
+        // all the other waves included (with 1024 cut patches every wave of the launch ran 3 x slower:
+        // scripts/timeline.py).  Instead everything another workgroup will read is stored past the L2 (agent-scope
+        // atomic stores: sc1 write-through), the wave waits until those stores are acknowledged (vmcnt(0)) before it
+        // draws its number, and the finishing part reads with agent-scope loads (sc1), issued behind the branch on the
+        // number it drew.
+        __hip_atomic_store(&a.heavy_cnt[hq * 64 + lane], sink.over ? -1 : sink.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(&a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq], (int)st.work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (compiler ordering)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): every store of the wave has been acknowledged
         int old = 0;
-        if (lane == 0) old = atomicAdd(&a.heavy_done[tile0], 1);
-        if (__builtin_amdgcn_readfirstlane(old) != HEAVY_PARTS - 1) return;  // another part will finish the patch
-        __threadfence();
+        if (lane == 0) old = __hip_atomic_fetch_add(&a.heavy_done[tile0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef D2D_AB_TIMELINE
+        if (a.grad && lane == 0) {
+            reinterpret_cast<unsigned*>(a.grad)[2 * b0] = (unsigned)(((t_line0 & 0xffffull) << 16) | (__builtin_amdgcn_s_memrealtime() & 0xffffull));
+            reinterpret_cast<unsigned*>(a.grad)[2 * b0 + 1] = (t_lineB << 16) | t_lineC;
+        }
+#endif
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != HEAVY_PARTS - 1) return;  // another part will finish the patch
         unsigned work = 0;
         for (int q = 0; q < HEAVY_PARTS; ++q) {
             const long hq2 = tile0 * HEAVY_PARTS + q;
-            const int n = a.heavy_cnt[hq2 * 64 + lane];
+            int n = __hip_atomic_load(&a.heavy_cnt[hq2 * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool bad = n < 0 || n > a.heavy_cap;  // cannot happen (heavy_cap covers every candidate); never silently wrong
+            n = bad ? 0 : n;
             int nmax = n;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
-            const float* col = a.heavy_list + hq2 * (long)a.heavy_cap * 64 + lane;
+            const int* col = reinterpret_cast<const int*>(a.heavy_list) + hq2 * (long)a.heavy_cap * 64 + lane;
             for (int i = 0; i < nmax; ++i)
-                if (i < n) acc = acc + col[i * 64];  // scene.py:1909, in candidate order
-            if (n < 0) acc = __builtin_nanf("");     // cannot happen (heavy_cap covers every candidate); never silently wrong
-            work += (unsigned)a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq2];
+                if (i < n) acc = acc + __int_as_float(__hip_atomic_load(&col[i * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // scene.py:1909, in candidate order
+            if (bad) acc = __builtin_nanf("");
+            work += (unsigned)__hip_atomic_load(&a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         st.work = work;
         if (lane == 0) a.heavy_done[tile0] = 0;  // ready for the next launch
@@ -1883,6 +1917,9 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
     if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
     unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[12] += tq2 - tq1;      // order 1
+#ifdef D2D_AB_TIMELINE
+    t_lineC = (unsigned)(__builtin_amdgcn_s_memrealtime() & 0xffffull);
+#endif
     if (a.min_order <= 2 && a.max_order >= 2) sweep_order_any<2, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
     if (STATS) st.c[13] += __builtin_amdgcn_s_memtime() - tq2;  // order 2
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_any<3, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
@@ -1908,11 +1945,13 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
         tby_sum += wave_sum(g.tby);
     }
     if (STATS && lane == 0 && a.wave_cycles) a.wave_cycles[tile] = __builtin_amdgcn_s_memtime() - t_start;
-#ifdef D2D_AB_TIMELINE  // diagnostic build (scripts/timeline.py): start / end stamps of the patch instead of its work
-    if (!STATS && a.cost_out && lane == 0)
-        a.cost_out[tile] = (unsigned)(((t_line0 & 0xffffull) << 16) | (__builtin_amdgcn_s_memrealtime() & 0xffffull));
-#else
     if (!STATS && a.cost_out && lane == 0) a.cost_out[tile] = st.work;
+#ifdef D2D_AB_TIMELINE  // diagnostic build (scripts/timeline.py): start / end stamps of every workgroup, beside the work history
+    if (!STATS && !GRADK && a.grad && lane == 0)
+    if (!quarter) {
+        reinterpret_cast<unsigned*>(a.grad)[2 * b0] = (unsigned)(((t_line0 & 0xffffull) << 16) | (__builtin_amdgcn_s_memrealtime() & 0xffffull));
+        reinterpret_cast<unsigned*>(a.grad)[2 * b0 + 1] = (t_lineB << 16) | t_lineC;
+    }
 #endif
     if (scene) {
         __syncthreads();
