@@ -198,6 +198,7 @@ struct d2d_ctx {
     long long region_budget_mb = 8192; // device memory the list pool may grow to
     long long rl_pool_mb = 256;        // its current size: quadrupled (up to the budget) after a launch whose lists did not fit
     hipStream_t aux_stream = nullptr;  // the patch schedule's sort runs here, beside the shadow masks and the region lists
+    hipStream_t sort_stream = nullptr; // .. and here when aux_stream carries the whole preparation (pipeline)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool use_aux = true;
     int* h_meta = nullptr;             // pinned: {patches left to the enumerating kernel, pool chunks handed out} of the last launch with lists
@@ -238,9 +239,10 @@ struct d2d_ctx {
         hipEvent_t ev_swept = nullptr;  // recorded on the main stream behind the sweep that read this set
         bool swept_pending = false;
     };
-    static constexpr int N_SPARE = 1;   // two sets in all: a preparation runs beside the previous launch's sweep (a third set was
-                                        // measured and bought nothing: beside a sweep that fills the chip the 35 us chain of small
-                                        // kernels takes as long as the sweep itself, and it is the chain that bounds the step)
+    static constexpr int N_SPARE = 2;   // three sets in all: the preparation runs freely ahead on its own streams (with two sets it
+                                        // could not start before the sweep before last had finished, i.e. at the very moment the
+                                        // previous sweep starts, and the sweep then waited for the tail of the chain: 0.111 ->
+                                        // 0.107 ms per step at cfg2 once the sort had left the chain)
     PrepSet spare_sets[N_SPARE];        // [0] the oldest (next to be reused) .. [N_SPARE - 1] the previous launch's
     PrepSet& spare = spare_sets[N_SPARE - 1];
     hipEvent_t ev_swept = nullptr;      // (the current set's)
@@ -538,6 +540,7 @@ int d2d_create(int device, d2d_ctx** out) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         e1 = hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, getenv("D2D_AUX_PRIO_OFF") ? prio_lo : prio_hi);
+        if (e1 == hipSuccess) e1 = hipStreamCreateWithPriority(&c->sort_stream, hipStreamNonBlocking, prio_hi);
     }
     if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence);
     if (e1 == hipSuccess) e1 = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence);
@@ -558,6 +561,7 @@ void d2d_destroy(d2d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c->sort_stream) (void)hipStreamSynchronize(c->sort_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm && rccl().ok) rccl().CommDestroy(c->comm);
@@ -612,6 +616,7 @@ void d2d_destroy(d2d_ctx* c) {
         sp.d_rl.release();
     }
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->sort_stream) (void)hipStreamDestroy(c->sort_stream);
     if (c->h_meta) (void)hipHostFree(c->h_meta);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -997,7 +1002,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         const size_t zero_words = ((size_t)c->N + d2d::SCHED_KEYS + (2 + rl_regions + 1) / 2 + 31) & ~(size_t)31;
         if ((rc = c->d_shadow.ensure(zero_words))) return rc;
         hipLaunchKernelGGL(d2d::zero_words_kernel, dim3((unsigned)((zero_words + 255) / 256)), dim3(256), 0, ps, c->d_shadow.p, (long)zero_words);
-        if (!piped) HIP_TRY(hipEventRecord(c->ev_fork, c->stream));  // (the schedule's sort may start here, on the side stream)
+        HIP_TRY(hipEventRecord(c->ev_fork, ps));  // (the schedule's sort may start here, on a stream of its own)
         prep_zeroed = true;
         // window where a test is certainly "hit" (hard) / exactly saturated to 1 (approx): shrink [-tol, 1+tol] by widen
         const double in_lo = -(double)p->seg_tol + widen_in, in_hi = 1.0 + (double)p->seg_tol - widen_in;
@@ -1177,8 +1182,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         {
             // keys from the work history depend on nothing this launch has built: the sort then runs on the side stream,
             // beside the shadow masks and the region lists, behind the memset of its counters
-            const bool side = !piped && from_history && prep_zeroed && c->use_aux && c->aux_stream != nullptr;
-            hipStream_t ss = side ? c->aux_stream : ps;
+            const bool side = from_history && prep_zeroed && c->use_aux && (piped ? c->sort_stream : c->aux_stream) != nullptr;
+            hipStream_t ss = side ? (piped ? c->sort_stream : c->aux_stream) : ps;
             if (side) HIP_TRY(hipStreamWaitEvent(ss, c->ev_fork, 0));
             const unsigned sort_blocks = (unsigned)((tiles + 256 * d2d::SCHED_PER_THREAD - 1) / (256 * d2d::SCHED_PER_THREAD));
             hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, ss, c->d_sched_key.p,
@@ -1188,7 +1193,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
                                hist + d2d::SCHED_KEYS, c->d_sched.p, (long)tiles);
             if (side) {
                 HIP_TRY(hipEventRecord(c->ev_join, ss));
-                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+                HIP_TRY(hipStreamWaitEvent(ps, c->ev_join, 0));
             }
         }
         HIP_TRY(hipGetLastError());
