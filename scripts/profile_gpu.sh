@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out
 TAG=${1:-r02}
 APPROX=${2:-0}
-CMD="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --approx ${APPROX}"
+CMD="python3 bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-extras --approx ${APPROX}"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_a${APPROX}_trace -- $CMD > $OUT/prof_${TAG}_a${APPROX}_trace.log 2>&1
 # PMC passes, each on its own (never combined with trace domains other than kernel-trace)

@@ -55,7 +55,7 @@ for approx in (0, 1):
     simd_cycles = cycles_per_xcd * 1024
     with open(os.path.join(root, "profiles", f"{tag}_a{approx}_summary.md"), "w") as f:
         f.write(f"# rocprofv3 summary, tag {tag}, approx={approx}\n\n")
-        f.write(f"command: `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --approx {approx}` (scripts/profile_gpu.sh)\n\n")
+        f.write(f"command: `python3 bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-extras --approx {approx}` (scripts/profile_gpu.sh)\n\n")
         f.write(f"| kernel | calls | avg ms | min ms | max ms |\n|---|---|---|---|---|\n")
         f.write(f"| `{k['Name']}` | {k['Calls']} | {avg_ms:.4f} | {float(k['MinNs'])/1e6:.4f} | {float(k['MaxNs'])/1e6:.4f} |\n\n")
         f.write("All kernels of the run (one launch sequence per step: memset, shadow masks, region lists, schedule sort on a side "
