@@ -167,3 +167,27 @@ def test_tx_grid_lists_change_no_bit(approx):
         b = off.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
         assert on.debug_region_stats()["patches_enumerated"] > 0
     assert _same(a, b)
+
+
+@pytest.mark.parametrize("approx", [False, True])
+def test_cut_patches_hand_over_with_a_moving_transmitter(approx):
+    """The parts of a cut patch run in different workgroups (different XCDs) and hand their lists over through global
+    memory without cache maintenance (write-through stores, agent-scope loads: DESIGN.md "Hand-over").  A different
+    transmitter every launch makes a stale read visible: it would return the previous launch's bytes."""
+    from differt2d_amd.engine import make_params
+
+    tx, walls = random_scene(24, seed=21)
+    X, Y = unit_grid(192, 160)  # 24 x 20 patches
+    txs = [tx, (tx + F([0.013, -0.021])).astype(F), (F([0.9, 0.1]) - tx * F(0.5)).astype(F)]
+    p = make_params(min_order=0, max_order=2, approx=approx, function="hard_sigmoid")
+    with _ctx(region_lists=0, split_max_tiles=0, sched_min_tiles=1, heavy_split=0) as ref:
+        ref.set_scene(walls)
+        want = [ref.power_map(t, X, Y, min_order=0, max_order=2, approx=approx, function="hard_sigmoid") for t in txs]
+    for cut in (16, 200, 480):
+        with _ctx(split_max_tiles=0, sched_min_tiles=1, heavy_split=cut) as c:
+            c.set_scene(walls)
+            c.set_grid(X, Y)
+            for i in range(15):
+                k = i % 3
+                c.launch(p, txs[k])
+                assert _same(c.get_map(), want[k]), (cut, i)
