@@ -217,10 +217,18 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *                   lists are refined from those of regions of region_size_top patches a side (default 16, rounded down to
  *                   a multiple of region_size), which are built by enumeration
  *   "region_slices": lists per top region = slices of first walls = waves that enumerate it (default 0: a quarter of
- *                   the allowed objects); "region_budget_mb": device memory of the list pool (default 512); a list
+ *                   the allowed objects); "region_budget_mb": device memory of the list pool (default 8192: an upper bound); a list
  *                   that does not fit is marked as not listed and the patches of its region enumerate (same results)
  *   "sched_key_mode": schedule keys from 0 (default) the work history if there is one, else the lengths of the region
  *                   lists, else the geometric proxy; 1 never the history; 2 never the lists
+ *   "pipeline": non-zero (default) = everything a launch rebuilds (shadow masks, region lists, the schedule's sort) lives
+ *                   in three rotating sets and is built on side streams beside the previous launches' sweeps; the work
+ *                   history a schedule is sorted by is then three launches old instead of one; zero = on the
+ *                   launch's own stream, in front of its sweep (same results)
+ *   "side_stream": zero = the schedule's sort is never moved to a stream of its own; "fwd_waves": patches per workgroup
+ *                   of the sweep with region lists (0 default: 4 when the per-wall LDS table is big, else 1)
+ *   "region_budget_mb" also bounds the growth of the list pool: it starts at 256 MB and is quadrupled (up to the budget,
+ *                   default 8192) when a launch's lists did not fit (read back without waiting)
  *   "time_kernel": non-zero = bracket the sweep kernel of every launch with HIP events (see d2d_last_kernel_ms)
  * Also read once at d2d_create from the environment: D2D_SPLIT_MAX_TILES, D2D_SCHED_MIN_TILES. No reference counterpart
  * (XLA picks its own launch shapes). Returns D2D_ERR_INVALID for an unknown name. */
