@@ -156,7 +156,12 @@ inline HeavyPlan heavy_plan(long long tiles, long long Nc, long long heavy_split
     if (tiles <= 0 || Nc < 2 || heavy_split <= 0 || parts <= 0) return hp;
     const long long H = heavy_split < tiles / 16 ? heavy_split : tiles / 16;
     if (H <= 0) return hp;
-    const long long cap = ((Nc + parts - 1) / parts + 2) * Nc + Nc + 2;
+    if (Nc > (1ll << 30)) return hp;
+    // what one part can push: its range of first walls (enumerating build), or -- region lists, parts by rank, part 0 a
+    // smaller share because it also sweeps orders 0 and 1 -- up to 1 / (parts - 1) of all order-2 candidates
+    const long long by_walls = ((Nc + parts - 1) / parts + 2) * Nc + Nc + 2;
+    const long long by_rank = (Nc * (Nc - 1) + (parts > 1 ? parts - 2 : 0)) / (parts > 1 ? parts - 1 : 1) + Nc + 2;
+    const long long cap = by_walls > by_rank ? by_walls : by_rank;
     // H * parts * cap * 64 * 4 bytes <= 4 GiB, evaluated without overflow
     const long long limit = (4ll << 30) / (64 * (long long)sizeof(float));
     if (cap <= 0 || H > limit / parts || H * parts > limit / cap) return hp;
