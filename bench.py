@@ -278,11 +278,11 @@ def main():
             modes[name] = {"ms_per_step": w * 1e3 / n, "kernel_ms": kernel_ms_of(p, tx, min(n, 10)), "steps": n,
                            "candidates_per_s": cells_total * C / (w / n)}
         extras["modes"] = modes
-        # ---- a different transmitter every step: the work history behind the patch schedule is one step stale
+        # ---- a different transmitter every step: the work history behind the patch schedule is a few steps stale
         txs = moving_transmitters(tx, n_x + 5)
         it = iter(txs)
         w, _ = timed(lambda: ctx.launch(params, next(it)), n_x, 5)
-        # the same positions, each swept three times in a row and the third launch timed (warm history for THAT position):
+        # the same positions, each swept five times in a row and the fifth launch timed (warm history for THAT position):
         # what the sequence would cost if the schedule always knew the current position's work
         ctx.set_option("time_kernel", 1)
         warm, stale = [], []
@@ -290,18 +290,20 @@ def main():
             ctx.launch(params, txs[5 + k - 1] if k else tx)
             ctx.launch(params, t_)
             stale.append(ctx.last_kernel_ms())  # history from the previous position
-            ctx.launch(params, t_)
-            ctx.launch(params, t_)
+            for _ in range(4):  # (the pipelined preparation sorts by the history of three launches back)
+                ctx.launch(params, t_)
             warm.append(ctx.last_kernel_ms())
         ctx.set_option("time_kernel", 0)
         extras["moving_tx"] = {"ms_per_step": w * 1e3 / n_x, "steps": n_x, "mode": timed_mode,
                                "kernel_ms_stale_history": float(np.mean(stale)), "kernel_ms_warm_history": float(np.mean(warm)),
                                "kernel_ms_warm_min_max": [float(np.min(warm)), float(np.max(warm))],
                                "what": "random walk of the transmitter (sigma 0.01 per step), a different position every step; "
-                                       "shadow masks and schedule rebuilt per launch as always, work history from the previous position. "
+                                       "shadow masks and schedule rebuilt per launch as always, work history from three positions back (the "
+                                       "preparation of a launch is sorted while the previous sweeps run). "
                                        "kernel_ms_warm_history: the same positions with each position's own history (the cost of the "
                                        "positions themselves: how much of the scene a transmitter sees varies a lot along the walk); "
-                                       "kernel_ms_stale_history - kernel_ms_warm_history = what the one-step-old history costs"}
+                                       "kernel_ms_stale_history (history from the previous position) - kernel_ms_warm_history = what a "
+                                       "stale history costs"}
         # ---- a launch right after set_grid with everything allocated: geometric-proxy schedule, no cut-in-four
         cold = []
         for _ in range(5):
