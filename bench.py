@@ -6,8 +6,11 @@ Step      = one forward power map of the workload, inputs resident in HBM:
             --workload cfg2 (default): 50 random walls (NumPy seed 1234), 1 TX, 1024 x 1024 RX grid over the unit square,
             orders 0..2 (C = 2501 candidates per cell) = BASELINE.json configs[1]; hard (reference default) validity.
             --workload cfg4: 200 walls, 2048 x 2048 grid, orders 0..3 (C = 7 960 201) = configs[3].
-N > 1     = launched by torch.distributed.run, one process per GPU (torch is never imported: rendezvous through a file in
-            /tmp, data plane, barrier and max-over-ranks through RCCL).  Rows are dealt to ranks in 8-row blocks
+N > 1     = one process per GPU: either launched by torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK in the
+            environment), or -- plain `python bench.py --gpus N` -- by this script itself: the parent, which never
+            touches HIP, starts N child processes of itself with those variables set, relays rank 0's JSON line and exits
+            with the worst child's code.  torch is never imported: rendezvous through a file in /tmp, data plane, barrier
+            and max-over-ranks through RCCL.  Rows are dealt to ranks in 8-row blocks
             round-robin (differt2d_amd/parallel.py).  cfg2: WEAK scaling, the grid becomes (1024 N) x 1024 cells over the
             same unit square, 1024 x 1024 per rank.  cfg4: STRONG scaling, the 2048 x 2048 grid is split over the ranks.
             Each step ends with ONE RCCL gather of the value map to rank 0 (--gather root, ncclSend/ncclRecv; or --gather
@@ -142,6 +145,138 @@ def moving_transmitters(tx, n, step=0.01, seed=7):
     return out
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N children of this script, one per GPU, with the environment
+    torch.distributed.run would give them, relay rank 0's stdout (the JSON line) and return the worst exit code.  The
+    parent never initialises HIP (children are fresh processes: subprocess.Popen, never os.exec*)."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rdzv = tempfile.mkdtemp(prefix="d2d_rdzv_")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), D2D_RDZV_DIR=rdzv, D2D_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0 prints the JSON line: into a file, so that nobody has to keep a pipe drained
+        out = open(os.path.join(rdzv, "rank0.out"), "wb") if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, stdout=out))
+        if r == 0:
+            out.close()
+    worst, failed_at = 0, None
+    out0 = b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0:
+                    worst = rc if worst == 0 or abs(rc) > abs(worst) else worst
+                    failed_at = failed_at or time.time()
+            # a rank that failed leaves the others waiting at the rendezvous or in a collective: give them a moment, then end them
+            if failed_at and pending and time.time() - failed_at > 20.0:
+                for r in pending:
+                    procs[r].kill()  # (the exact processes started above)
+            if pending:
+                time.sleep(0.05)
+        with open(os.path.join(rdzv, "rank0.out"), "rb") as f:
+            out0 = f.read()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        shutil.rmtree(rdzv, ignore_errors=True)
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return worst if worst >= 0 else 128 + abs(worst)
+
+
+def api_leg(tx, walls, resident_ms, sizes=(300, 1024), n_calls=12):
+    """Wall time of the reference's own entry point (scene.py:1803-1826) on the Python mirror, PCIe included: every call
+    hands X, Y and the objects over again and returns the map as a host array.  `first` = the first call on a context that
+    has never seen this grid (upload, allocation of the launch's buffers, no work history); `steady` = the median of the
+    following calls.  Arrays as scene.grid() returns them (immutable: recognised by identity) and plain writable arrays
+    (recognised by a content hash of their 2 x 4 m n bytes)."""
+    from differt2d_amd.geometry import Point
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import received_power
+
+    scene = Scene.from_walls_array(walls).with_transmitters(tx=Point(xy=tx))
+    ctx = scene._ctx()
+    out = {"what": "Scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, reduce_all=True, max_order=2), hard "
+                   "validity, wall time per call incl. PCIe both ways (host arrays in, host array out); steady = median of "
+                   f"{n_calls - 2} calls after the first two", "resident_ms_per_step": resident_ms}
+    for g in sizes:
+        x = np.linspace(0.0, 1.0, g).astype(np.float32)
+        entry = {}
+        for label, freeze in (("immutable_arrays", True), ("writable_arrays", False)):
+            X, Y = np.meshgrid(x, x)
+            if freeze:
+                X.setflags(write=False)
+                Y.setflags(write=False)
+            ts = []
+            for _ in range(n_calls):
+                t0 = time.perf_counter()
+                Z = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, reduce_all=True, max_order=2)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            assert Z.shape == X.shape
+            entry[label] = {"first_ms": ts[0], "steady_ms": float(np.median(ts[2:])), "min_ms": float(np.min(ts[2:]))}
+        # the parts of a steady call: the sweep alone (launch -> synchronize) and the download alone
+        p = None
+        from differt2d_amd.engine import make_params as mk
+
+        p = mk(min_order=0, max_order=2)
+        ds, ls = [], []
+        for _ in range(n_calls):
+            t0 = time.perf_counter()
+            ctx.launch(p, tx)
+            ctx.synchronize()
+            ls.append((time.perf_counter() - t0) * 1e3)
+            t0 = time.perf_counter()
+            ctx.get_map()
+            ds.append((time.perf_counter() - t0) * 1e3)
+        entry["launch_and_sync_ms"] = float(np.median(ls[2:]))
+        entry["download_ms"] = float(np.median(ds[2:]))
+        entry["grid_reuses"] = ctx.grid_reuses()
+        out[f"{g}x{g}"] = entry
+    return out
+
+
+def strong_leg(ctx, world, rank, distributed, do_gather, timed, steps=5):
+    """BASELINE.json configs[3] (200 walls, 2048 x 2048, orders 0..3) with its rows split over the ranks: the STRONG-scaling
+    companion of the timed (weak) workload, in the same process, for the N = 1, 2, 4, 8 sequence."""
+    from differt2d_amd.engine import make_params
+    from differt2d_amd.parallel import RowShards
+
+    n_walls, grid, max_order = WORKLOADS["cfg4"][:3]
+    tx, walls, X, Y = workload(n_walls, grid)
+    shards = RowShards(X.shape[0], world)
+    ctx.set_scene(walls)
+    ctx.set_grid(shards.take(X, rank), shards.take(Y, rank))
+    p = make_params(min_order=0, max_order=max_order)
+
+    def step():
+        ctx.launch(p, tx)
+        if world > 1:
+            do_gather()
+
+    step()
+    ctx.synchronize()
+    wall, _ = timed(step, steps, 2)
+    C = num_candidates(n_walls, 0, max_order)
+    return {"workload": f"{n_walls} walls, {grid}x{grid} RX grid split over {world} rank(s), orders 0..{max_order} (C={C}), hard validity; "
+                        "BASELINE.json configs[3]", "scaling": "strong", "steps": steps, "ms_per_step": wall * 1e3 / steps,
+            "candidates_per_s": X.size * C / (wall / steps)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +291,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other modes / moving-TX / value+grad / parity legs")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # before anything touches HIP
 
     wl_walls, wl_grid, wl_order, wl_cfg, wl_scaling = WORKLOADS[args.workload]
     n_walls = args.walls or wl_walls
@@ -175,11 +314,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if distributed and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not distributed and args.gpus != 1:
-        raise SystemExit("N > 1 must be launched with torch.distributed.run (one process per GPU)")
 
     n_dev = max(1, L.device_count())
-    ctx = Context(local_rank % n_dev)  # one GPU per rank; ranks only share a device on a box with fewer GPUs than ranks
+    try:
+        ctx = Context(local_rank % n_dev)  # one GPU per rank; ranks only share a device on a box with fewer GPUs than ranks
+    except L.D2DError as e:
+        # (no CPU fallback: without a GPU there is nothing to time)
+        print(f"[bench rank {rank}] {e}", file=sys.stderr, flush=True)
+        sys.exit(4)
     if distributed:
         # torch.distributed.run is only the launcher: rendezvous through /tmp, everything else through RCCL
         from differt2d_amd.parallel import file_rendezvous, file_rendezvous_cleanup
@@ -262,6 +404,12 @@ def main():
     wall, sequence_ms = timed(step, steps, warmup)
     ms_per_step = wall * 1e3 / steps
     kernel_ms = kernel_ms_of(params, tx, min(steps, 50))
+    rccl_ranks, kernel_ms_per_rank = 1, [kernel_ms]
+    if distributed:
+        rccl_ranks = ctx.comm_count()  # ncclCommCount: what RCCL itself says
+        mine = np.zeros(world)
+        mine[rank] = kernel_ms
+        kernel_ms_per_rank = [float(v) for v in ctx.comm_allreduce_host(mine, "sum")]
     cells_total = X.size
     cells_local = Xl.size
     small = (Xl.shape[0] + 7) // 8 * ((Xl.shape[1] + 7) // 8) <= 8192
@@ -342,12 +490,20 @@ def main():
         extras["value_and_grad"] = {"culled": {"ms_per_step": w * 1e3 / n, "steps": n, "candidates_per_s": cells_total * C / (w / n)},
                                     "what": "value + gradient maps gathered, scene VJP all-reduced, every step"}
 
+    final_map = None
     if rank == 0:
-        approx = timed_mode != "hard"
         ctx.launch(params, tx)
         final_map = ctx.get_map()  # rank 0's shard of the timed configuration (N = 1: the whole map)
         stats = ctx.launch_stats(params, tx)  # instrumented build, outside the timed region (deterministic counts)
         list_stats = ctx.debug_region_stats()  # the region candidate lists of that launch (none for orders < 2)
+    if not args.no_extras and args.workload == "cfg2" and default_shape:
+        # (collective at N > 1: every rank takes part; replaces the context's scene and grid, hence after everything else)
+        extras["strong_cfg4"] = strong_leg(ctx, world, rank, distributed, do_gather, timed)
+    if not args.no_extras and world == 1 and args.workload == "cfg2" and default_shape:
+        extras["api"] = api_leg(tx, walls, ms_per_step)
+
+    if rank == 0:
+        approx = timed_mode != "hard"
         flop_ref, flop_cull = executed_flop(stats, approx)
         flop_unpruned = unpruned_flop_per_rx(n_walls, 0, max_order, approx) * cells_local
         per_s = 1.0 / (kernel_ms * 1e-3) / 1e12
@@ -358,6 +514,8 @@ def main():
             "value": cells_total * C / (ms_per_step * 1e-3),
             "unit": "candidates/s",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,
+            "kernel_ms_per_rank": kernel_ms_per_rank,
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": ms_per_step,

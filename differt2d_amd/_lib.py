@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("D2D_LIB") or os.path.join(CSRC, "libd2d.so")
 D2D_MAX_ORDER = 4
 D2D_NUM_STATS = 16
 D2D_COMM_ID_BYTES = 128
-D2D_ABI_VERSION = 5
+D2D_ABI_VERSION = 6
 
 D2D_WALL, D2D_RIS, D2D_VERTEX = 0, 1, 2
 SOLVER_IMAGE, SOLVER_MINPATH, SOLVER_FERMAT = 0, 1, 2
@@ -97,6 +97,8 @@ SYMBOLS = [
     ("d2d_num_candidates", C.c_int, [_ctx, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     ("d2d_list_candidates", C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     ("d2d_set_grid", C.c_int, [_ctx, _f32p, _f32p, C.c_int32, C.c_int32]),
+    ("d2d_set_grid_versioned", C.c_int, [_ctx, _f32p, _f32p, C.c_int32, C.c_int32, C.c_uint64]),
+    ("d2d_debug_grid_reuses", C.c_int, [_ctx, C.POINTER(C.c_int64)]),
     ("d2d_power_map_launch", C.c_int, [_ctx, C.POINTER(Params), _f32p]),
     ("d2d_set_cotangent", C.c_int, [_ctx, C.c_void_p]),
     ("d2d_power_map_vg_launch", C.c_int, [_ctx, C.POINTER(Params), _f32p, C.c_int32]),
@@ -122,6 +124,7 @@ SYMBOLS = [
     ("d2d_comm_unique_id", C.c_int, [C.c_void_p]),
     ("d2d_comm_init", C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int32]),
     ("d2d_comm_destroy", C.c_int, [_ctx]),
+    ("d2d_comm_count", C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     ("d2d_comm_allgather_map", C.c_int, [_ctx, C.c_int32]),
     ("d2d_comm_gather_map", C.c_int, [_ctx, C.c_int32, C.c_int32]),
     ("d2d_comm_get_gathered", C.c_int, [_ctx, C.c_int32, _f32p, C.c_int64]),

@@ -61,6 +61,10 @@ class Plottable(ABC):
         x = linspace_f32(bbox[0, 0], bbox[1, 0], m)
         y = linspace_f32(bbox[0, 1], bbox[1, 1], n)
         X, Y = np.meshgrid(x, y)
+        # immutable, like the reference's JAX arrays (docs/source/jax_and_jaxtyping.md:52-57): a grid passed to a sweep again
+        # is then recognised by identity and not uploaded a second time (engine.Context.set_grid)
+        X.setflags(write=False)
+        Y.setflags(write=False)
         return X, Y
 
     def center(self) -> np.ndarray:

@@ -174,6 +174,9 @@ struct d2d_ctx {
     long long sched_key_mode = 0;       // schedule keys: 0 work history if there is one, else list lengths, else the proxy; 1 never the history; 2 never the lists
     bool txg_exhaustive = false;        // TX-grid value sweeps with the exhaustive kernel (A/B and tests)
     long long sched_min_tiles = 2048;   // launches with fewer patches keep the identity schedule
+    uint64_t grid_hash = 0, grid_token = 0;  // content hash / caller's version token of the resident grid (valid with have_grid)
+    bool grid_hash_valid = false;
+    long long grid_reuses = 0;  // d2d_set_grid calls that found their grid resident already (diagnostic: d2d_debug_grid_reuses)
     float grid_absmax = 0.0f;   // max |coordinate| of the grid (host scan at d2d_set_grid)
     bool grid_all_finite = false;  // every cell coordinate is below 1e18 in magnitude (what the kernels call comfortably finite)
     float scene_absmax = 0.0f;  // max |coordinate| of the objects
@@ -183,6 +186,7 @@ struct d2d_ctx {
     bool have_cot = false;
     bool have_vjp = false;   // d_vjp holds the scene VJP of a sweep of the CURRENT scene (4 N + 2 values)
     bool vjp_has_phi = false;  // d_vjp[4N+2 .. 5N+2) holds d/d phi (optimiser-based sweeps); image sweeps: identically 0
+    bool vjp_reduced = false;  // d_vjp has been all-reduced over ranks: it is a global sum, nothing local may be added to it
     bool have_grad = false;  // d_grad holds the per-cell gradient map of a sweep of the CURRENT grid (2 m n values)
     bool want_wave_cycles = false;
     long long split_max_tiles = 8192;   // launches up to this many patches share every patch between 4 waves
@@ -195,7 +199,7 @@ struct d2d_ctx {
     long long region_size = 4;         // leaf regions (what the sweep kernels read) are region_size x region_size patches
     long long region_size_top = 16;    // regions listed by enumeration (a multiple of region_size; equal: one level only)
     long long region_slices = 0;       // slices of first walls per enumerated region (0: chosen from the number of allowed walls)
-    long long region_budget_mb = 8192; // device memory the list pool may grow to
+    long long region_budget_mb = 24576; // device memory all list pools together may grow to (one pool per rotating set)
     long long rl_pool_mb = 256;        // its current size: quadrupled (up to the budget) after a launch whose lists did not fit
     hipStream_t aux_stream = nullptr;  // the patch schedule's sort runs here, beside the shadow masks and the region lists
     hipStream_t sort_stream = nullptr; // .. and here when aux_stream carries the whole preparation (pipeline)
@@ -204,7 +208,8 @@ struct d2d_ctx {
     int* h_meta = nullptr;             // pinned: {patches left to the enumerating kernel, pool chunks handed out} of the last launch with lists
     hipEvent_t ev_meta = nullptr;
     bool meta_pending = false;
-    long long rl_meta_static = 0, rl_meta_chunks = 0;  // n_static / max_chunks of the launch h_meta describes
+    long long rl_meta_static = 0, rl_meta_chunks = 0;  // n_static / max_chunks of the last launch that built lists
+    long long pend_static = 0, pend_chunks = 0;        // ... of the launch the pending h_meta read-back describes
     long long fb_hint = 0;             // patches the last such launch left to the enumerating kernel
     long long rl_launches = 0;         // launches with lists since the plan last changed (the read-back thins out: 1, 2, 3, then every 16th)
     DevBuf<unsigned long long> d_rl_pool;
@@ -415,6 +420,7 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool ok = false;
 };
@@ -439,6 +445,7 @@ Rccl& rccl() {
     r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.h, "ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
     r.GetVersion = (decltype(r.GetVersion))dlsym(r.h, "ncclGetVersion");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.GetErrorString && r.Send &&
            r.Recv && r.GroupStart && r.GroupEnd;
     return r;
@@ -649,6 +656,22 @@ int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float
             if (!std::isfinite(phi[j])) return fail(D2D_ERR_INVALID, "phi[%d] is not finite", j);
     int rc = set_device(c);
     if (rc) return rc;
+    // The scene that is resident already (a caller of the reference's API hands the objects over with every call): nothing
+    // to upload, and the wall-to-wall masks and the work history stay valid.  Only the candidate mask is reset, as always.
+    if (c->have_scene && c->N == n_objects && (n_objects == 0 || std::memcmp(c->xys.data(), xys, 4 * (size_t)n_objects * sizeof(float)) == 0)) {
+        bool same = true;
+        for (int j = 0; j < n_objects && same; ++j) {
+            same = c->kind[(size_t)j] == (kind ? kind[j] : (uint8_t)D2D_WALL);
+            const float ph = phi ? phi[j] : 0.78539816339744830962f;
+            same = same && std::memcmp(&c->phi[(size_t)j], &ph, sizeof(float)) == 0;
+        }
+        if (same) {
+            bool all = true;
+            for (int j = 0; j < n_objects; ++j) all = all && c->allowed[(size_t)j] != 0;
+            if (all) return D2D_OK;
+            return d2d_set_candidate_mask(c, nullptr);
+        }
+    }
     // from here on the old scene is gone: a failed upload leaves the context without a scene, never with half of one
     c->have_scene = false;
     c->have_vjp = false;          // d_vjp was sized for (and computed from) the previous scene
@@ -676,9 +699,14 @@ int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float
 
 int d2d_set_candidate_mask(d2d_ctx* c, const uint8_t* allowed) {
     if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
+    {
+        bool same = (int)c->allowed.size() == c->N && c->d_cw.p != nullptr;
+        for (int j = 0; j < c->N && same; ++j) same = (c->allowed[(size_t)j] != 0) == (allowed ? allowed[j] != 0 : true);
+        if (same) return D2D_OK;  // the mask in place already
+    }
     c->cost_tiles = 0;  // the patch-cost history describes another sweep
     for (int i = 0; i < d2d_ctx::N_SPARE; ++i) c->spare_sets[i].cost_tiles = 0;
-    if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come first");
     int rc = set_device(c);
     if (rc) return rc;
     if (allowed) c->allowed.assign(allowed, allowed + c->N);
@@ -711,30 +739,51 @@ int d2d_list_candidates(d2d_ctx* c, int32_t min_order, int32_t max_order, int32_
     return d2d_enumerate_candidates(c->N, c->allowed.data(), min_order, max_order, cand, order, capacity);
 }
 
-int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t n) {
+// token != 0: the caller vouches that equal tokens mean equal contents (an immutable array it has passed before); 0: the
+// contents are hashed.  A grid that is resident already is not uploaded again, and everything keyed to it -- the regions'
+// bounding boxes, the work history behind the patch schedule -- stays valid: a caller of the reference's API, which passes
+// X and Y with every call (scene.py:1803-1826, examples/plot_power_optimize.py:78-93), then runs at the resident rate.
+static int set_grid_impl(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t n, uint64_t token) {
     if (!c || !X || !Y) return fail(D2D_ERR_INVALID, "NULL argument");
-    c->cost_tiles = 0;  // the patch-cost history describes another sweep
-    for (int i = 0; i < d2d_ctx::N_SPARE; ++i) c->spare_sets[i].cost_tiles = 0;
-    c->grid_version += 1;  // ... and the regions' bounding boxes another grid
     if (m <= 0 || n <= 0) return fail(D2D_ERR_INVALID, "grid must be at least 1 x 1, got %d x %d", m, n);
     int rc = set_device(c);
     if (rc) return rc;
     size_t cells = (size_t)m * (size_t)n;
-    if ((rc = c->d_X.ensure(cells))) return rc;
-    if ((rc = c->d_Y.ensure(cells))) return rc;
-    if ((rc = c->d_out.ensure(cells))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->d_X.p, X, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_Y.p, Y, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_out.p, 0, cells * sizeof(float), c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->grid_absmax = 0.0f;
-    c->grid_all_finite = true;
-    for (size_t i = 0; i < cells; ++i) {
-        const float ax = std::fabs(X[i]), ay = std::fabs(Y[i]);
-        c->grid_all_finite = c->grid_all_finite && (ax < 1e18f) && (ay < 1e18f);
-        if (ax > c->grid_absmax) c->grid_absmax = ax;  // NaN compares false: such cells are handled by the kernel
-        if (ay > c->grid_absmax) c->grid_absmax = ay;
+    bool same = c->have_grid && c->m == m && c->n == n && c->d_X.p && c->d_Y.p && c->d_out.p;
+    uint64_t h = 0;
+    if (token != 0) {
+        same = same && c->grid_token == token;
+    } else {
+        h = d2d_host::hash_floats(Y, cells, d2d_host::hash_floats(X, cells, ((uint64_t)(uint32_t)m << 32) | (uint32_t)n));
+        same = same && c->grid_hash_valid && c->grid_hash == h;
     }
+    if (same) {
+        c->grid_reuses += 1;
+    } else {
+        c->have_grid = false;
+        c->cost_tiles = 0;  // the patch-cost history describes another sweep
+        for (int i = 0; i < d2d_ctx::N_SPARE; ++i) c->spare_sets[i].cost_tiles = 0;
+        c->grid_version += 1;  // ... and the regions' bounding boxes another grid
+        if ((rc = c->d_X.ensure(cells))) return rc;
+        if ((rc = c->d_Y.ensure(cells))) return rc;
+        if ((rc = c->d_out.ensure(cells))) return rc;
+        // (sweeps of the previous grid may still be in flight on the main stream: the copies are ordered behind them)
+        HIP_TRY(hipMemcpyAsync(c->d_X.p, X, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_Y.p, Y, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        c->grid_absmax = 0.0f;
+        c->grid_all_finite = true;
+        for (size_t i = 0; i < cells; ++i) {
+            const float ax = std::fabs(X[i]), ay = std::fabs(Y[i]);
+            c->grid_all_finite = c->grid_all_finite && (ax < 1e18f) && (ay < 1e18f);
+            if (ax > c->grid_absmax) c->grid_absmax = ax;  // NaN compares false: such cells are handled by the kernel
+            if (ay > c->grid_absmax) c->grid_absmax = ay;
+        }
+        c->grid_token = token;
+        c->grid_hash = h;
+        c->grid_hash_valid = token == 0;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_out.p, 0, cells * sizeof(float), c->stream));
+    if (!same) HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's buffers may go away
     c->m = m;
     c->n = n;
     c->have_grid = true;
@@ -742,6 +791,18 @@ int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t 
     c->have_vjp = false;
     c->have_grad = false;  // d_grad (if any) was sized for the previous grid
     c->gathered[0] = c->gathered[1] = 0;
+    return D2D_OK;
+}
+
+int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t n) { return set_grid_impl(c, X, Y, m, n, 0); }
+
+int d2d_set_grid_versioned(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t n, uint64_t version) {
+    return set_grid_impl(c, X, Y, m, n, version);
+}
+
+int d2d_debug_grid_reuses(d2d_ctx* c, int64_t* count) {
+    if (!c || !count) return fail(D2D_ERR_INVALID, "NULL argument");
+    *count = c->grid_reuses;
     return D2D_OK;
 }
 
@@ -804,6 +865,12 @@ static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, in
                         (long long)C, (long long)a.cells);
         const int n_elem = 5 * c->N + 2;  // [4N] object end points, [2] fixed end point, [N] phi
         if (p->out_mode == D2D_OUT_ADD && !c->have_grad) return fail(D2D_ERR_STATE, "D2D_OUT_ADD needs a previous value+grad sweep on this grid");
+        if (grad_mode == 2 && p->out_mode == D2D_OUT_ADD && c->have_vjp) {
+            if (!c->vjp_has_phi)
+                return fail(D2D_ERR_STATE, "D2D_OUT_ADD: the resident scene VJP comes from an ImagePath sweep; a MinPath / FermatPath sweep cannot be added to it");
+            if (c->vjp_reduced)
+                return fail(D2D_ERR_STATE, "D2D_OUT_ADD: the resident scene VJP has been all-reduced over ranks; fetch it, then start a new sum (D2D_OUT_OVERWRITE)");
+        }
         if ((rc = c->d_contrib.ensure((size_t)C * (size_t)a.cells))) return rc;
         if ((rc = c->d_gcontrib.ensure(2 * (size_t)C * (size_t)a.cells))) return rc;
         if ((rc = c->d_grad.ensure(2 * (size_t)a.cells))) return rc;
@@ -832,9 +899,10 @@ static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, in
         HIP_TRY(d2d::launch_opt_grad_reduce(c->d_contrib.p, c->d_gcontrib.p, (int)C, a.cells, c->d_out.p, c->d_grad.p, p->out_mode, c->stream));
         if (grad_mode == 2) {
             if ((rc = join_comm(c, 2))) return rc;  // the previous step's all-reduce has finished with d_vjp
-            // a VJP accumulated over several transmitters (D2D_OUT_ADD) must come from sweeps of one kind: the image-method
-            // sweeps leave the phi part untouched
-            const int accumulate = (p->out_mode == D2D_OUT_ADD && c->have_vjp && c->vjp_has_phi) ? 1 : 0;
+            // a VJP accumulated over several transmitters (D2D_OUT_ADD) must come from sweeps of one kind (the image-method
+            // sweeps have no phi part) and must still be this rank's own partial sum
+            const int accumulate = (p->out_mode == D2D_OUT_ADD && c->have_vjp) ? 1 : 0;
+            c->vjp_reduced = false;
             hipLaunchKernelGGL(d2d::vjp_reduce_kernel, dim3((unsigned)n_elem), dim3(256), 0, c->stream, c->d_partial.p, (long)rows, n_elem,
                                c->d_vjp.p, accumulate);
             HIP_TRY(hipGetLastError());
@@ -882,7 +950,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
 
     // Pipelined preparation (see d2d_ctx::PrepSet): this launch takes the set the launch before the previous one used,
     // and builds into it on the side stream, which first waits for the sweep that read it last.
-    const bool piped = c->pipeline && c->aux_stream != nullptr;
+    // (instrumented launches prepare on the main stream: their counters are zeroed there, and the list kernels add to them)
+    const bool piped = c->pipeline && c->aux_stream != nullptr && d_stats == nullptr;
     if (piped) {
         // rotate: the oldest set becomes the current one, the current one the newest spare
         auto swap_with = [&](d2d_ctx::PrepSet& o) {
@@ -1060,24 +1129,35 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     a.fb_list = nullptr;
     bool queue_impossible = false;
     if ((!txg || txg_culled) && c->use_region_lists && p->max_order >= 2 && c->cw.size() >= 2 && c->N <= 4095 && !(grad_mode && p->strict_nan)) {
+        // "region_budget_mb" bounds the device memory of ALL list pools: the pipeline keeps one per rotating set
+        const long long pool_cap_mb = std::max<long long>(1, c->region_budget_mb / (piped ? 1 + d2d_ctx::N_SPARE : 1));
         // how the previous launch's lists fared (read back without waiting: a launch or two late is early enough)
         if (c->meta_pending && hipEventQuery(c->ev_meta) == hipSuccess) {
             c->meta_pending = false;
             c->fb_hint = c->h_meta[0];
-            if ((long long)c->h_meta[1] + c->rl_meta_static > c->rl_meta_chunks && c->rl_pool_mb < c->region_budget_mb)
-                c->rl_pool_mb = std::min(c->region_budget_mb, c->rl_pool_mb * 4);  // the pool ran out: a bigger one from now on
+            if ((long long)c->h_meta[1] + c->pend_static > c->pend_chunks && c->rl_pool_mb < pool_cap_mb)
+                c->rl_pool_mb = std::min(pool_cap_mb, c->rl_pool_mb * 4);  // the pool ran out: a bigger one from now on
         }
-        if (c->rl_pool_mb > c->region_budget_mb) c->rl_pool_mb = c->region_budget_mb;
-        const d2d_host::RegionPlan rp =
+        if (c->rl_pool_mb > pool_cap_mb) c->rl_pool_mb = pool_cap_mb;
+        d2d_host::RegionPlan rp =
             d2d_host::region_plan(tiles_x, tiles_y, (long long)c->cw.size(), p->min_order, p->max_order, (int)c->region_size,
                                   (int)c->region_size_top, (int)c->region_slices, c->rl_pool_mb << 20, d2d::RL_CHUNK);
         const size_t lds_l = (size_t)(3 * c->N + 1) * sizeof(float4) + 512;                                         // tables + culling queue
         const size_t lds_r = (size_t)(3 * c->N + 1) * sizeof(float4) + (size_t)d2d::RL_GATHER * sizeof(unsigned long long);  // tables + gather buffer
         if (rp.on && lds_l <= d2d_host::LDS_LIMIT && lds_r <= d2d_host::LDS_LIMIT) {
+            // the pool is the one big allocation of the library: when the device cannot give it, this launch enumerates
+            // (same results) and later launches ask for a quarter
+            if (c->d_rl_pool.ensure((size_t)rp.max_chunks * d2d::RL_CHUNK) != D2D_OK || c->d_rl_next.ensure((size_t)rp.max_chunks) != D2D_OK) {
+                (void)hipGetLastError();
+                c->d_rl_pool.release();
+                c->d_rl_next.release();
+                c->rl_pool_mb = std::max<long long>(1, c->rl_pool_mb / 4);
+                rp.on = false;
+            }
+        }
+        if (rp.on && lds_l <= d2d_host::LDS_LIMIT && lds_r <= d2d_host::LDS_LIMIT) {
             const int orders = p->max_order - rp.k_lo + 1;
             const size_t per_order = (size_t)rp.leaf.slots + (size_t)rp.top.slots;
-            if ((rc = c->d_rl_pool.ensure((size_t)rp.max_chunks * d2d::RL_CHUNK))) return rc;
-            if ((rc = c->d_rl_next.ensure((size_t)rp.max_chunks))) return rc;
             if ((rc = c->d_rl_idx.ensure(per_order * (size_t)orders))) return rc;
             // meta (zeroed with the shadow masks above): [0] queue length, [1] pool head, [2 ..) leaf region flags
             int* const meta = reinterpret_cast<int*>(c->d_shadow.p + c->N + d2d::SCHED_KEYS);
@@ -1129,9 +1209,12 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             a.fb_n = meta;
             a.fb_list = c->d_rl_meta.p;
             if (!c->rl_host_valid || std::memcmp(&rl, &c->rl_host, sizeof rl) != 0) {
-                c->rl_host = rl;  // (the copy reads rl_host: it stays valid after this call returns)
+                // written by a kernel that takes the descriptor by value: stream-ordered, and nothing reads host memory
+                // after this call returns (a copy from a pageable member would be staged synchronously and drain `ps`)
+                c->rl_host = rl;
                 c->rl_host_valid = true;
-                HIP_TRY(hipMemcpyAsync(c->d_rl.p, &c->rl_host, sizeof rl, hipMemcpyHostToDevice, ps));
+                hipLaunchKernelGGL(d2d::write_region_lists_kernel, dim3(1), dim3(1), 0, ps, c->d_rl.p, rl);
+                HIP_TRY(hipGetLastError());
             }
             d2d::SweepArgs al = a;
             al.fb_n = nullptr;
@@ -1232,6 +1315,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             HIP_TRY(hipMemcpyAsync(c->h_meta, c->rl_meta_ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipEventRecord(c->ev_meta, c->stream));
             c->meta_pending = true;
+            c->pend_static = c->rl_meta_static;  // the plan THIS launch's counters belong to
+            c->pend_chunks = c->rl_meta_chunks;
         }
         return D2D_OK;
     };
@@ -1261,6 +1346,14 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     if (grad_mode) {
         const size_t cells = (size_t)c->m * c->n;
         if (p->out_mode == D2D_OUT_ADD && !c->have_grad) return fail(D2D_ERR_STATE, "D2D_OUT_ADD needs a previous value+grad sweep on this grid");
+        if (grad_mode == 2 && p->out_mode == D2D_OUT_ADD && c->have_vjp) {
+            // a scene VJP accumulated over several transmitters must come from sweeps of one kind (an ImagePath sweep has no
+            // phi part) and must still be this rank's own partial sum
+            if (c->vjp_has_phi)
+                return fail(D2D_ERR_STATE, "D2D_OUT_ADD: the resident scene VJP comes from a MinPath / FermatPath sweep; an ImagePath sweep cannot be added to it");
+            if (c->vjp_reduced)
+                return fail(D2D_ERR_STATE, "D2D_OUT_ADD: the resident scene VJP has been all-reduced over ranks; fetch it, then start a new sum (D2D_OUT_OVERWRITE)");
+        }
         if ((rc = c->d_grad.ensure(2 * cells))) return rc;
         c->have_grad = true;
         a.grad = c->d_grad.p;
@@ -1285,11 +1378,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
                 af.rl = nullptr; af.sched = nullptr; af.n_heavy = 0;
                 HIP_TRY(d2d::launch_fwd_grad(mode, false, p->max_order, dim3((unsigned)std::min<long long>(tiles, std::max<long long>(256, c->fb_hint))),
                                              lds2, c->stream, af));
-                if (!c->meta_pending && c->h_meta && (c->rl_launches <= 3 || c->rl_launches % 16 == 0)) {
-                    HIP_TRY(hipMemcpyAsync(c->h_meta, c->rl_meta_ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(hipEventRecord(c->ev_meta, c->stream));
-                    c->meta_pending = true;
-                }
+                if ((rc = read_back_meta())) return rc;
             }
         } else if (txg_culled) {
             // TX grid, culled value+grad sweep
@@ -1309,9 +1398,11 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         if (grad_mode == 2) {
             const long rows = (long)tiles;  // one row of partials per patch
             if ((rc = join_comm(c, 2))) return rc;  // the previous step's all-reduce has finished with d_vjp
+            const int accumulate = (p->out_mode == D2D_OUT_ADD && c->have_vjp) ? 1 : 0;
             c->vjp_has_phi = false;
+            c->vjp_reduced = false;
             hipLaunchKernelGGL(d2d::vjp_reduce_kernel, dim3((unsigned)n_elem), dim3(256), 0, c->stream, c->d_partial.p,
-                               rows, n_elem, c->d_vjp.p, (p->out_mode == D2D_OUT_ADD && c->have_vjp) ? 1 : 0);
+                               rows, n_elem, c->d_vjp.p, accumulate);
             HIP_TRY(hipGetLastError());
             c->have_vjp = true;
         }
@@ -1380,11 +1471,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         const dim3 gq((unsigned)std::min<long long>(tiles, std::max<long long>(256, c->fb_hint)));
         if (split) HIP_TRY(d2d::launch_fwd_split(mode, false, d_stats != nullptr, p->max_order, gq, split_lds, c->stream, af));
         else HIP_TRY(d2d::launch_fwd(mode, false, d_stats != nullptr, p->max_order, gq, tab_lds, c->stream, af));
-        if (!c->meta_pending && c->h_meta && (c->rl_launches <= 3 || c->rl_launches % 16 == 0)) {
-            HIP_TRY(hipMemcpyAsync(c->h_meta, c->rl_meta_ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipEventRecord(c->ev_meta, c->stream));
-            c->meta_pending = true;
-        }
+        if ((rc = read_back_meta())) return rc;
     }
     D2D_KERNEL_DONE();
     return D2D_OK;
@@ -1507,7 +1594,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 1024) return fail(D2D_ERR_INVALID, "region_slices must lie in 0..1024, got %lld", (long long)value);
         c->region_slices = value;
     } else if (!strcmp(name, "region_budget_mb")) {
-        if (value < 1 || value > (64ll << 10)) return fail(D2D_ERR_INVALID, "region_budget_mb must lie in 1..65536, got %lld", (long long)value);
+        if (value < 1 || value > (256ll << 10)) return fail(D2D_ERR_INVALID, "region_budget_mb must lie in 1..262144, got %lld", (long long)value);
         c->region_budget_mb = value;
         c->rl_pool_mb = std::min<long long>(256, value);
     }
@@ -1774,6 +1861,16 @@ int d2d_comm_init(d2d_ctx* c, const uint8_t* id, int32_t rank, int32_t world) {
     return D2D_OK;
 }
 
+int d2d_comm_count(d2d_ctx* c, int32_t* ranks) {
+    if (!c || !ranks) return fail(D2D_ERR_INVALID, "NULL argument");
+    if (!c->comm) return fail(D2D_ERR_STATE, "d2d_comm_init must come first");
+    if (!rccl().CommCount) return fail(D2D_ERR_COMM, "librccl has no ncclCommCount");
+    int n = 0;
+    RCCL_TRY(rccl().CommCount(c->comm, &n));
+    *ranks = n;
+    return D2D_OK;
+}
+
 int d2d_comm_destroy(d2d_ctx* c) {
     if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
     if (c->comm) {
@@ -1869,6 +1966,7 @@ int d2d_comm_allreduce_vjp(d2d_ctx* c) {
     RCCL_TRY(rccl().AllReduce(c->d_vjp.p, c->d_vjp.p, n, ncclFloat64, ncclSum, c->comm, c->comm_stream));
     HIP_TRY(hipEventRecord(c->ev_done[2], c->comm_stream));
     c->inflight[2] = true;
+    c->vjp_reduced = true;
     return D2D_OK;
 }
 

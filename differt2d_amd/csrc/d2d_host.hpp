@@ -31,6 +31,43 @@ inline float integer_pow(float x, int n) {
     return acc;
 }
 
+// 64-bit content hash of an fp32 array (bit patterns: -0.0 != 0.0, every NaN payload its own value), four independent
+// multiply-xor lanes over 8-byte words so that the loop runs at memory speed.  d2d_set_grid uses it to recognise a grid it
+// already holds (a caller of the reference's API passes X, Y with every call: scene.py:1803-1826).
+inline uint64_t hash_floats(const float* p, size_t n, uint64_t seed) {
+    const uint64_t K0 = 0x9E3779B97F4A7C15ull, K1 = 0xC2B2AE3D27D4EB4Full, K2 = 0x165667B19E3779F9ull, K3 = 0xD6E8FEB86659FD93ull;
+    uint64_t h0 = seed ^ K0, h1 = seed ^ K1, h2 = seed ^ K2, h3 = seed ^ K3;
+    size_t i = 0;
+    auto word = [&](size_t at) {
+        uint64_t w;
+        __builtin_memcpy(&w, p + at, 8);
+        return w;
+    };
+    for (; i + 8 <= n; i += 8) {
+        h0 = (h0 ^ word(i)) * K1;
+        h1 = (h1 ^ word(i + 2)) * K2;
+        h2 = (h2 ^ word(i + 4)) * K3;
+        h3 = (h3 ^ word(i + 6)) * K0;
+        h0 ^= h0 >> 29;
+        h1 ^= h1 >> 31;
+        h2 ^= h2 >> 30;
+        h3 ^= h3 >> 28;
+    }
+    for (; i < n; ++i) {
+        uint32_t w;
+        __builtin_memcpy(&w, p + i, 4);
+        h0 = (h0 ^ (uint64_t)w) * K2;
+        h0 ^= h0 >> 31;
+    }
+    uint64_t h = h0 ^ (h1 * K3) ^ (h2 * K0) ^ (h3 * K1) ^ ((uint64_t)n * K2);
+    h ^= h >> 33;
+    h *= 0xFF51AFD7ED558CCDull;
+    h ^= h >> 33;
+    h *= 0xC4CEB9FE1A85EC53ull;
+    h ^= h >> 33;
+    return h;
+}
+
 // candidates of order k over nc allowed objects: nc (nc - 1)^(k-1), 1 for k = 0; saturates at INT64_MAX
 inline int64_t count_order(int64_t nc, int k) {
     if (k == 0) return 1;

@@ -1725,6 +1725,15 @@ __device__ __forceinline__ long region_of(const SweepArgs& a, int tcol, int trow
 #ifndef D2D_HEAVY_PARTS
 #define D2D_HEAVY_PARTS 4
 #endif
+// Hand-over between the parts of a cut patch without cache maintenance (fwd_patch): relies on gfx9 encodings and on the
+// memory system of gfx942 / gfx950; every other target (and -DD2D_FENCE_FREE_HANDOVER=0) uses release / acquire.
+#ifndef D2D_FENCE_FREE_HANDOVER
+#if defined(__gfx942__) || defined(__gfx950__)
+#define D2D_FENCE_FREE_HANDOVER 1
+#else
+#define D2D_FENCE_FREE_HANDOVER 0
+#endif
+#endif
 constexpr int HEAVY_PARTS = D2D_HEAVY_PARTS;  // the dearest patches of a launch are cut into this many parts (power_fwd_kernel)
 constexpr int TILE_W = 8;  // a wave covers an 8 x 8 patch of RX cells: neighbouring cells share skips
 constexpr int TILE_H = 8;
@@ -1881,10 +1890,16 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
         // number it drew.
         __hip_atomic_store(&a.heavy_cnt[hq * 64 + lane], sink.over ? -1 : sink.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) __hip_atomic_store(&a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq], (int)st.work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int old = 0;
+#if D2D_FENCE_FREE_HANDOVER
+        // gfx942 / gfx950 only: the s_waitcnt immediate below is the gfx9 encoding, stores count in vmcnt there, and an
+        // sc1 store is acknowledged once it is visible at agent scope.  Any other target takes the portable branch.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (compiler ordering)
         __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): every store of the wave has been acknowledged
-        int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(&a.heavy_done[tile0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        if (lane == 0) old = __hip_atomic_fetch_add(&a.heavy_done[tile0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 #ifdef D2D_AB_TIMELINE
         if (a.grad && lane == 0) {
             reinterpret_cast<unsigned*>(a.grad)[2 * b0] = (unsigned)(((t_line0 & 0xffffull) << 16) | (__builtin_amdgcn_s_memrealtime() & 0xffffull));
@@ -1893,6 +1908,9 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
 #endif
         old = __builtin_amdgcn_readfirstlane(old);
         if (old != HEAVY_PARTS - 1) return;  // another part will finish the patch
+#if !D2D_FENCE_FREE_HANDOVER
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the finishing part only
+#endif
         unsigned work = 0;
         for (int q = 0; q < HEAVY_PARTS; ++q) {
             const long hq2 = tile0 * HEAVY_PARTS + q;
@@ -1909,7 +1927,7 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
             work += (unsigned)__hip_atomic_load(&a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         st.work = work;
-        if (lane == 0) a.heavy_done[tile0] = 0;  // ready for the next launch
+        if (lane == 0) __hip_atomic_store(&a.heavy_done[tile0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     } else {
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, GRADK>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, &g);
     unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -2701,6 +2719,9 @@ __global__ void __launch_bounds__(256) region_box_kernel(const float* __restrict
         box[region] = make_float4(anybad ? __builtin_nanf("") : x0, x1, y0, y1);
     }
 }
+
+// The lists' descriptor as the sweep kernels read it (a.rl), written in stream order from a by-value argument.
+__global__ void write_region_lists_kernel(RegionLists* __restrict__ dst, RegionLists v) { *dst = v; }
 
 // What a launch needs zeroed (shadow masks, sort counters, list bookkeeping): a kernel of its own rather than
 // hipMemsetAsync, which the runtime does not let run ahead on the side stream.

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define D2D_MAX_ORDER 4 /* highest interaction order a sweep accepts */
-#define D2D_ABI_VERSION 5
+#define D2D_ABI_VERSION 6
 
 typedef enum d2d_status {
     D2D_OK = 0,
@@ -117,6 +117,8 @@ int d2d_synchronize(d2d_ctx* ctx);
 /* objects: xys[N][2][2] (origin, dest; a Vertex stores its point in both rows), kind[N]
  * (D2D_WALL / D2D_RIS / D2D_VERTEX, NULL = all walls), phi[N] (RIS angle, NULL = pi/4). */
 int d2d_set_scene(d2d_ctx* ctx, const float* xys, const uint8_t* kind, const float* phi, int32_t n_objects);
+/* (A scene that is resident already -- bit-identical arguments -- is recognised: nothing is uploaded and the scene-only
+ * masks and the schedule's work history stay valid; the candidate mask is reset to "all" as always.) */
 
 /* filter_objects of Scene.all_path_candidates (differt2d/scene.py:1089-1134): allowed[i] != 0
  * means object i may appear in a path candidate; NULL = all. Filtered objects still occlude. */
@@ -144,8 +146,15 @@ int d2d_list_candidates(d2d_ctx* ctx, int32_t min_order, int32_t max_order, int3
  *      for one transmitter at a time; X, Y as produced by Plottable.grid, differt2d/abc.py:57-81) -------- */
 
 /* Uploads the receiver grid (row-major [m][n], any coordinates) and (re)allocates the resident
- * output maps; the value map is zeroed. */
+ * output maps; the value map is zeroed.  A grid that is resident already (same m, n and bit patterns: a 64-bit content
+ * hash decides) is not uploaded again and keeps everything keyed to it (the regions' bounding boxes, the work history of
+ * the patch schedule): the reference's callers pass X, Y with every call (differt2d/scene.py:1803-1826). */
 int d2d_set_grid(d2d_ctx* ctx, const float* X, const float* Y, int32_t m, int32_t n);
+/* The same with a caller-supplied version token instead of the content hash: version != 0 asserts that equal versions
+ * mean equal contents (an immutable array the caller has passed before, like the reference's JAX arrays); 0 = hash. */
+int d2d_set_grid_versioned(d2d_ctx* ctx, const float* X, const float* Y, int32_t m, int32_t n, uint64_t version);
+/* Diagnostic: how many d2d_set_grid / d2d_set_grid_versioned calls found their grid resident already. */
+int d2d_debug_grid_reuses(d2d_ctx* ctx, int64_t* count);
 
 /* Initial guesses of the optimiser-based solvers for the NEXT sweeps: theta0[n_candidates * many][D2D_MAX_ORDER]
  * (n_rows = n_candidates * max(1, params->many)), candidates in enumeration order, the `many` starts of one candidate
@@ -217,7 +226,8 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *                   lists are refined from those of regions of region_size_top patches a side (default 16, rounded down to
  *                   a multiple of region_size), which are built by enumeration
  *   "region_slices": lists per top region = slices of first walls = waves that enumerate it (default 0: a quarter of
- *                   the allowed objects); "region_budget_mb": device memory of the list pool (default 8192: an upper bound); a list
+ *                   the allowed objects); "region_budget_mb": device memory of ALL list pools (default 24576: an upper bound; the pipeline keeps one pool per
+ *                   rotating set, three in all, so a pool may grow to a third of it); a list
  *                   that does not fit is marked as not listed and the patches of its region enumerate (same results)
  *   "sched_key_mode": schedule keys from 0 (default) the work history if there is one, else the lengths of the region
  *                   lists, else the geometric proxy; 1 never the history; 2 never the lists
@@ -228,7 +238,8 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *   "side_stream": zero = the schedule's sort is never moved to a stream of its own; "fwd_waves": patches per workgroup
  *                   of the sweep with region lists (0 default: 4 when the per-wall LDS table is big, else 1)
  *   "region_budget_mb" also bounds the growth of the list pool: it starts at 256 MB and is quadrupled (up to the budget,
- *                   default 8192) when a launch's lists did not fit (read back without waiting)
+ *                   a third of it per pool) when a launch's lists did not fit (read back without waiting); when the device cannot
+ *                   provide the pool, the launch enumerates instead (same results) and later launches ask for a quarter
  *   "time_kernel": non-zero = bracket the sweep kernel of every launch with HIP events (see d2d_last_kernel_ms)
  * Also read once at d2d_create from the environment: D2D_SPLIT_MAX_TILES, D2D_SCHED_MIN_TILES. No reference counterpart
  * (XLA picks its own launch shapes). Returns D2D_ERR_INVALID for an unknown name. */
@@ -294,6 +305,8 @@ int d2d_comm_unique_id(uint8_t* id /* [D2D_COMM_ID_BYTES] */);
 /* Collective: ncclCommInitRank on the ctx's device. */
 int d2d_comm_init(d2d_ctx* ctx, const uint8_t* id, int32_t rank, int32_t world);
 int d2d_comm_destroy(d2d_ctx* ctx);
+/* Ranks of the communicator as RCCL itself reports them (ncclCommCount): what bench.py prints as `rccl_ranks`. */
+int d2d_comm_count(d2d_ctx* ctx, int32_t* ranks);
 /* Collective, asynchronous: all-gathers this rank's resident map (what = 0: value map, m*n floats; what = 1:
  * grad_rx map, m*n*2 floats; every rank must hold the same m, n) into a resident buffer [world][...]. The map is
  * first copied aside on the ctx stream and the all-gather runs on a second stream behind that copy, so the NEXT sweep

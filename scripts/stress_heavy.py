@@ -30,6 +30,24 @@ with Context(0) as ctx:
                     if not np.array_equal(got, refs[k], equal_nan=True):
                         bad += 1
                         print("MISMATCH approx", approx, "heavy", h, "launch", i, int((got != refs[k]).sum()), "cells")
+        # back to back without any host synchronisation, a different transmitter each launch: the launches
+        # accumulate into the map (D2D_OUT_ADD), so one read-back at the end observes every one of them -- a part's list
+        # read stale (the previous launch's bytes at the same addresses) would change the sum
+        import differt2d_amd._lib as L
+        p_add = make_params(max_order=2, approx=approx, out_mode=L.OUT_ADD)
+        for h in (-1, 64, 1024):
+            ctx.set_option("heavy_split", h)
+            for burst in (16, 61):
+                ctx.launch(p, txs[0])  # overwrite: the sum starts from refs[0]
+                want = refs[0].copy()
+                for i in range(burst):
+                    k = (i * 7 + 1) % len(txs)
+                    ctx.launch(p_add, txs[k])
+                    want = want + refs[k]  # fp32, in launch order
+                got = ctx.get_map()
+                if not np.array_equal(got, want, equal_nan=True):
+                    bad += 1
+                    print("MISMATCH (no host sync) approx", approx, "heavy", h, "burst", burst, int((got != want).sum()), "cells")
         print(f"approx={approx}: done", flush=True)
     print(f"stress: {bad} mismatching maps")
     sys.exit(1 if bad else 0)

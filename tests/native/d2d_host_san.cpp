@@ -30,6 +30,8 @@ int san_check_params(const d2d_params* p, char* msg, int cap) {
 
 float san_integer_pow(float x, int n) { return d2d_host::integer_pow(x, n); }
 
+uint64_t san_hash_floats(const float* p, uint64_t n, uint64_t seed) { return d2d_host::hash_floats(p, (size_t)n, seed); }
+
 void san_lds(int n_objects, int W, int list_len, uint64_t* tab, uint64_t* split_base, uint64_t* split_total) {
     *tab = d2d_host::tab_lds_bytes(n_objects);
     const d2d_host::SplitLds s = d2d_host::split_lds_bytes(n_objects, W, list_len);

@@ -398,3 +398,102 @@ def test_trace_paths_checks_the_number_of_theta0_rows():
             ctx.trace_paths(p, [[0.2, 0.2]], [[0.8, 0.6]], cands, theta0=[[0.5], [0.5]])
         out = ctx.trace_paths(p, [[0.2, 0.2]], [[0.8, 0.6]], cands, theta0=[[0.5], [0.5], [0.5]])
         assert out["xys"].shape[:2] == (1, 3)
+
+
+# ---- the reference's calling pattern at the resident rate -------------------------------------------
+
+
+def test_repeated_api_calls_reuse_the_resident_grid_and_the_work_history():
+    """A caller of the reference's API hands X, Y and the objects over with every call (scene.py:1803-1826).  The grid and the
+    scene that are resident already must be recognised -- immutable arrays by identity, writable ones by their content
+    hash -- so that nothing is uploaded again and the patch schedule keeps its work history (the keys of the schedule are
+    then the ones derived from the counted work, not the cold launch's proxy).  A grid that differs in one bit is a new grid."""
+    from differt2d_amd.engine import default_context
+    from differt2d_amd.geometry import Point
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import received_power
+    from conftest import random_scene
+
+    tx, walls = random_scene(30, seed=3)
+    scene = Scene.from_walls_array(walls).with_transmitters(tx=Point(xy=tx))
+    ctx = default_context()
+    ctx.set_option("sched_min_tiles", 1)
+    ctx.set_option("split_max_tiles", 0)
+    try:
+        x = np.linspace(0.0, 1.0, 160).astype(F)
+        n_patches = 20 * 20
+        for freeze in (True, False):
+            X, Y = np.meshgrid(x * F(0.999) if freeze else x, x)
+            if freeze:
+                X.setflags(write=False)
+                Y.setflags(write=False)
+            kw = dict(fun=received_power, reduce_all=True, max_order=2)
+            r0 = ctx.grid_reuses()
+            maps = [scene.accumulate_on_receivers_grid_over_paths(X, Y, **kw) for _ in range(6)]
+            assert ctx.grid_reuses() - r0 == 5  # every call after the first found its grid resident
+            assert all(np.array_equal(m, maps[0]) for m in maps)
+            # the schedule of the last launch was sorted by the work history (three launches old in the pipeline): its keys
+            # are the history's keys.  The counted work is deterministic, so the current history gives the same keys.
+            work = ctx.debug_get_work(n_patches)
+            order, key = ctx.debug_get_schedule(n_patches)
+            want = np.clip((8.0 * np.log2((work | 1).astype(np.float32))).astype(np.int64) - 16, 0, 255)
+            assert sorted(order.tolist()) == list(range(n_patches))
+            # (a patch that is cut in four records the sum of its parts' work, which counts the shared list culling four
+            # times: the dearest patches' keys move a little from launch to launch)
+            assert (np.abs(key.astype(np.int64) - want) <= 1).mean() >= 0.9 and len(np.unique(key)) > 8
+            assert (np.diff(key[order].astype(np.int64)) <= 0).all()  # dearest first
+            if not freeze:
+                Y2 = Y.copy()
+                Y2.view(np.uint32)[77, 5] ^= np.uint32(1)  # one bit: another grid (upload, no reuse)
+                r1 = ctx.grid_reuses()
+                m2 = scene.accumulate_on_receivers_grid_over_paths(X, Y2, **kw)
+                assert ctx.grid_reuses() == r1 and m2.shape == X.shape
+                with pytest.raises(Exception):
+                    ctx.debug_get_work(n_patches + 1)
+        # a changed object is a new scene: the history goes (debug_get_work raises until a sweep has run), results follow
+        from oracle import c_oracle as CO
+
+        assert np.array_equal(maps[0], CO.power_map(walls, tx, X, Y, min_order=0, max_order=2), equal_nan=True)
+        walls2 = walls.copy()
+        walls2[:, :, 0] += F(0.01)
+        scene2 = Scene.from_walls_array(walls2).with_transmitters(tx=Point(xy=tx))
+        a = scene2.accumulate_on_receivers_grid_over_paths(X, Y, **kw)
+        assert np.array_equal(a, CO.power_map(walls2, tx, X, Y, min_order=0, max_order=2), equal_nan=True)
+        assert not np.array_equal(a, maps[0])
+        # the candidate mask is reset by every call that has no filter (reference: filter_objects is per call)
+        b = scene2.accumulate_on_receivers_grid_over_paths(X, Y, filter_objects=lambda o: o is not scene2.objects[1], **kw)
+        c = scene2.accumulate_on_receivers_grid_over_paths(X, Y, **kw)
+        assert np.array_equal(c, a) and not np.array_equal(b, a)
+    finally:
+        ctx.set_option("sched_min_tiles", 2048)
+        ctx.set_option("split_max_tiles", 8192)
+
+
+def test_scene_vjp_accumulation_refuses_mixed_sweep_kinds():
+    """D2D_OUT_ADD adds a sweep's scene VJP to the resident one (reduce_all over transmitters).  Adding an ImagePath sweep to a
+    MinPath / FermatPath sweep's VJP (or the other way round) would silently drop or overwrite parts of it: D2D_ERR_STATE."""
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import default_context, make_params
+
+    ctx = default_context()
+    walls = np.array([[[0, 0], [1, 0]], [[1, 0], [1, 1]], [[1, 1], [0, 1]], [[0, 1], [0, 0]]], F)
+    ctx.set_scene(walls)
+    x = np.linspace(0.1, 0.9, 16).astype(F)
+    X, Y = np.meshgrid(x, x)
+    ctx.set_grid(X, Y)
+    tx = np.array([0.3, 0.4], F)
+    ctx.set_theta0([np.array([0.5, 0, 0, 0], F)] * 4)
+    img = dict(min_order=0, max_order=1, approx=True)
+    opt = dict(min_order=1, max_order=1, approx=True, solver="min", steps=5)
+    ctx.launch_vg(make_params(**img), tx, scene_vjp=True)
+    ctx.launch_vg(make_params(out_mode=L.OUT_ADD, **img), tx, scene_vjp=True)  # same kind: fine
+    one = ctx.get_scene_vjp()
+    with pytest.raises(L.D2DError) as e:
+        ctx.launch_vg(make_params(out_mode=L.OUT_ADD, **opt), tx, scene_vjp=True)
+    assert e.value.status == -5
+    assert np.array_equal(ctx.get_scene_vjp()[1], one[1])  # the refused launch left the resident VJP alone
+    ctx.launch_vg(make_params(**opt), tx, scene_vjp=True)
+    ctx.launch_vg(make_params(out_mode=L.OUT_ADD, **opt), tx, scene_vjp=True)
+    with pytest.raises(L.D2DError) as e:
+        ctx.launch_vg(make_params(out_mode=L.OUT_ADD, **img), tx, scene_vjp=True)
+    assert e.value.status == -5

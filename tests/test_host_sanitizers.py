@@ -149,6 +149,26 @@ def test_libd2d_host_logic_under_asan_and_ubsan(asan, tmp_path):
             for n in range(0, 9):
                 got = L.san_integer_pow(x, n)
                 assert got == np.float32(x) ** n or abs(got - float(np.float32(x)) ** n) <= 1e-6 * abs(got), (x, n, got)
+        # ---- content hash of a grid (d2d_set_grid): every length incl. odd tails read exactly (ASan), any single bit matters
+        L.san_hash_floats.restype = C.c_uint64
+        L.san_hash_floats.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        rng = np.random.default_rng(0)
+        seen = set()
+        for n in (0, 1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 1000, 4099):
+            a = rng.random(n, dtype=np.float32)   # EXACTLY n floats: reading past the end is an ASan report
+            h = L.san_hash_floats(a.ctypes.data_as(C.c_void_p), n, 5)
+            assert h == L.san_hash_floats(a.copy().ctypes.data_as(C.c_void_p), n, 5) and h not in seen
+            seen.add(h)
+            assert n == 0 or L.san_hash_floats(a.ctypes.data_as(C.c_void_p), n, 6) != h
+            for i in ([0, n // 2, n - 1] if n else []):
+                b = a.copy()
+                b.view(np.uint32)[i] ^= np.uint32(1 << int(rng.integers(0, 32)))
+                assert L.san_hash_floats(b.ctypes.data_as(C.c_void_p), n, 5) != h, (n, i)
+            if n >= 2:
+                b = a.copy(); b[0], b[1] = a[1], a[0]
+                assert (a[0] == a[1]) or L.san_hash_floats(b.ctypes.data_as(C.c_void_p), n, 5) != h
+        z, nz = np.zeros(4, np.float32), np.array([0.0, -0.0, 0.0, 0.0], np.float32)
+        assert L.san_hash_floats(z.ctypes.data_as(C.c_void_p), 4, 0) != L.san_hash_floats(nz.ctypes.data_as(C.c_void_p), 4, 0)  # bit patterns
         # ---- LDS sizes: monotone, aligned, inside each other
         prev = 0
         for n in (0, 1, 50, 200, 1023, 1024, 5000):

@@ -311,3 +311,38 @@ def test_cotangent_mask_zeroes_padding_rows():
     assert np.array_equal(m1[: len(sh.rows(1))], cot[sh.rows(1)]) and not m1[len(sh.rows(1)):].any()
     total = sum(sh.cotangent_mask(r, 3).sum() for r in range(2))
     assert total == 21 * 3  # every real cell exactly once
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher: the parent starts N children of itself with RANK /
+    WORLD_SIZE / LOCAL_RANK set, never touches HIP, relays rank 0's output and exits with the worst child's code.  On this
+    CPU box both children must get as far as creating their context (D2D_ERR_NO_DEVICE: there is no CPU fallback) -- not
+    stop at a launcher check."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    from differt2d_amd import _lib as L
+
+    if L.device_count() >= 2:  # a multi-GPU box: a full run, one JSON line from rank 0
+        import json
+
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["kernel_ms_per_rank"]) == 2
+        return
+    if L.device_count() == 1:  # one GPU: both ranks create their context on it, RCCL refuses two ranks on one device
+        assert out.returncode == 3, (out.returncode, out.stderr[-3000:])
+        for r in (0, 1):
+            assert f"[bench rank {r}] RCCL communicator unavailable" in out.stderr, out.stderr[-3000:]
+        return
+    assert out.returncode == 4, (out.returncode, out.stderr[-3000:])
+    for r in (0, 1):
+        assert f"[bench rank {r}] D2D_ERR_NO_DEVICE" in out.stderr, out.stderr[-3000:]
+    assert "must be launched with" not in out.stderr and out.stdout.strip() == ""
+    # under torch.distributed.run's environment the script is a rank itself and does not spawn anything
+    env.update(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-extras"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode == 4 and out.stderr.count("D2D_ERR_NO_DEVICE") == 1
