@@ -18,6 +18,7 @@
 #include "d2d_launch.hpp"
 #include "d2d_host.hpp"
 #include "d2d_optgrad.hpp"
+#include "d2d_optrev.hpp"
 
 // ---- mode dispatch of the sweep-kernel launchers (d2d_launch.hpp); the per-mode launchers live in the
 // d2d_sweep_tu objects, one per (kernel family, validity mode) ----
@@ -146,7 +147,10 @@ struct d2d_ctx {
     DevBuf<float2> d_sincos;
     DevBuf<float4> d_xys;  // raw end points {origin, dest} (gradient sweeps of the optimiser-based solvers)
     // optimiser-based solvers
-    DevBuf<float> d_bc1, d_bc2, d_theta0, d_contrib, d_gcontrib;
+    DevBuf<float> d_bc1, d_bc2, d_theta0, d_contrib, d_gcontrib, d_traj;
+    DevBuf<long long> d_traj_off;
+    long long opt_grad_mode = 0;    // gradients through the solvers: 0 reverse mode over the stored trajectory (d2d_optrev.hpp), 1 forward tangents (d2d_optgrad.hpp)
+    long long opt_traj_mb = 16384;  // device memory the trajectory store may take; grids that need more are swept in chunks of cells
     bool opt_parallel = true;  // optimiser-based sweeps: candidates side by side (same results as one after the other)
     int bc_steps = -1;
     std::vector<float> theta0;  // [C][D2D_MAX_ORDER] as set by d2d_set_theta0
@@ -254,6 +258,7 @@ struct d2d_ctx {
     bool swept_pending = false;
     hipEvent_t ev_prep = nullptr;       // recorded on aux_stream behind a launch's preparation
     bool pipeline = true;
+    bool prep_fused = true;             // shadow masks + zeroing in one kernel, the schedule's sort in one workgroup ("prep_fused" option; 0: round 2's chain)
     // RCCL (one communicator per ctx, collectives run on the ctx stream)
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -583,7 +588,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_cw.release();
     c->d_kind.release();
     c->d_sincos.release();
-    c->d_xys.release(); c->d_gcontrib.release();
+    c->d_xys.release(); c->d_gcontrib.release(); c->d_traj.release(); c->d_traj_off.release();
     c->d_bc1.release(); c->d_bc2.release(); c->d_theta0.release(); c->d_contrib.release(); c->d_scand.release(); c->d_sorder.release();
     c->d_tcand.release(); c->d_torder.release(); c->d_ttx.release(); c->d_trx.release();
     c->d_txys_in.release(); c->d_tloss_in.release(); c->d_txys.release(); c->d_tloss.release();
@@ -808,6 +813,8 @@ int d2d_debug_grid_reuses(d2d_ctx* c, int64_t* count) {
 
 // MinPath / FermatPath sweep: explicit candidate list (these sweeps have few candidates), theta0 per candidate.
 // grad_mode: 0 values; 1 + per-cell gradient; 2 + scene VJP (d2d_optgrad.hpp: tangents carried through the Adam loop).
+static inline long long steps_of(const d2d_params* p) { return p->steps; }
+
 static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, int grad_mode) {
     int rc;
     if ((rc = set_device(c))) return rc;
@@ -890,8 +897,47 @@ static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, in
             if (p->out_mode == D2D_OUT_OVERWRITE) c->have_vjp = false;
         }
         c->have_grad = true;
+        // reverse mode: the trajectories of the solver (4 floats per step and unknown) go through HBM
+        d2d::OptRevArgs ra;
+        memset(&ra, 0, sizeof ra);
+        long long chunk_cells = 0;
+        if (c->opt_grad_mode == 0) {
+            std::vector<long long> off((size_t)C + 1, 0);
+            for (int64_t i = 0; i < C; ++i) {
+                int nu = 0;
+                for (int q = 0; q < order[(size_t)i]; ++q) nu += c->kind[cand[(size_t)i * D2D_MAX_ORDER + q]] != D2D_VERTEX ? 1 : 0;
+                off[(size_t)i + 1] = off[(size_t)i] + 4ll * steps_of(p) * nu;
+            }
+            const long long per_cell = std::max<long long>(1, off[(size_t)C]);  // floats per cell, all candidates
+            const long long cells_pad = ((long long)a.cells + 63) / 64 * 64;
+            const long long budget = std::max<long long>(c->opt_traj_mb, 1) << 20;
+            chunk_cells = std::min<long long>(cells_pad, std::max<long long>(64, budget / (4 * per_cell) / 64 * 64));
+            if ((rc = c->d_traj.ensure((size_t)(chunk_cells * per_cell)))) return rc;
+            if ((rc = c->d_traj_off.ensure((size_t)C + 1))) return rc;
+            HIP_TRY(hipMemcpyAsync(c->d_traj_off.p, off.data(), ((size_t)C + 1) * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));  // (the host vector goes out of scope)
+            ra.g = g;
+            ra.traj = c->d_traj.p;
+            ra.traj_off = c->d_traj_off.p;
+            ra.total_blocks = blocks;
+        }
         if (c->time_kernel) HIP_TRY(hipEventRecord(c->evk0, c->stream));
-        HIP_TRY(d2d::launch_opt_grad(g, dim3(blocks, (unsigned)C), (size_t)n_elem * sizeof(float), c->stream));
+        if (c->opt_grad_mode == 0) {
+            for (long long cell0 = 0; cell0 < (long long)a.cells; cell0 += chunk_cells) {
+                ra.cell0 = (long)cell0;
+                ra.chunk_cells = (long)std::min<long long>(chunk_cells, (long long)a.cells - cell0);
+                ra.stride = (long)((ra.chunk_cells + 63) / 64 * 64);
+                for (int64_t c0 = 0; c0 < C;) {  // one launch per order: a contiguous range of the enumeration
+                    int64_t c1 = c0 + 1;
+                    while (c1 < C && order[(size_t)c1] == order[(size_t)c0]) ++c1;
+                    HIP_TRY(d2d::launch_opt_rev(order[(size_t)c0], ra, (int)c0, dim3((unsigned)(ra.stride / 64), (unsigned)(c1 - c0)),
+                                                (size_t)n_elem * sizeof(float), c->stream));
+                    c0 = c1;
+                }
+            }
+        } else {
+            HIP_TRY(d2d::launch_opt_grad(g, dim3(blocks, (unsigned)C), (size_t)n_elem * sizeof(float), c->stream));
+        }
         if (c->time_kernel) {
             HIP_TRY(hipEventRecord(c->evk1, c->stream));
             c->have_kernel_time = true;
@@ -952,6 +998,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     // and builds into it on the side stream, which first waits for the sweep that read it last.
     // (instrumented launches prepare on the main stream: their counters are zeroed there, and the list kernels add to them)
     const bool piped = c->pipeline && c->aux_stream != nullptr && d_stats == nullptr;
+    bool set_was_swept = false;  // the set this launch takes was read by a sweep that may still be running (ev_swept says when it is through)
     if (piped) {
         // rotate: the oldest set becomes the current one, the current one the newest spare
         auto swap_with = [&](d2d_ctx::PrepSet& o) {
@@ -973,6 +1020,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         };
         swap_with(c->spare_sets[0]);                                   // cur <- [0] (the oldest), [0] <- cur
         for (int i = 0; i + 1 < d2d_ctx::N_SPARE; ++i) std::swap(c->spare_sets[i], c->spare_sets[i + 1]);  // .. which moves to the newest place
+        set_was_swept = c->swept_pending;
         if (c->swept_pending) HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_swept, 0));
         c->swept_pending = false;
     }
@@ -1070,23 +1118,37 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         // (a multiple of 256 bytes: the runtime fills odd tails with a second kernel)
         const size_t zero_words = ((size_t)c->N + d2d::SCHED_KEYS + (2 + rl_regions + 1) / 2 + 31) & ~(size_t)31;
         if ((rc = c->d_shadow.ensure(zero_words))) return rc;
-        hipLaunchKernelGGL(d2d::zero_words_kernel, dim3((unsigned)((zero_words + 255) / 256)), dim3(256), 0, ps, c->d_shadow.p, (long)zero_words);
-        HIP_TRY(hipEventRecord(c->ev_fork, ps));  // (the schedule's sort may start here, on a stream of its own)
+        if (!c->prep_fused) {
+            hipLaunchKernelGGL(d2d::zero_words_kernel, dim3((unsigned)((zero_words + 255) / 256)), dim3(256), 0, ps, c->d_shadow.p, (long)zero_words);
+            HIP_TRY(hipEventRecord(c->ev_fork, ps));  // (the schedule's sort may start here, on a stream of its own)
+        }
         prep_zeroed = true;
         // window where a test is certainly "hit" (hard) / exactly saturated to 1 (approx): shrink [-tol, 1+tol] by widen
         const double in_lo = -(double)p->seg_tol + widen_in, in_hi = 1.0 + (double)p->seg_tol - widen_in;
         float ext = std::fmax(std::fmax(c->scene_absmax, c->grid_absmax), std::fmax(std::fabs(tx[0]), std::fabs(tx[1])));
         bool pair_ext_ok = false;
-        if (in_hi > in_lo + 1e-3 && std::isfinite(ext) && ext > 0.0f) {
-            const float dperp = 4096.0f * 1.1920929e-07f * ext * (float)(p->max_order + 1);
-            const int pairs = c->N * c->N;
-            // bins span the parametric window in which on_objects is not exactly 0 (+ a little)
-            const double dom_lo = (double)a.on_lo - 2e-3, dom_hi = (double)a.on_hi + 2e-3;
-            const double dom_w = (dom_hi - dom_lo) / 64.0;
-            hipLaunchKernelGGL(d2d::shadow_tx_kernel, dim3((unsigned)pairs), dim3(64), 0, ps, c->d_occl.p,
-                               c->d_refl.p, c->d_kind.p, c->N, tx[0], tx[1], (float)(in_lo + 1e-4), (float)(in_hi - 1e-4), dperp,
-                               (float)dom_lo, (float)dom_w, c->d_shadow.p);
+        const bool masks_ok = in_hi > in_lo + 1e-3 && std::isfinite(ext) && ext > 0.0f;
+        // bins span the parametric window in which on_objects is not exactly 0 (+ a little)
+        const double dom_lo = (double)a.on_lo - 2e-3, dom_hi = (double)a.on_hi + 2e-3;
+        const double dom_w = (dom_hi - dom_lo) / 64.0;
+        const float dperp = 4096.0f * 1.1920929e-07f * (masks_ok ? ext : 1.0f) * (float)(p->max_order + 1);
+        if (c->prep_fused) {
+            // one kernel: the masks (stored, not OR-ed: nothing to zero in front) and the zeroing of everything behind them
+            const long n_zero = (long)zero_words - c->N;
+            hipLaunchKernelGGL(d2d::shadow_fill_kernel, dim3((unsigned)(c->N + (n_zero + 255) / 256)), dim3(256), 0, ps, c->d_occl.p, c->d_refl.p,
+                               c->d_kind.p, c->N, tx[0], tx[1], (float)(in_lo + 1e-4), (float)(in_hi - 1e-4), dperp, (float)dom_lo, (float)dom_w,
+                               masks_ok ? 1 : 0, c->d_shadow.p, c->d_shadow.p + c->N, n_zero);
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev_fork, ps));  // (the sort of a big launch needs its counters zeroed: it may start here)
+        }
+        if (masks_ok) {
+            if (!c->prep_fused) {
+                const int pairs = c->N * c->N;
+                hipLaunchKernelGGL(d2d::shadow_tx_kernel, dim3((unsigned)pairs), dim3(64), 0, ps, c->d_occl.p,
+                                   c->d_refl.p, c->d_kind.p, c->N, tx[0], tx[1], (float)(in_lo + 1e-4), (float)(in_hi - 1e-4), dperp,
+                                   (float)dom_lo, (float)dom_w, c->d_shadow.p);
+                HIP_TRY(hipGetLastError());
+            }
             a.shadow = c->d_shadow.p;
             a.shadow_dperp = dperp;
             a.shadow_lo = (float)dom_lo;
@@ -1265,15 +1327,26 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         {
             // keys from the work history depend on nothing this launch has built: the sort then runs on the side stream,
             // beside the shadow masks and the region lists, behind the memset of its counters
-            const bool side = from_history && prep_zeroed && c->use_aux && (piped ? c->sort_stream : c->aux_stream) != nullptr;
+            const bool one_wg = c->prep_fused && tiles <= d2d::SORT1_MAX;  // the whole sort in one workgroup's LDS: nothing zeroed, nothing to wait for
+            const bool side = from_history && (prep_zeroed || (one_wg && piped)) && c->use_aux && (piped ? c->sort_stream : c->aux_stream) != nullptr;
             hipStream_t ss = side ? (piped ? c->sort_stream : c->aux_stream) : ps;
-            if (side) HIP_TRY(hipStreamWaitEvent(ss, c->ev_fork, 0));
-            const unsigned sort_blocks = (unsigned)((tiles + 256 * d2d::SCHED_PER_THREAD - 1) / (256 * d2d::SCHED_PER_THREAD));
-            hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, ss, c->d_sched_key.p,
-                               from_history ? c->d_cost.p : (const unsigned*)nullptr, hist, (long)tiles,
-                               from_lists ? a.rl : (const d2d::RegionLists*)nullptr, tiles_x, c->rl_plan.k_lo, p->max_order);
-            hipLaunchKernelGGL(d2d::patch_order_kernel, dim3(sort_blocks), dim3(256), 0, ss, c->d_sched_key.p, hist,
-                               hist + d2d::SCHED_KEYS, c->d_sched.p, (long)tiles);
+            // (ev_fork sits on `ps` behind the zeroing; without the pipeline `ps` is the main stream, i.e. also behind the
+            // previous sweep, whose work counters the sort reads)
+            if (side && (!one_wg || !piped)) HIP_TRY(hipStreamWaitEvent(ss, c->ev_fork, 0));
+            // (the one-workgroup sort waits for nothing this launch builds -- only for the sweep that last read this set's schedule)
+            if (side && one_wg && piped && set_was_swept) HIP_TRY(hipStreamWaitEvent(ss, c->ev_swept, 0));
+            if (one_wg) {
+                hipLaunchKernelGGL(d2d::patch_sort_kernel, dim3(1), dim3(d2d::SORT1_THREADS), 0, ss, c->d_sched_key.p,
+                                   from_history ? c->d_cost.p : (const unsigned*)nullptr, c->d_sched.p, (long)tiles,
+                                   from_lists ? a.rl : (const d2d::RegionLists*)nullptr, tiles_x, c->rl_plan.k_lo, p->max_order);
+            } else {
+                const unsigned sort_blocks = (unsigned)((tiles + 256 * d2d::SCHED_PER_THREAD - 1) / (256 * d2d::SCHED_PER_THREAD));
+                hipLaunchKernelGGL(d2d::patch_hist_kernel, dim3(sort_blocks), dim3(256), 0, ss, c->d_sched_key.p,
+                                   from_history ? c->d_cost.p : (const unsigned*)nullptr, hist, (long)tiles,
+                                   from_lists ? a.rl : (const d2d::RegionLists*)nullptr, tiles_x, c->rl_plan.k_lo, p->max_order);
+                hipLaunchKernelGGL(d2d::patch_order_kernel, dim3(sort_blocks), dim3(256), 0, ss, c->d_sched_key.p, hist,
+                                   hist + d2d::SCHED_KEYS, c->d_sched.p, (long)tiles);
+            }
             if (side) {
                 HIP_TRY(hipEventRecord(c->ev_join, ss));
                 HIP_TRY(hipStreamWaitEvent(ps, c->ev_join, 0));
@@ -1581,7 +1654,15 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
         c->fwd_waves = value;
     }
     else if (!strcmp(name, "pair_masks")) c->use_pair_masks = value != 0;
+    else if (!strcmp(name, "prep_fused")) c->prep_fused = value != 0;
     else if (!strcmp(name, "opt_parallel")) c->opt_parallel = value != 0;
+    else if (!strcmp(name, "opt_grad_mode")) {
+        if (value != 0 && value != 1) return fail(D2D_ERR_INVALID, "opt_grad_mode must be 0 (reverse mode) or 1 (forward tangents), got %lld", (long long)value);
+        c->opt_grad_mode = value;
+    } else if (!strcmp(name, "opt_traj_mb")) {
+        if (value < 1 || value > (256ll << 10)) return fail(D2D_ERR_INVALID, "opt_traj_mb must lie in 1..262144, got %lld", (long long)value);
+        c->opt_traj_mb = value;
+    }
     else if (!strcmp(name, "txg_exhaustive")) c->txg_exhaustive = value != 0;
     else if (!strcmp(name, "region_lists")) c->use_region_lists = value != 0;
     else if (!strcmp(name, "region_size")) {

@@ -52,6 +52,22 @@ __device__ __forceinline__ int4 ldc4i(const int4* p, long i) {
     return make_int4(v.x, v.y, v.z, v.w);
 }
 
+// A field of the kernel's own argument block, read WHERE IT IS NEEDED (the compiler loads every argument at the top of a
+// kernel and keeps it in a scalar register until its last use: the pointers a sweep only needs for its final stores -- map,
+// work counters, the cut patches' hand-over -- then occupy registers through the whole candidate loop, and what does not fit
+// is parked in VGPR lanes: 82 parked scalars in the hot kernel before, 58 with these late reads).  Valid in kernels whose
+// FIRST parameter is the struct, by value (kernarg offset 0).
+template <typename T, unsigned OFF>
+__device__ __forceinline__ T late_kernarg() {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "one or two dwords");
+    const auto base = __builtin_amdgcn_kernarg_segment_ptr();
+    T v;
+    if constexpr (sizeof(T) == 8) asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "i"(OFF));
+    else asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(base), "i"(OFF));
+    return v;
+}
+#define D2D_LATE_ARG(T, field) late_kernarg<T, (unsigned)__builtin_offsetof(SweepArgs, field)>()
+
 enum Mode { MODE_HARD = 0, MODE_HSIG = 1, MODE_SIG = 2 };
 
 // Region candidate lists: for every order K >= 2, every region of R x R patches and every slice of first-wall positions,
@@ -1888,17 +1904,20 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
         // atomic stores: sc1 write-through), the wave waits until those stores are acknowledged (vmcnt(0)) before it
         // draws its number, and the finishing part reads with agent-scope loads (sc1), issued behind the branch on the
         // number it drew.
-        __hip_atomic_store(&a.heavy_cnt[hq * 64 + lane], sink.over ? -1 : sink.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0) __hip_atomic_store(&a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq], (int)st.work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int* const heavy_cnt = D2D_LATE_ARG(int*, heavy_cnt);
+        int* const heavy_done = D2D_LATE_ARG(int*, heavy_done);
+        const int n_heavy_l = D2D_LATE_ARG(int, n_heavy), heavy_cap_l = D2D_LATE_ARG(int, heavy_cap);
+        __hip_atomic_store(&heavy_cnt[hq * 64 + lane], sink.over ? -1 : sink.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(&heavy_cnt[(long)n_heavy_l * HEAVY_PARTS * 64 + hq], (int)st.work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int old = 0;
 #if D2D_FENCE_FREE_HANDOVER
         // gfx942 / gfx950 only: the s_waitcnt immediate below is the gfx9 encoding, stores count in vmcnt there, and an
         // sc1 store is acknowledged once it is visible at agent scope.  Any other target takes the portable branch.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (compiler ordering)
         __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): every store of the wave has been acknowledged
-        if (lane == 0) old = __hip_atomic_fetch_add(&a.heavy_done[tile0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) old = __hip_atomic_fetch_add(&heavy_done[tile0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-        if (lane == 0) old = __hip_atomic_fetch_add(&a.heavy_done[tile0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) old = __hip_atomic_fetch_add(&heavy_done[tile0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 #ifdef D2D_AB_TIMELINE
         if (a.grad && lane == 0) {
@@ -1914,20 +1933,20 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
         unsigned work = 0;
         for (int q = 0; q < HEAVY_PARTS; ++q) {
             const long hq2 = tile0 * HEAVY_PARTS + q;
-            int n = __hip_atomic_load(&a.heavy_cnt[hq2 * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool bad = n < 0 || n > a.heavy_cap;  // cannot happen (heavy_cap covers every candidate); never silently wrong
+            int n = __hip_atomic_load(&heavy_cnt[hq2 * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool bad = n < 0 || n > heavy_cap_l;  // cannot happen (heavy_cap covers every candidate); never silently wrong
             n = bad ? 0 : n;
             int nmax = n;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
-            const int* col = reinterpret_cast<const int*>(a.heavy_list) + hq2 * (long)a.heavy_cap * 64 + lane;
+            const int* col = reinterpret_cast<const int*>(D2D_LATE_ARG(float*, heavy_list)) + hq2 * (long)heavy_cap_l * 64 + lane;
             for (int i = 0; i < nmax; ++i)
                 if (i < n) acc = acc + __int_as_float(__hip_atomic_load(&col[i * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // scene.py:1909, in candidate order
             if (bad) acc = __builtin_nanf("");
-            work += (unsigned)__hip_atomic_load(&a.heavy_cnt[(long)a.n_heavy * HEAVY_PARTS * 64 + hq2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            work += (unsigned)__hip_atomic_load(&heavy_cnt[(long)n_heavy_l * HEAVY_PARTS * 64 + hq2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         st.work = work;
-        if (lane == 0) __hip_atomic_store(&a.heavy_done[tile0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        if (lane == 0) __hip_atomic_store(&heavy_done[tile0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     } else {
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, GRADK>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, &g);
     unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1943,18 +1962,22 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_any<3, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
     if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_any<4, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
     }
-    if (in_range) {
-        if (a.out_mode == D2D_OUT_ADD) {
-            a.out[idx] = a.out[idx] + acc;
-            if (GRADK) {
-                a.grad[2 * idx] = a.grad[2 * idx] + g.grx;
-                a.grad[2 * idx + 1] = a.grad[2 * idx + 1] + g.gry;
-            }
-        } else {
-            a.out[idx] = acc;
-            if (GRADK) {
-                a.grad[2 * idx] = g.grx;
-                a.grad[2 * idx + 1] = g.gry;
+    {
+        float* const out = D2D_LATE_ARG(float*, out);
+        const int out_mode = D2D_LATE_ARG(int, out_mode);
+        if (in_range) {
+            if (out_mode == D2D_OUT_ADD) {
+                out[idx] = out[idx] + acc;
+                if (GRADK) {
+                    a.grad[2 * idx] = a.grad[2 * idx] + g.grx;
+                    a.grad[2 * idx + 1] = a.grad[2 * idx + 1] + g.gry;
+                }
+            } else {
+                out[idx] = acc;
+                if (GRADK) {
+                    a.grad[2 * idx] = g.grx;
+                    a.grad[2 * idx + 1] = g.gry;
+                }
             }
         }
     }
@@ -1963,7 +1986,10 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
         tby_sum += wave_sum(g.tby);
     }
     if (STATS && lane == 0 && a.wave_cycles) a.wave_cycles[tile] = __builtin_amdgcn_s_memtime() - t_start;
-    if (!STATS && a.cost_out && lane == 0) a.cost_out[tile] = st.work;
+    if (!STATS) {
+        unsigned* const cost_out = D2D_LATE_ARG(unsigned*, cost_out);
+        if (cost_out && lane == 0) cost_out[tile] = st.work;
+    }
 #ifdef D2D_AB_TIMELINE  // diagnostic build (scripts/timeline.py): start / end stamps of every workgroup, beside the work history
     if (!STATS && !GRADK && a.grad && lane == 0)
     if (!quarter) {
@@ -1998,8 +2024,22 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
 #else
 #define D2D_SGPR_ATTR
 #endif
+// Minimum waves per SIMD asked of the register allocator, A/B only.  The order-2 sweep from the region lists -- the benchmark's
+// kernel -- fits 7 waves (71 VGPRs, no scratch, -DD2D_FWD_WAVES_L2=7) now that its cold arguments are read late (late_kernarg:
+// 82 -> 58 parked scalars); unconstrained the allocator stops at 73, one register past the 72 that 7 waves allow.  Measured on
+// the MI355X (round 3, scripts/ab_build.sh "w1:-DD2D_FWD_WAVES_L2=1" "w7:-DD2D_FWD_WAVES_L2=7", two runs each): sweep kernel
+// 0.098 ms at 6 waves, 0.099 - 0.100 ms at 7 (90 parked scalars), step 0.110 - 0.113 vs 0.119 ms: residency is not what
+// bounds the kernel (mean 4.9 waves per SIMD over the launch: it is never full for long).  Default: unconstrained.
+#ifndef D2D_FWD_WAVES_L2
+#define D2D_FWD_WAVES_L2 1
+#endif
+constexpr int fwd_min_waves(int mode, bool stats, int maxk, bool gradk, bool listed, int wpb) {
+    if (wpb != 1) return 1;
+    if (listed && maxk == 2 && !gradk && !stats && mode == MODE_HARD) return D2D_FWD_WAVES_L2;
+    return D2D_FWD_WAVES;
+}
 template <int MODE, bool STATS, int MAXK, bool GRADK = false, bool LISTED = false, int WPB = 1>
-__global__ void __launch_bounds__(64 * WPB, WPB == 1 ? D2D_FWD_WAVES : 1) D2D_SGPR_ATTR power_fwd_kernel(SweepArgs a) {
+__global__ void __launch_bounds__(64 * WPB, fwd_min_waves(MODE, STATS, MAXK, GRADK, LISTED, WPB)) D2D_SGPR_ATTR power_fwd_kernel(SweepArgs a) {
     const int lane = threadIdx.x & 63;
     // LDS copy of the per-wall tables for the lanes-as-candidates phase (lane-varying wall index), staged once per wave
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then (GRADK) [N] float4 = the wave's scene-VJP partial sums
@@ -2674,6 +2714,65 @@ __global__ void __launch_bounds__(256) patch_order_kernel(const unsigned char* _
     }
 }
 
+// The two passes above in ONE workgroup (launches of up to SORT1_MAX patches: 1024^2 has 16 384): keys, histogram, offsets and
+// scatter all in LDS, nothing to zero beforehand and nothing for a second kernel to wait for.  Each of the 16 waves counts
+// into its own 256 bins, so a wave's atomics only contend with themselves; within a key the patches are placed wave by wave
+// (wave w takes the patches t with (t / 64) % 16 == w), inside a wave in atomic order: the schedule may differ from run to
+// run, the results cannot.  Beside a sweep that fills the chip this is one workgroup of 1024 threads instead of 2 x 16 of 256.
+constexpr int SORT1_THREADS = 1024;
+constexpr long SORT1_MAX = 1 << 16;
+__global__ void __launch_bounds__(SORT1_THREADS) patch_sort_kernel(unsigned char* __restrict__ key, const unsigned* __restrict__ cost,
+                                                                   int* __restrict__ sched, long n_tiles, const RegionLists* __restrict__ lists,
+                                                                   int tiles_x, int k_lo, int k_hi) {
+    constexpr int W = SORT1_THREADS / 64;
+    __shared__ int cnt[W][SCHED_KEYS];  // per wave: patches per key, then the wave's cursor within the key
+    __shared__ int tot[SCHED_KEYS];
+    const int wv = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < W * SCHED_KEYS; i += SORT1_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    // pass 1: keys (work history, list lengths, or given) and per-wave histograms
+    for (long t = threadIdx.x; t < n_tiles; t += SORT1_THREADS) {
+        unsigned char k;
+        if (lists) {
+            const int R = lists->leaf.R;
+            const long region = (long)((int)(t / tiles_x) / R) * lists->leaf.regions_x + ((int)(t % tiles_x) / R);
+            unsigned len = 4;
+            for (int o = k_lo; o <= k_hi; ++o) {
+                const int c = lists->leaf.cnt[o][region];
+                len += c > 0 ? (unsigned)c : 0u;
+            }
+            k = key_from_cost(len << 4);
+            key[t] = k;
+        } else if (cost) {
+            k = key_from_cost(cost[t]);
+            key[t] = k;
+        } else {
+            k = key[t];
+        }
+        atomicAdd(&cnt[wv][k], 1);
+    }
+    __syncthreads();
+    // offsets: key descending (dearest first), within a key wave ascending
+    if (threadIdx.x < SCHED_KEYS) {
+        int s = 0;
+        for (int w = 0; w < W; ++w) s += cnt[w][threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < SCHED_KEYS) {
+        int s = 0;
+        for (int k = SCHED_KEYS - 1; k > (int)threadIdx.x; --k) s += tot[k];
+        for (int w = 0; w < W; ++w) {
+            const int c = cnt[w][threadIdx.x];
+            cnt[w][threadIdx.x] = s;  // from a count to the wave's first slot
+            s += c;
+        }
+    }
+    __syncthreads();
+    // pass 2: scatter (same thread -> same patches -> same wave as in pass 1)
+    for (long t = threadIdx.x; t < n_tiles; t += SORT1_THREADS) sched[atomicAdd(&cnt[wv][key[t]], 1)] = (int)t;
+}
+
 // Bounding boxes of the cells of every region of R x R patches (one 256-thread workgroup per region): {x0, x1, y0, y1},
 // x0 = NaN when some cell is not comfortably finite.  Depends on the grid only: rebuilt when the grid or R changes.
 __global__ void __launch_bounds__(256) region_box_kernel(const float* __restrict__ X, const float* __restrict__ Y, int m, int n, int R,
@@ -2746,19 +2845,15 @@ __global__ void selftest_div_kernel(const float* __restrict__ x, const float* __
 // p within `dperp` of the bin.  t_a, t_b are linear-fractional in p, so on a thin quad around a bin that does not meet
 // the pole (fd keeps its sign) their ranges are spanned by the 4 vertices.  Margins: 8 eps per product sum for the
 // rounding of either evaluation chain.  Only bins certified at all four vertices are set (atomicOr).
-__global__ void shadow_tx_kernel(const float4* __restrict__ occl, const float4* __restrict__ refl,
-                                 const unsigned char* __restrict__ kind, int N, float ex, float ey, float win_lo, float win_hi,
-                                 float dperp, float dom_lo, float dom_w, unsigned long long* __restrict__ shadow) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = (int)(gid & 63);       // one lane per bin: a wave = one (w, j) pair, its ballot = the pair's 64 bits
-    const long idx = gid >> 6;
-    if (idx >= (long)N * N) return;
-    const int w = (int)(idx / N), j = (int)(idx % N);
-    if (w == j) return;                  // segment 0 ignores the wall it ends on (geometry.py:881-890)
-    if (kind[j] == D2D_VERTEX) return;   // vertices never occlude (geometry.py:407-414)
+// (one (wall w, blocker j) pair, lane = bin b: is bin b of w certainly hidden from (ex, ey) by j?)
+__device__ __forceinline__ bool shadow_pair_bin(const float4* __restrict__ occl, const float4* __restrict__ refl,
+                                                const unsigned char* __restrict__ kind, int w, int j, int b, float ex, float ey, float win_lo,
+                                                float win_hi, float dperp, float dom_lo, float dom_w) {
+    if (w == j) return false;                  // segment 0 ignores the wall it ends on (geometry.py:881-890)
+    if (kind[j] == D2D_VERTEX) return false;   // vertices never occlude (geometry.py:407-414)
     {
         const float4 t1 = refl[2 * w + 1];
-        if (t1.x * t1.x + t1.y * t1.y == 0.0f) return;  // a zero-length wall has no line for its point to lie on
+        if (t1.x * t1.x + t1.y * t1.y == 0.0f) return false;  // a zero-length wall has no line for its point to lie on
     }
     const float eps = 1.1920929e-07f;
     const float4 r0 = refl[2 * w], r1 = refl[2 * w + 1];
@@ -2768,32 +2863,65 @@ __global__ void shadow_tx_kernel(const float4* __restrict__ occl, const float4* 
     const float errB = 8.0f * eps * (fabsf(o.z * Cy) + fabsf(o.w * Cx));
     const float tlen = fabsf(r1.x) + fabsf(r1.y);
     const float pad = dperp * (r1.w > 0.0f ? 1.0f / r1.w : 0.0f);  // dperp expressed in parametric units of w
-    unsigned long long bits = 0ull;
-    {
-        bool ok = true;
-        int sgn = 0;
+    bool ok = true;
+    int sgn = 0;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float sg = dom_lo + ((v & 1) ? (float)(b + 1) * dom_w + pad : (float)b * dom_w - pad);
-            const float off = (v & 2) ? dperp : -dperp;
-            const float qx = r0.x + sg * r1.x + off * r0.z, qy = r0.y + sg * r1.y + off * r0.w;  // P4 = q
-            const float Bx = ex - qx, By = ey - qy;
-            const float fa = By * Cx - Bx * Cy;
-            const float fd = o.w * Bx - o.z * By;
-            const float errA = 8.0f * eps * (fabsf(By * Cx) + fabsf(Bx * Cy));
-            const float errD = 8.0f * eps * (fabsf(o.w * Bx) + fabsf(o.z * By)) + 4.0f * eps * tlen * (fabsf(o.z) + fabsf(o.w));
-            const float ad = fabsf(fd);
-            if (!(ad > 8.0f * errD)) { ok = false; break; }
-            const int sv = fd > 0.0f ? 1 : -1;
-            if (sgn == 0) sgn = sv;
-            if (sv != sgn) { ok = false; break; }
-            const float ta = fa / fd, tb = fb / fd;
-            const float ea = (errA + 2.0f * errD) / (ad - errD) + 4.0f * eps, eb = (errB + 2.0f * errD) / (ad - errD) + 4.0f * eps;
-            if (!(ta - ea >= win_lo && ta + ea <= win_hi && tb - eb >= win_lo && tb + eb <= win_hi)) { ok = false; break; }
-        }
-        bits = __ballot(ok);
+    for (int v = 0; v < 4; ++v) {
+        const float sg = dom_lo + ((v & 1) ? (float)(b + 1) * dom_w + pad : (float)b * dom_w - pad);
+        const float off = (v & 2) ? dperp : -dperp;
+        const float qx = r0.x + sg * r1.x + off * r0.z, qy = r0.y + sg * r1.y + off * r0.w;  // P4 = q
+        const float Bx = ex - qx, By = ey - qy;
+        const float fa = By * Cx - Bx * Cy;
+        const float fd = o.w * Bx - o.z * By;
+        const float errA = 8.0f * eps * (fabsf(By * Cx) + fabsf(Bx * Cy));
+        const float errD = 8.0f * eps * (fabsf(o.w * Bx) + fabsf(o.z * By)) + 4.0f * eps * tlen * (fabsf(o.z) + fabsf(o.w));
+        const float ad = fabsf(fd);
+        if (!(ad > 8.0f * errD)) { ok = false; break; }
+        const int sv = fd > 0.0f ? 1 : -1;
+        if (sgn == 0) sgn = sv;
+        if (sv != sgn) { ok = false; break; }
+        const float ta = fa / fd, tb = fb / fd;
+        const float ea = (errA + 2.0f * errD) / (ad - errD) + 4.0f * eps, eb = (errB + 2.0f * errD) / (ad - errD) + 4.0f * eps;
+        if (!(ta - ea >= win_lo && ta + ea <= win_hi && tb - eb >= win_lo && tb + eb <= win_hi)) { ok = false; break; }
     }
+    return ok;
+}
+
+__global__ void shadow_tx_kernel(const float4* __restrict__ occl, const float4* __restrict__ refl,
+                                 const unsigned char* __restrict__ kind, int N, float ex, float ey, float win_lo, float win_hi,
+                                 float dperp, float dom_lo, float dom_w, unsigned long long* __restrict__ shadow) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(gid & 63);       // one lane per bin: a wave = one (w, j) pair, its ballot = the pair's 64 bits
+    const long idx = gid >> 6;
+    if (idx >= (long)N * N) return;
+    const int w = (int)(idx / N), j = (int)(idx % N);
+    const unsigned long long bits = __ballot(shadow_pair_bin(occl, refl, kind, w, j, b, ex, ey, win_lo, win_hi, dperp, dom_lo, dom_w));
     if (bits && b == 0) atomicOr(&shadow[w], bits);
+}
+
+// The same masks by ONE kernel that needs nothing zeroed beforehand and zeroes what the rest of the launch's preparation
+// wants zeroed (sort counters of big launches, the lists' bookkeeping: `zero[0 .. n_zero)`): workgroup w < N owns wall w -- its
+// four waves take every fourth blocker each, OR their ballots in registers, combine through LDS and STORE the mask --, the
+// workgroups behind them clear 256 words each.  N + a few workgroups instead of N x N single-wave ones and a memset kernel in
+// front: beside a sweep that fills the chip, what a small kernel costs is its wave count and the kernel boundaries.
+__global__ void __launch_bounds__(256) shadow_fill_kernel(const float4* __restrict__ occl, const float4* __restrict__ refl,
+                                                          const unsigned char* __restrict__ kind, int N, float ex, float ey, float win_lo,
+                                                          float win_hi, float dperp, float dom_lo, float dom_w, int want_masks,
+                                                          unsigned long long* __restrict__ shadow, unsigned long long* __restrict__ zero,
+                                                          long n_zero) {
+    if ((int)blockIdx.x >= N) {
+        const long i = (long)(blockIdx.x - N) * 256 + threadIdx.x;
+        if (i < n_zero) zero[i] = 0ull;
+        return;
+    }
+    __shared__ unsigned long long part[4];
+    const int w = blockIdx.x, wv = threadIdx.x >> 6, b = threadIdx.x & 63;
+    unsigned long long bits = 0ull;
+    if (want_masks)
+        for (int j = wv; j < N; j += 4) bits |= __ballot(shadow_pair_bin(occl, refl, kind, w, j, b, ex, ey, win_lo, win_hi, dperp, dom_lo, dom_w));
+    if (b == 0) part[wv] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) shadow[w] = part[0] | part[1] | part[2] | part[3];
 }
 
 // Wall-to-wall occlusion masks (scene-only: no end point involved, so they are built once per scene / mode).  One wave

@@ -1,0 +1,18 @@
+// Translation unit of the reverse-mode MinPath / FermatPath value+gradient sweep (d2d_optrev.hpp).
+#define D2D_OPTREV_KERNELS 1
+#include "d2d_optrev.hpp"
+
+namespace d2d {
+
+hipError_t launch_opt_rev(int K, const OptRevArgs& a, int c_first, dim3 grid, size_t lds, hipStream_t stream) {
+    switch (K) {
+        case 0: hipLaunchKernelGGL(power_opt_rev_kernel<0>, grid, dim3(64), lds, stream, a, c_first); break;
+        case 1: hipLaunchKernelGGL(power_opt_rev_kernel<1>, grid, dim3(64), lds, stream, a, c_first); break;
+        case 2: hipLaunchKernelGGL(power_opt_rev_kernel<2>, grid, dim3(64), lds, stream, a, c_first); break;
+        case 3: hipLaunchKernelGGL(power_opt_rev_kernel<3>, grid, dim3(64), lds, stream, a, c_first); break;
+        default: hipLaunchKernelGGL(power_opt_rev_kernel<4>, grid, dim3(64), lds, stream, a, c_first); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace d2d

@@ -175,8 +175,11 @@ int d2d_power_map_launch(d2d_ctx* ctx, const d2d_params* params, const float* tx
 int d2d_set_cotangent(d2d_ctx* ctx, const float* cot);
 
 /* Value+grad sweep.  ImagePath: fused, hand-derived reverse mode.  MinPath / FermatPath (differt2d/geometry.py:1117-1288):
- * the derivative of the reference's lax.scan of Adam steps (differt2d/optimize.py:83-97) carried forward as tangents
- * through the same loop (d2d_optgrad.hpp), for Wall, RIS (incl. phi, geometry.py:698-711) and Vertex objects.  Writes the value map exactly as
+ * hand-derived reverse mode through the reference's lax.scan of Adam steps (differt2d/optimize.py:83-97): the solver writes its
+ * trajectory to HBM and the steps are walked backwards (d2d_optrev.hpp; 16 bytes per step and unknown, grids whose
+ * trajectories exceed "opt_traj_mb" are swept in chunks of cells), for Wall, RIS (incl. phi, geometry.py:698-711) and Vertex
+ * objects; "opt_grad_mode" = 1 selects the older forward-tangent kernel (d2d_optgrad.hpp), kept as an independent
+ * cross-check.  Writes the value map exactly as
  * d2d_power_map_launch does, the per-cell gradient d Z[i,j] / d rx[i,j] (resident, [m][n][2]) and, when
  * want_scene_vjp != 0, the VJP of the map w.r.t. the transmitter position and every object end point,
  * contracted with the cotangent. out_mode D2D_OUT_ADD accumulates all of them (reduce_all). Asynchronous. */
@@ -217,6 +220,10 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *                   work each took then (counted by the kernels); zero = always by the geometric proxy
  *   "pair_masks": zero = do not build / use the wall-to-wall occlusion masks (A/B and tests; same results)
  *   "opt_parallel": zero = MinPath / FermatPath sweeps walk the candidates one after the other in every lane (same results)
+ *   "opt_grad_mode": gradients through the MinPath / FermatPath solvers: 0 (default) reverse mode over the stored trajectory,
+ *                   1 forward tangents carried through the loop (same derivative; NaN only where a local partial derivative
+ *                   is infinite vs. also where an accumulated tangent overflowed); "opt_traj_mb": device memory the
+ *                   trajectory store of the reverse mode may take (default 16384)
  *   "txg_exhaustive": non-zero = TX-grid value sweeps use the exhaustive kernel instead of the culled one (same results)
  *   "region_lists": zero = no region candidate lists: every patch enumerates the prefixes of its candidates itself
  *                   (default non-zero: culled RX-grid launches of max_order >= 2 build, per launch, for every region of

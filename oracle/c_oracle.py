@@ -78,7 +78,7 @@ def make_params(min_order=0, max_order=1, order=None, approx=False, function="ha
     if order is not None:
         min_order = max_order = order
     return OrcParams(min_order, max_order, int(bool(approx)), ACT_IDS[function], alpha, tol, patch, seg_tol,
-                     FUN_IDS[fun], r_coef, height, int(bool(prune)), 1 if grid_role == "tx" else 0)
+                     FUN_IDS[fun], r_coef, height, int(prune), 1 if grid_role == "tx" else 0)
 
 
 def _allowed_ptr(allowed):

@@ -47,7 +47,10 @@ typedef struct orc_params {
     float seg_tol;    /* geometry.py:89 */
     int32_t fun_id;   /* 0 received_power, 1 length**2, 2 length, 3 one */
     float r_coef, height;
-    int32_t prune;    /* 1: skip work whose result is provably discarded (exact); 0: evaluate everything */
+    int32_t prune;    /* 0: evaluate everything; 1: skip the occlusion tests of a candidate whose on_objects is exactly 0;
+                         2: also leave the candidate at the first wall (in the backward scan's order) whose on_objects term is
+                         exactly 0 -- per cell and candidate, exact fp32 arithmetic on the reference's own values: nothing
+                         here knows about the GPU's patch-level culling */
     int32_t grid_is_tx; /* 0: grid cells are receivers (scene.py:1803-1953); 1: transmitters, `tx` is the fixed receiver (scene.py:1489-1648) */
 } orc_params;
 
@@ -145,6 +148,24 @@ static void eval_candidate(const wall_t* W, int N, const int* cand, int k, const
             else { incx = (vn * ux) / un; incy = (vn * uy) / un; }
             ptx = ptx + incx; pty = pty + incy;
             px[i + 1] = ptx; py[i + 1] = pty;
+            if (p->prune >= 2) {
+                /* prune level 2: this wall's term of on_objects (the very expression evaluated below, on the very same
+                 * point) right away.  Exactly 0 here makes on_objects -- a min / and over the walls -- exactly 0 and the
+                 * contribution valid * fun = 0 * fun, as at prune level 1; the remaining points, the loss and the occlusion
+                 * tests are then never computed.  (fun is finite: for coordinates of order 1 a non-zero u.n is no smaller
+                 * than an ulp of its terms, so the interaction points stay of order 1e9 at most and the path length is
+                 * finite.  tests/test_oracle_c.py checks level 2 against levels 0 and 1 cell for cell.) */
+                float ox_ = ptx - w->ox, oy_ = pty - w->oy;
+                float sq = w->tx_ * w->tx_ + w->ty_ * w->ty_;
+                if (sq == 0.0f) sq = 1.0f;
+                float s = (w->tx_ * ox_ + w->ty_ * oy_) / sq;
+                float c = t_and(t_ge(s, 0.0f, p), t_le(s, 1.0f, p), p->approx);
+                if (c == 0.0f && isfinite(ptx) && isfinite(pty)) {
+                    *valid_out = 0.0f;
+                    *fun_out = 0.0f;
+                    return;
+                }
+            }
         }
     }
     /* on_objects, geometry.py:821-854 */
@@ -181,6 +202,10 @@ static void eval_candidate(const wall_t* W, int N, const int* cand, int k, const
             for (int j = 0; j < N; ++j) {
                 if (j == ig0 || j == ig1) continue;
                 hit = t_or(hit, wall_hits(&W[j], px[i], py[i], px[i + 1], py[i + 1], p), p->approx);
+                /* prune level 2: an occluder whose test is exactly True / saturated to 1 settles not(intersects) = 0 and
+                 * with it valid = 0: whatever the remaining tests return -- a larger value does not exist, a NaN ends in
+                 * nan_to_num(NaN) = 0 as well -- so they are not evaluated */
+                if (p->prune >= 2 && hit == 1.0f) { i = k; break; }
             }
         }
     }
@@ -276,7 +301,7 @@ int orc_power_map_ex(const float* walls, int N, const uint8_t* allowed, const or
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 1)
     for (long c = 0; c < ncell; ++c) {
         float acc = 0.0f;
         float cnt = 0.0f; /* the same sweep with fun = 1.0: the map of (soft) valid-path counts */

@@ -34,6 +34,34 @@ def scene_tables():
     return xys, kind, phi
 
 
+def solver_agreement(kind, xys, phi, tx, X, Y, cands, theta0, steps, solver="min", tol=2e-5):
+    """Cells where the SOLVER of every candidate follows the same trajectory in the oracle's fp32 run, in its fp32 run from
+    inputs nudged by one ulp, and in its fp64 run: interaction points within `tol` after 30, 100, 300 and all `steps`
+    iterations.  Agreement of the summed value alone can be an accident: a candidate whose solver wanders chaotically next to
+    a wall usually ends somewhere invalid in every run and contributes 0 each time -- until an evaluation with another
+    rounding (XLA's, a hand-derived gradient) happens to end on the valid reflection point.  And agreement of the FINAL points
+    alone says little about the gradient: Adam's second moment remembers the transient (0.999 ** 700 = 0.5), so the
+    derivative through the loop depends on the whole trajectory -- a grazing reflection whose fp32 and fp64 transients are
+    1e-4 apart ends on the same point with gradients that differ in the third digit."""
+    up = lambda a: np.nextafter(np.asarray(a, F), F(np.inf)).astype(F)
+    ok = np.ones(np.shape(X), bool)
+    objs64 = [R.Obj(int(k), np.asarray(xys[j, 0] if int(k) == R.VERTEX else xys[j], np.float64), float(phi[j])) for j, k in enumerate(kind)]
+    objs32 = [R.Obj(int(k), np.asarray(xys[j, 0] if int(k) == R.VERTEX else xys[j], F), float(phi[j])) for j, k in enumerate(kind)]
+    rx32 = np.stack([X, Y], -1).astype(F)
+    tx32 = np.broadcast_to(np.asarray(tx, F), rx32.shape)
+    for c, th in zip(cands, theta0):
+        if len(th) == 0:
+            continue
+        for n_steps in sorted({s_ for s_ in (30, 100, 300, steps) if s_ <= steps}):
+            ref, _ = R.opt_path(solver, tx32.astype(np.float64), [objs64[int(i)] for i in c], rx32.astype(np.float64), th, n_steps, R.NUMPY64)
+            for t_, r_, th_ in ((tx32, rx32, th), (tx32, up(rx32), th), (np.broadcast_to(up(tx), rx32.shape), rx32, up(th))):
+                got, _ = R.opt_path(solver, t_, [objs32[int(i)] for i in c], r_, th_, n_steps, R.NUMPY)
+                for a, b in zip(got[1:-1], ref[1:-1]):
+                    with np.errstate(invalid="ignore"):
+                        ok &= np.abs(np.asarray(a, np.float64) - b).max(-1) <= tol
+    return ok
+
+
 def main():
     n_cells = int(sys.argv[1]) if len(sys.argv) > 1 else 48
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -65,6 +93,10 @@ def main():
     gscale = np.maximum(np.abs(g64).max(-1), np.median(np.abs(g64).max(-1)))
     stable = (np.isclose(v32, v64, rtol=2e-3, atol=2e-3 * np.abs(v64).max()) & np.isfinite(g32).all(-1)
               & (np.abs(g32 - g64).max(-1) <= 1e-2 * gscale))
+    agree = solver_agreement(kind, xys, phi, tx, X, Y, cands, theta0, steps)[0]
+    print("cells whose solvers agree (fp32, nudged fp32, fp64):", int(agree.sum()), "of", n_cells, "-- of the", int(stable.sum()),
+          "value/gradient-stable ones:", int((agree & stable).sum()), flush=True)
+    stable &= agree
     out["stable"] = stable
     print("stable cells:", int(stable.sum()), "of", n_cells, flush=True)
     for dt in ("float64", "float32"):

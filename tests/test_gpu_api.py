@@ -118,7 +118,13 @@ def test_notebook_valid_count_via_all_paths():
 
 
 def _length_sq(transmitter, receiver, path, interacting_objects):
-    return path.length() ** 2  # an arbitrary python fun: goes through the GPU trace + host fun path
+    # the reference's own local `fun` (tests/test_scene.py:444, 558-560): recognised by what it computes and fused natively
+    return path.length() ** 2
+
+
+def _length_sq_host(transmitter, receiver, path, interacting_objects):
+    # an arbitrary python fun (it depends on the interacting objects): goes through the GPU trace + host fun path
+    return path.length() ** 2 * (1.0 + 1e-3 * len(interacting_objects))
 
 
 def test_accumulate_over_paths():
@@ -135,14 +141,17 @@ def test_accumulate_over_paths():
     np.testing.assert_allclose(total, 6.0, rtol=1e-6)
 
 
-@pytest.mark.parametrize("native", [True, False])
+@pytest.mark.parametrize("native", ["tagged", "recognised", "host"])
 def test_accumulate_on_receivers_grid_los(native):
-    # tests/test_scene.py:558-627 (values; gradients are tested with the gradient kernels)
+    # tests/test_scene.py:558-627, with the test's own local `fun` ("recognised": the reference's call pattern as written,
+    # grad=True included), the tagged library function, and a callable that only the host can evaluate (values only)
     from differt2d_amd.geometry import Point
-    from differt2d_amd.scene import Scene
+    from differt2d_amd.scene import Scene, _native_fun
     from differt2d_amd.utils import path_length_squared
 
-    fun = path_length_squared if native else _length_sq
+    fun = {"tagged": path_length_squared, "recognised": _length_sq, "host": _length_sq_host}[native]
+    assert (_native_fun(fun, (), None) is None) == (native == "host")
+    native = native != "host"
     scene = Scene(transmitters={"tx0": Point(xy=[0.0, 0.0]), "tx1": Point(xy=[1.0, 0.0])}, objects=[], receivers={})
     x = np.linspace(-3, 3, 10).astype(F)
     X, Y = np.meshgrid(x, x)
@@ -169,14 +178,15 @@ def test_accumulate_on_receivers_grid_los(native):
     np.testing.assert_allclose(per_tx["tx1"], np.stack([2 * (X - 1.0), 2 * Y], axis=-1), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("native", [True, False])
+@pytest.mark.parametrize("native", ["tagged", "recognised", "host"])
 def test_accumulate_on_transmitters_grid_los(native):
     # tests/test_scene.py:487-556
     from differt2d_amd.geometry import Point
     from differt2d_amd.scene import Scene
     from differt2d_amd.utils import path_length_squared
 
-    fun = path_length_squared if native else _length_sq
+    fun = {"tagged": path_length_squared, "recognised": _length_sq, "host": _length_sq_host}[native]
+    native = native != "host"
     scene = Scene(transmitters={}, objects=[], receivers={"rx0": Point(xy=[0.0, 0.0]), "rx1": Point(xy=[0.0, 1.0])})
     x = np.linspace(-3, 3, 10).astype(F)
     X, Y = np.meshgrid(x, x)
@@ -497,3 +507,30 @@ def test_scene_vjp_accumulation_refuses_mixed_sweep_kinds():
     with pytest.raises(L.D2DError) as e:
         ctx.launch_vg(make_params(out_mode=L.OUT_ADD, **img), tx, scene_vjp=True)
     assert e.value.status == -5
+
+
+def test_user_functions_are_recognised_by_what_they_compute():
+    """VERDICT r2 item 9: a local `fun` that is one of the fused closed forms runs fused -- with gradients -- without a rename;
+    anything else goes to the host (values) or raises (gradients), as before."""
+    from differt2d_amd import _lib as L
+    from differt2d_amd.scene import Scene, _native_fun
+    from differt2d_amd.utils import received_power
+
+    assert _native_fun(lambda t, r, p, o: p.length(), (), None) == ("length", {})
+    assert _native_fun(lambda t, r, p, o: F(1.0), (), None) == ("one", {})
+    assert _native_fun(lambda t, r, p, o: received_power(t, r, p, o, r_coef=0.3, height=0.2), (), None) == (
+        "received_power", {"r_coef": 0.3, "height": 0.2})
+    assert _native_fun(lambda t, r, p, o, h: received_power(t, r, p, o, height=h), (0.5,), None) == ("received_power", {"r_coef": 0.5, "height": 0.5})
+    assert _native_fun(lambda t, r, p, o: np.sum((r.xy - t.xy) ** 2), (), None) is None  # = length ** 2 in line of sight only
+    assert _native_fun(lambda t, r, p, o: p.length() ** 3, (), None) is None
+    assert _native_fun(lambda t, r, p, o: p.nope(), (), None) is None  # raises on the probes: the host's business
+    scene = Scene.square_scene_with_obstacle()
+    X, Y = scene.grid(n=40)
+    mine = lambda transmitter, receiver, path, interacting_objects: 0.25 ** (path.xys.shape[-2] - 2) / (0.04 + path.length() ** 2)  # noqa: E731
+    kw = dict(reduce_all=True, max_order=2, approx=True)
+    Z, dZ = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=mine, value_and_grad=True, **kw)
+    Zr, dZr = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, fun_kwargs=dict(r_coef=0.25, height=0.2),
+                                                            value_and_grad=True, **kw)
+    assert np.array_equal(Z, Zr) and np.array_equal(dZ, dZr, equal_nan=True) and np.isfinite(dZ).mean() > 0.9
+    with pytest.raises(L.D2DUnsupported):
+        scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=_length_sq_host, grad=True, **kw)

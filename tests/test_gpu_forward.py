@@ -343,6 +343,37 @@ def test_cfg4_full_size_against_sampled_oracle_cells(ctx, mode):
     assert (z["per_order"][3] != 0).sum() >= 5  # the sample does see third-order paths
 
 
+@pytest.mark.parametrize("mode", ["hard", "hsig"])
+def test_cfg4_full_size_against_contiguous_oracle_blocks(ctx, mode):
+    """BASELINE.json configs[3] at FULL size, inside the full 2048^2 launch, against six CONTIGUOUS blocks
+    of 64 x 64 cells that the C oracle computed cell by cell (scripts/make_golden_cfg4_blocks.py: per-cell pruning that
+    knows nothing of the GPU's patch culling) -- the transmitter's block, where the region candidate lists are longest, two
+    of its neighbours (one straddling four top regions), a block in full shadow, the corner and a random one: 24 576 cells
+    per mode, every bit.  Both launch shapes of the sweep kernel (one / four patches per workgroup)."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg4_blocks.npz"))
+    B = int(z["block_size"])
+    assert int(z["grid"]) == 2048 and z[mode].shape == (len(z["blocks"]), B, B)
+    kw = dict(approx=False) if mode == "hard" else dict(approx=True, function="hard_sigmoid")
+    tx, walls = random_scene(200, seed=1234)
+    x = np.linspace(0.0, 1.0, 2048).astype(F)
+    X, Y = np.meshgrid(x, x)
+    ctx.set_scene(walls)
+    for waves in (0, 1):
+        ctx.set_option("fwd_waves", waves)
+        try:
+            got = ctx.power_map(tx, X, Y, min_order=0, max_order=3, **kw)
+        finally:
+            ctx.set_option("fwd_waves", 0)
+        bad = 0
+        for b, (i0, j0) in enumerate(z["blocks"]):
+            blk = got[i0 : i0 + B, j0 : j0 + B]
+            n = int((~((blk == z[mode][b]) | (np.isnan(blk) & np.isnan(z[mode][b])))).sum())
+            print(f"   cfg4 {mode} block {b} at ({int(i0)}, {int(j0)}): {n} of {B * B} cells differ; {int((z[mode][b] != 0).sum())} non-zero")
+            bad += n
+        assert bad == 0
+    assert sum(int((z[mode][b] != 0).sum()) for b in range(len(z["blocks"]))) >= 4096  # the blocks do see paths
+
+
 def test_bad_inputs_are_rejected_or_propagated(ctx):
     from differt2d_amd import _lib as L
 

@@ -278,14 +278,57 @@ def _gpu_opt_grads(xys, kind, phi, tx, X, Y, cands, theta0, cot, **kw):
     return ctx.value_and_grads(tx, X, Y, cotangent=cot, **kw)
 
 
+def _tight(got, want, want32, name, report=None):
+    """north_star's bar (the same as tests/test_gpu_grad.py holds the image-method gradients to): NaN positions identical to
+    the reference chain's fp32 autodiff, and every entry within 1e-5 (of the largest entry, + 1e-5 relative) of the fp64
+    autodiff result -- or, where the reference's OWN fp32 autodiff (`want32`, same op chain) is further than that from fp64,
+    within twice that entry's fp32-autodiff error: no fp32 evaluation can be held closer to fp64 than the reference is."""
+    got, want, want32 = np.asarray(got, np.float64), np.asarray(want, np.float64), np.asarray(want32, np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want32)), (
+        f"{name}: NaN positions differ from the fp32 autodiff of the oracle: GPU only {np.argwhere(np.isnan(got) & ~np.isnan(want32)).tolist()[:12]}, "
+        f"oracle only {np.argwhere(~np.isnan(got) & np.isnan(want32)).tolist()[:12]}")
+    fin = np.isfinite(want) & np.isfinite(want32)
+    if not fin.any():
+        return
+    scale = max(float(np.abs(want[fin]).max()), 1e-12)
+    err, ref_err = np.abs(got - want)[fin], np.abs(want32 - want)[fin]
+    plain = 1e-5 * scale + 1e-5 * np.abs(want[fin]) + 1e-7
+    line = (f"{name}: max err/scale {err.max() / scale:.2e} (the reference's fp32 autodiff: {ref_err.max() / scale:.2e}; scale {scale:.3g}); "
+            f"{int((err > plain).sum())} of {err.size} entries beyond 1e-5")
+    print("   " + line)
+    if report is not None:
+        report.append(line)
+    bad = err > np.maximum(plain, 2.0 * ref_err + 1e-7)
+    assert not bad.any(), line + f" -- and {int(bad.sum())} of them beyond 2x the fp32-autodiff error at that entry, worst {err[bad].max():.3e}"
+
+
+def _oracle_stable(v64, v32, g64, g32):
+    """Cells where the reference chain is well conditioned: its own fp32 run agrees with its fp64 run (value within 2e-3,
+    gradient within 1e-2 of the cell's gradient scale).  Elsewhere hundreds of sequential fp32 Adam steps have amplified
+    round-off into a different solution: the reference's fp32 result is noise there, and so is anybody's.  Defined from the
+    ORACLE alone -- never from how close the GPU came."""
+    fin = np.isfinite(g64).all(-1) & np.isfinite(g32).all(-1)
+    gmax = np.abs(np.nan_to_num(g64)).max(-1)
+    gscale = np.maximum(gmax, np.median(gmax[fin]) if fin.any() else 1.0)
+    with np.errstate(invalid="ignore"):
+        return fin & np.isclose(v32, v64, rtol=2e-3, atol=2e-3 * np.abs(v64).max()) & (np.abs(g32 - g64).max(-1) <= 1e-2 * gscale)
+
+
+@pytest.mark.parametrize("grad_mode", [0, 1], ids=["reverse", "forward_tangents"])
 @pytest.mark.parametrize("solver,steps", [("min", 30), ("min", 200), ("fermat", 60)])
 @pytest.mark.parametrize("approx", [False, True])
 @pytest.mark.parametrize("role", ["rx", "tx"])
-def test_gradients_through_the_solver_match_autodiff_of_the_oracle(solver, steps, approx, role):
+def test_gradients_through_the_solver_match_autodiff_of_the_oracle(solver, steps, approx, role, grad_mode):
     """Value, per-cell gradient and the scene VJP (fixed end point, every object's end points incl. the RIS's and the
     diffraction vertices', the RIS's phi) of a MinPath / FermatPath sweep against reverse-mode autodiff of the oracle
-    through its Adam loop (oracle/ref.py: opt_value_and_grads, torch double backward, fp64)."""
+    through its Adam loop (oracle/ref.py: opt_value_and_grads, torch double backward), for both gradient kernels: reverse
+    mode over the stored trajectory (d2d_optrev.hpp, the default) and forward tangents (d2d_optgrad.hpp).
+
+    No conditional assertion: the cotangent of the scene VJP is masked to the cells where the ORACLE is well conditioned
+    (fp32 vs fp64 of the reference chain itself), the same mask goes to the oracle and to the GPU, and every quantity is held
+    to the bar of the image-method gradients (_tight)."""
     from differt2d_amd import _lib as L
+    from differt2d_amd.engine import default_context
     from oracle import ref as R
 
     scene, xys, kind, phi, X, Y, cands, theta0 = _opt_case(steps, solver, approx, role=role)
@@ -293,48 +336,36 @@ def test_gradients_through_the_solver_match_autodiff_of_the_oracle(solver, steps
     rng = np.random.default_rng(5)
     cot = (rng.random(X.shape) + 0.5).astype(F)
     kw = dict(min_order=0, max_order=1, approx=approx)
-    okw = dict(solver=solver, steps=steps, cotangent=cot, grid_role=role, approx=approx)
-    want = R.opt_value_and_grads(kind, xys, phi, tx, X, Y, cands, theta0, dtype="float64", **okw)
-    # the same chain in fp32: where the reference's own arithmetic produces NaN (e.g. cells on the RIS's supporting line:
-    # the RIS residual does not depend on theta there, d objective / d theta == 0 exactly, Adam's sqrt(nu = 0) has an
-    # infinite derivative), and how far fp32 round-off alone moves each entry (min / max selections between coincident
-    # points -- a Vertex sitting on the RIS's end point -- flip between fp32 and fp64, shifting gradient mass between them)
-    want32 = R.opt_value_and_grads(kind, xys, phi, tx, X, Y, cands, theta0, dtype="float32", **okw)
-    got = _gpu_opt_grads(xys, kind, phi, tx, X, Y, cands, theta0, cot, solver=solver, steps=steps,
-                         grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw)
+    okw = dict(solver=solver, steps=steps, grid_role=role, approx=approx)
+    w64 = R.opt_value_and_grads(kind, xys, phi, tx, X, Y, cands, theta0, dtype="float64", cotangent=cot, **okw)
+    w32 = R.opt_value_and_grads(kind, xys, phi, tx, X, Y, cands, theta0, dtype="float32", cotangent=cot, **okw)
+    stable = _oracle_stable(w64["value"], w32["value"], w64["grad_cell"], w32["grad_cell"])
+    assert stable.mean() >= 0.8, f"only {int(stable.sum())} of {stable.size} cells are well conditioned in the oracle"
+    cot_m = (cot * stable).astype(F)
+    if not stable.all():  # the scene VJP over the well-conditioned cells only (cotangent 0 elsewhere), both precisions
+        w64 = R.opt_value_and_grads(kind, xys, phi, tx, X, Y, cands, theta0, dtype="float64", cotangent=cot_m, **okw)
+        w32 = R.opt_value_and_grads(kind, xys, phi, tx, X, Y, cands, theta0, dtype="float32", cotangent=cot_m, **okw)
+    ctx = default_context()
+    ctx.set_option("opt_grad_mode", grad_mode)
+    try:
+        got = _gpu_opt_grads(xys, kind, phi, tx, X, Y, cands, theta0, cot_m, solver=solver, steps=steps,
+                             grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw)
+    finally:
+        ctx.set_option("opt_grad_mode", 0)
     # the value map of the gradient sweep is the forward sweep's, bit for bit
-    from differt2d_amd.engine import default_context
-
-    fwd = default_context().power_map(tx, X, Y, solver=solver, steps=steps, grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw)
+    fwd = ctx.power_map(tx, X, Y, solver=solver, steps=steps, grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw)
     assert np.array_equal(got["value"], fwd, equal_nan=True)
-    scale_v = np.abs(want["value"]).max()
-    # cells where the fp32 solver and the fp64 oracle landed on the same solution (see test_ris_vertex_sweep_matches_oracle)
-    stable = np.isclose(got["value"], want["value"], rtol=2e-3, atol=2e-3 * scale_v)
-    assert stable.mean() >= 0.8
-
-    def check(name, a, b64, b32):
-        a, b64, b32 = (np.asarray(v, np.float64) for v in (a, b64, b32))
-        assert np.array_equal(np.isnan(a), np.isnan(b32)), (
-            f"{name}: NaN positions differ from the fp32 autodiff of the oracle: GPU only {np.argwhere(np.isnan(a) & ~np.isnan(b32)).tolist()[:12]}, "
-            f"oracle only {np.argwhere(~np.isnan(a) & np.isnan(b32)).tolist()[:12]}")
-        fin = np.isfinite(b32) & np.isfinite(b64)
-        if not fin.any():
-            return
-        s_ = max(float(np.abs(b64[fin]).max()), 1e-12)
-        err, ref_err = np.abs(a - b64)[fin], np.abs(b32 - b64)[fin]
-        print(f"   {name}: max err/scale {err.max() / s_:.2e}, median {np.median(err) / s_:.2e} (oracle fp32 vs fp64: {ref_err.max() / s_:.2e}; scale {s_:.3g})")
-        bad = err > np.maximum(1e-3 * s_ + 1e-3 * np.abs(b64[fin]), 4.0 * ref_err + 1e-6 * s_)
-        assert not bad.any(), f"{name}: {int(bad.sum())} entries off, worst {err[bad].max():.3e} at scale {s_:.3e}"
-        assert np.quantile(err, 0.75) <= 2e-4 * s_
-
-    print(f"{solver} {steps} {role} approx={approx}: {int(stable.sum())} of {stable.size} cells stable")
-    check("per-cell gradient", got["grad_rx"][stable], want["grad_cell"][stable], want32["grad_cell"][stable])
-    if stable.all():
-        check("fixed end point", got["tx_bar"], want["fixed_bar"], want32["fixed_bar"])
-        check("object end points", got["walls_bar"], want["xys_bar"], want32["xys_bar"])
-        check("phi", got["phi_bar"], want["phi_bar"], want32["phi_bar"])
+    print(f"{solver} {steps} {role} approx={approx}: {int(stable.sum())} of {stable.size} cells well conditioned in the oracle")
+    scale_v = np.abs(w64["value"]).max()
+    np.testing.assert_allclose(got["value"][stable], w64["value"][stable], rtol=2e-3, atol=2e-3 * scale_v)
+    # NaN positions of the per-cell gradient: identical to the fp32 reference chain's on EVERY cell; values on the stable ones
+    assert np.array_equal(np.isnan(got["grad_rx"]), np.isnan(w32["grad_cell"]))
+    _tight(got["grad_rx"][stable], w64["grad_cell"][stable], w32["grad_cell"][stable], "per-cell gradient")
+    _tight(got["tx_bar"], w64["fixed_bar"], w32["fixed_bar"], "fixed end point")
+    _tight(got["walls_bar"], w64["xys_bar"], w32["xys_bar"], "object end points")
+    _tight(got["phi_bar"], w64["phi_bar"], w32["phi_bar"], "phi")
     if solver == "min" and approx and role == "rx":
-        assert np.abs(want["phi_bar"][4]) > 0 and not want["phi_bar"][[0, 1, 2, 3, 5, 6]].any()  # only the RIS has a phi
+        assert np.abs(w64["phi_bar"][4]) > 0 and not w64["phi_bar"][[0, 1, 2, 3, 5, 6]].any()  # only the RIS has a phi
 
 
 def test_receivers_on_the_ris_line_have_nan_gradients_like_the_reference_chain():
@@ -392,14 +423,27 @@ def test_scene_mirror_exposes_the_solver_gradients():
 def test_cfg5_full_size_value_and_gradient_on_sampled_cells():
     """BASELINE.json configs[4] at full size: square scene + RIS + its two diffraction vertices, 300 x 300 receivers, order 1,
     MinPath with 1000 Adam steps, hard_sigmoid validity -- value map, per-cell gradient and the scene VJP (incl. the RIS's
-    vertices and phi) in one sweep, against the oracle on 48 sampled cells (tests/golden/cfg5_samples.npz,
-    scripts/make_golden_cfg5.py: reverse mode through all 1000 steps, fp64 and fp32)."""
+    vertices and phi) in one sweep (reverse mode over the stored trajectories, d2d_optrev.hpp), against the oracle on
+
+      * 48 random cells (tests/golden/cfg5_samples.npz, scripts/make_golden_cfg5.py: reverse mode through all 1000 steps,
+        fp64 and fp32), and
+      * 997 cells on and next to the square's walls -- the outer rows and columns of scene.grid(n=300) lie exactly on the walls'
+        supporting lines -- and across the RIS's end points (tests/golden/cfg5_edges.npz, scripts/make_golden_cfg5_edges.py).
+
+    `stable` (both fixtures) = the ORACLE's own fp32 run agrees with its fp64 run; it never looks at the GPU.  On those cells:
+    NaN positions identical to the fp32 oracle's, value within 2e-3, per-cell gradient and every entry of the scene VJP within
+    the image-method bar (_tight).  No conditional assertion.  On the other cells the derivative through 1000 Adam steps is
+    ill conditioned in the reference itself (next to the corners its fp32 gradients reach 1e30 and overflow to NaN in
+    neighbouring cells, and which neighbour overflows depends on the last bit of the hand-derived vs the autodiff objective
+    gradient): there the assertion is that the GPU is no less finite than the reference -- the same share of cells."""
     import os
     import time
 
     from differt2d_amd.engine import default_context
 
-    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg5_samples.npz"))
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(gold, "cfg5_samples.npz"))
+    ez = np.load(os.path.join(gold, "cfg5_edges.npz"))
     xys, kind, phi, tx, ij, steps = z["xys"], z["kind"], z["phi"], z["tx"], z["ij"], int(z["steps"])
     theta0 = [np.array([t, 0, 0, 0], F) if np.isfinite(t) else np.zeros(4, F) for t in z["theta0"]]
     x = np.linspace(0.0, 1.0, 300).astype(F)
@@ -415,34 +459,44 @@ def test_cfg5_full_size_value_and_gradient_on_sampled_cells():
     fwd = ctx.power_map(tx, X, Y, **kw)
     assert np.array_equal(full["value"], fwd, equal_nan=True)
     print(f"cfg5 value + per-cell gradient + scene VJP, 300^2 x 7 candidates x {steps} steps: {dt * 1e3:.1f} ms")
-    got_v, got_g = full["value"][ij[:, 0], ij[:, 1]], full["grad_rx"][ij[:, 0], ij[:, 1]]
-    v64, v32, g64, g32 = z["value64"][0], z["value32"][0], z["grad_cell64"][0], z["grad_cell32"][0]
-    scale = np.abs(v64).max()
-    # `stable`: cells where the oracle's own fp32 run agrees with its fp64 run in value AND gradient.  The derivative through
-    # 1000 Adam steps is ill-conditioned in some cells (as nu decays, the update's sensitivity to the gradient grows like
-    # 1 / (sqrt(nu) + eps)): there the oracle's fp32 gradient is orders of magnitude off its fp64 gradient -- the reference's
-    # fp32 result is noise in those cells, and so is anybody's.
+    assert np.isfinite(full["value"]).all()
+
+    def per_cell(name, cells, v64, v32, g64, g32, stable, min_stable):
+        got_v, got_g = full["value"][cells[:, 0], cells[:, 1]], full["grad_rx"][cells[:, 0], cells[:, 1]]
+        scale = np.abs(v64).max()
+        print(f"   {name}: {int(stable.sum())} of {stable.size} cells well conditioned in the oracle (fp32 vs fp64)")
+        assert stable.mean() >= min_stable
+        # NaN positions on the well-conditioned cells: the fp32 reference chain's (none: a stable cell has a finite gradient)
+        assert np.array_equal(np.isnan(got_g[stable]), np.isnan(g32[stable])) and np.isfinite(got_g[stable]).all(), (
+            f"{name}: non-finite GPU gradient in well-conditioned cells {cells[stable][~np.isfinite(got_g[stable]).all(-1)].tolist()}")
+        np.testing.assert_allclose(got_v[stable], v64[stable], rtol=2e-3, atol=2e-3 * scale, err_msg=name)
+        # per-cell gradient: each cell against its own gradient scale (the cells differ by orders of magnitude)
+        fin = np.isfinite(g64).all(-1)
+        gscale = np.maximum(np.abs(np.nan_to_num(g64)).max(-1), np.median(np.abs(g64[fin]).max(-1)))[:, None]
+        err, ref_err = (np.abs(got_g - g64) / gscale)[stable], (np.abs(g32 - g64) / gscale)[stable]
+        print(f"   {name}: per-cell gradient max err / cell scale {err.max():.2e}, median {np.median(err):.2e} "
+              f"(the oracle's fp32 vs fp64: max {ref_err.max():.2e}, median {np.median(ref_err):.2e})")
+        bad = err > np.maximum(1e-5, 2.0 * ref_err)
+        assert not bad.any(), f"{name}: {int(bad.sum())} gradient entries beyond max(1e-5, 2 x the oracle's fp32 error), worst {err[bad].max():.2e}"
+        # ill-conditioned cells: no less finite than the reference chain itself
+        n_bad_gpu, n_bad_ref = int((~np.isfinite(got_g).all(-1)).sum()), int((~np.isfinite(g32).all(-1)).sum())
+        print(f"   {name}: non-finite gradients: GPU {n_bad_gpu}, fp32 oracle {n_bad_ref} of {len(cells)} cells")
+        assert n_bad_gpu <= max(2 * n_bad_ref, 2) + len(cells) // 200
+
+    per_cell("48 random cells", ij, z["value64"][0], z["value32"][0], z["grad_cell64"][0], z["grad_cell32"][0], z["stable"], 0.7)
+    # (the strips along the walls are where the reference chain is ill conditioned: its fp64 gradients reach 1e83 there)
+    per_cell("997 cells on / next to the walls", ez["ij"], ez["value64"], ez["value32"], ez["grad_cell64"], ez["grad_cell32"], ez["stable"], 0.15)
+    # the whole map: what is not finite sits next to a wall (the ill-conditioned corners and wall strips), and is rare
+    bad = ~np.isfinite(full["grad_rx"]).all(-1)
+    xx, yy = X[bad], Y[bad]
+    near = np.minimum(np.minimum(xx, 1 - xx), np.minimum(yy, 1 - yy)) <= 0.05
+    near |= np.abs(xx - 0.5) <= 0.05
+    print(f"   whole map: {int(bad.sum())} of {bad.size} cells with a non-finite gradient, {int(near.sum())} of them within 0.05 of a wall / the RIS's line")
+    assert bad.mean() <= 0.01 and near.mean() >= 0.9
+    # the scene VJP over the well-conditioned sampled cells (cotangent 1 on them): those cells as a 1 x n grid
     stable = z["stable"]
-    close = np.isclose(got_v, v64, rtol=2e-3, atol=2e-3 * scale)
-    print(f"   {int(stable.sum())} of {stable.size} sampled cells stable in the oracle (fp32 vs fp64), GPU value close on {int(close[stable].sum())} of them")
-    assert stable.mean() >= 0.7 and close[stable].mean() >= 0.9
-    ok = stable & close
-    gscale = np.maximum(np.abs(g64).max(-1), np.median(np.abs(g64).max(-1)))[:, None]
-    err, ref_err = np.abs(got_g - g64) / gscale, np.abs(g32 - g64) / gscale
-    good = (err <= np.maximum(2e-3, 8.0 * ref_err)).all(-1)
-    print(f"   per-cell gradient on those {int(ok.sum())}: {int(good[ok].sum())} within max(2e-3, 8 x the oracle's fp32 round-off) of the "
-          f"cell's gradient scale; median err {np.nanmedian(err[ok]):.2e} (oracle fp32 vs fp64: {np.nanmedian(ref_err[ok]):.2e})")
-    assert good[ok].mean() >= 0.9 and np.nanmedian(err[ok]) <= max(1e-4, 4.0 * np.nanmedian(ref_err[ok]))
-    # the scene VJP over the stable cells alone (cotangent 1 on them): those cells as a 1 x n grid
     sub = ctx.value_and_grads(tx, x[ij[stable, 1]][None], x[ij[stable, 0]][None], **kw)
-    assert np.array_equal(sub["value"][0], got_v[stable], equal_nan=True)
-    clean = bool((good & close)[stable].all())  # one cell where the GPU's own round-off went the other way spoils the sum
+    assert np.array_equal(sub["value"][0], full["value"][ij[stable, 0], ij[stable, 1]], equal_nan=True)
     for k_got, k_want in (("tx_bar", "fixed_bar"), ("walls_bar", "xys_bar"), ("phi_bar", "phi_bar")):
-        a, b64, b32 = np.asarray(sub[k_got], np.float64), z[k_want + "64"], z[k_want + "32"]
-        s = max(float(np.abs(b64).max()), 1e-12)
-        e, r = np.abs(a - b64), np.abs(b32 - b64)
-        print(f"   {k_got}: max err/scale {np.nanmax(e) / s:.2e} (oracle fp32 vs fp64: {np.nanmax(r) / s:.2e}; scale {s:.3g})"
-              + ("" if clean else "  [not asserted: a stable cell is a GPU outlier]"))
-        if clean:
-            assert (e <= np.maximum(5e-3 * s, 8.0 * r)).all(), k_got
+        _tight(sub[k_got], z[k_want + "64"], z[k_want + "32"], k_got)
     assert np.abs(z["xys_bar64"][4]).max() > 0 and z["phi_bar64"][4] != 0  # d sum(P) / d (RIS vertices, phi) is not trivially 0
