@@ -115,6 +115,7 @@ SYMBOLS = [
     ("d2d_power_map_wave_cycles", C.c_int, [_ctx, C.POINTER(Params), _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS"),
                                             C.c_int64, C.POINTER(C.c_int64)]),
     ("d2d_selftest_div", C.c_int, [_ctx, _f32p, _f32p, C.c_int64, _f32p, _f32p, _f32p]),
+    ("d2d_selftest_expf", C.c_int, [_ctx, _f32p, C.c_int64, _f32p]),
     ("d2d_get_map", C.c_int, [_ctx, _f32p]),
     ("d2d_power_map", C.c_int, [_ctx, C.POINTER(Params), _f32p, _f32p, _f32p, C.c_int32, C.c_int32, _f32p]),
     ("d2d_trace_paths", C.c_int, [_ctx, C.POINTER(Params), _f32p, _f32p, C.c_int32, _i32p, _i32p, C.c_int32,

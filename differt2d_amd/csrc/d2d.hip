@@ -1632,6 +1632,22 @@ int d2d_selftest_div(d2d_ctx* c, const float* x, const float* y, int64_t n, floa
     return D2D_OK;
 }
 
+int d2d_selftest_expf(d2d_ctx* c, const float* x, int64_t n, float* y) {
+    if (!c || !x || !y || n <= 0) return fail(D2D_ERR_INVALID, "bad argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    DevBuf<float> dx, dy;
+    if ((rc = dx.ensure((size_t)n)) || (rc = dy.ensure((size_t)n))) return rc;
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(d2d::selftest_expf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dx.p, dy.p, (long)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(y, dy.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    dx.release();
+    dy.release();
+    return D2D_OK;
+}
+
 int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return fail(D2D_ERR_INVALID, "d2d_set_option: NULL argument");
     if (!strcmp(name, "split_max_tiles")) c->split_max_tiles = value;

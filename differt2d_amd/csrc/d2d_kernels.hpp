@@ -259,7 +259,41 @@ __device__ __forceinline__ float clampact(float x, float alpha) {
     return fminf(fmaxf(z + 3.0f, 0.0f), 6.0f);
 }
 
-__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+// expf as the C library of the reference's host evaluates it -- glibc >= 2.27 (sysdeps/ieee754/flt-32/e_expf.c, from ARM's
+// optimized-routines): x N / ln 2 = k + r in double, exp(x) = 2^(k/N) * (C0 r^3 + C1 r^2 + C2 r + 1) with N = 32 and a table
+// of 2^(i/N), rounded to float once at the end.  jax.nn.sigmoid on XLA-CPU is its own polynomial and cannot be reproduced
+// here; what CAN be made identical is this repository's oracle (oracle/d2d_oracle.c calls libm's expf) and the device: the
+// device library's expf differs from libm's by an ulp in a few percent of the arguments, and the sigmoid mode's validity is a
+// product of such terms.  The same double operations in the same order, no contraction: checked bit for bit against libm over
+// 800 000 arguments on the host (scripts/check_expf_model.py) and on the device (tests/test_gpu_selftest.py).
+static __device__ __constant__ unsigned long long EXPF_TAB[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+__device__ __forceinline__ float expf_libm(float x) {
+    if (x != x) return x + x;
+    if (x > 0x1.62e42ep6f) return __builtin_inff();   // log(0x1p128)
+    if (x < -0x1.9fe368p6f) return 0.0f;              // log(0x1p-150)
+    if (x < -0x1.9d1d9ep6f) return 0x1p-149f;         // log(0x1p-149): __math_may_uflowf
+    const double z = (0x1.71547652b82fep+0 * 32.0) * (double)x;
+    double kd = z + 0x1.8p+52;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd = kd - 0x1.8p+52;
+    const double r = z - kd;
+    const unsigned long long t = EXPF_TAB[ki & 31ull] + (ki << 47);
+    const double sc = __longlong_as_double((long long)t);
+    const double zz = (0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0) * r + (0x1.ebfce50fac4f3p-3 / 32.0 / 32.0);
+    const double r2 = r * r;
+    double y = (0x1.62e42ff0c52d6p-1 / 32.0) * r + 1.0;
+    y = zz * r2 + y;
+    y = y * sc;
+    return (float)y;
+}
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf_libm(-z)); }
 
 // Sigmoid validity (MODE_SIG): the pre-activation z below which a candidate's contribution valid * fun <= exp(z) * f_max
 // is certainly less than a quarter ulp of `acc` -- adding it would leave acc unchanged under round to nearest, whatever
@@ -2839,6 +2873,12 @@ __global__ void selftest_div_kernel(const float* __restrict__ x, const float* __
     q_hostr[i] = div_with_rcp(x[i], y[i], ry[i]);  // with a host-computed correctly rounded reciprocal
 }
 
+// expf_libm on the device, for comparison with the host C library's expf (tests/test_gpu_selftest.py)
+__global__ void selftest_expf_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = expf_libm(x[i]);
+}
+
 // Shadow coverage of every wall as seen from the fixed end point `e` (the transmitter of an RX-grid sweep): one thread per
 // (wall w, blocker j) pair rasterises, into 64 bins of w's parametric range, where the segment e -> p is CERTAINLY
 // reported as intersecting j by the exact path (hard: hit; approx: the four activations exactly saturated), for every
@@ -3098,7 +3138,7 @@ struct Truth {
     __device__ float act(float x) const {
         float z = alpha * x;
         if (mode == MODE_HSIG) return minp(maxp(z + 3.0f, 0.0f), 6.0f) / 6.0f;
-        return 1.0f / (1.0f + expf(-z));
+        return 1.0f / (1.0f + expf_libm(-z));
     }
     __device__ float t_and(float a, float b) const { return mode ? minp(a, b) : ((a != 0.0f && b != 0.0f) ? 1.0f : 0.0f); }
     __device__ float t_or(float a, float b) const { return mode ? maxp(a, b) : ((a != 0.0f || b != 0.0f) ? 1.0f : 0.0f); }

@@ -174,7 +174,7 @@ struct DTruth {
         Dual<B> z = alpha * x;
         if (mode == MODE_HSIG) return dmin(dmax(z + 3.0f, dconst<B>(0.0f)), dconst<B>(6.0f)) / 6.0f;
         Dual<B> r;  // lax.logistic: value 1 / (1 + exp(-z)), JVP s (1 - s)
-        r.v = 1.0f / (1.0f + expf(-z.v));
+        r.v = 1.0f / (1.0f + expf_libm(-z.v));
         const float s1 = r.v * (1.0f - r.v);
 #pragma unroll
         for (int i = 0; i < B; ++i) r.d[i] = s1 * z.d[i];

@@ -262,7 +262,7 @@ __device__ __forceinline__ void act_vd(int mode, float alpha, float x, float& v,
         const float w6 = (y < 6.0f) ? 1.0f : ((y == 6.0f) ? 0.5f : 0.0f);
         d = (y != y) ? y : (alpha * w0 * w6) / 6.0f;
     } else {
-        v = 1.0f / (1.0f + expf(-z));
+        v = 1.0f / (1.0f + expf_libm(-z));
         d = alpha * (v * (1.0f - v));
     }
 }

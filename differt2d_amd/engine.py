@@ -293,6 +293,13 @@ class Context:
         L.check(self._lib.d2d_selftest_div(self._ctx, x, y, x.size, *outs))
         return outs
 
+    def selftest_expf(self, x) -> np.ndarray:
+        """The device's expf of the sigmoid activation (include/d2d.h: must equal the host libm's bit for bit)."""
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        y = np.empty_like(x)
+        L.check(self._lib.d2d_selftest_expf(self._ctx, x, x.size, y))
+        return y
+
     def get_map(self) -> np.ndarray:
         out = np.empty(self.shape, np.float32)
         L.check(self._lib.d2d_get_map(self._ctx, out))

@@ -277,6 +277,10 @@ int d2d_last_kernel_ms(d2d_ctx* ctx, float* ms);
  * reciprocal. For operands in [2^-62, 2^62] (or x == 0) all three must be bit-identical. */
 int d2d_selftest_div(d2d_ctx* ctx, const float* x, const float* y, int64_t n, float* q_fast, float* q_ref, float* q_hostr);
 
+/* Diagnostic: the device's expf as the sigmoid activation uses it (the algorithm of glibc's expf, in double, rounded once:
+ * d2d_kernels.hpp expf_libm) on x[n] -> y[n]; must equal the host C library's expf bit for bit. */
+int d2d_selftest_expf(d2d_ctx* ctx, const float* x, int64_t n, float* y);
+
 /* Synchronises and copies the resident value map to out[m*n]. */
 int d2d_get_map(d2d_ctx* ctx, float* out);
 

@@ -1,7 +1,7 @@
 """
 GPU parity: the HIP forward sweep (through the C ABI) against the CPU oracle on the same
 seeded inputs.  Bar: bit-exact in hard and hard_sigmoid modes (identical fp32 op chain, IEEE
-divide/sqrt, no contraction); sigmoid mode within rtol 2e-5 / atol 1e-5 (expf implementations
+divide/sqrt, no contraction); sigmoid mode within rtol 1e-6 and bit-equal in >= 99.9 % of the cells (expf evaluated
 differ by an ulp; BASELINE.json's tolerance is 1e-5).
 """
 
@@ -40,7 +40,14 @@ def _oracle(walls, tx, X, Y, **kw):
 def _compare(got, want, function):
     assert got.shape == want.shape and got.dtype == np.float32
     if function == "sigmoid":
-        np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-5)
+        # The device evaluates expf exactly as the oracle's C library does (d2d_kernels.hpp: expf_libm), so sigmoid maps are
+        # bit-comparable too -- up to two effects that touch a cell in a million: the oracle's libm may pick an FMA build of
+        # the same polynomial (the double result then differs by an ulp before the rounding to float), and the kernel takes
+        # sigmoid(min z) where the reference takes min(sigmoid z) (equal wherever the fp32 sigmoid is monotone).  Bar: 1e-6
+        # (north_star: 1e-5) everywhere, and bit equality in all but 0.1 % of the cells.
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9)
+        same = (got == want) | (np.isnan(got) & np.isnan(want))
+        assert same.mean() >= 0.999, f"{int((~same).sum())} of {same.size} cells differ in some bit"
     else:
         bad = ~((got == want) | (np.isnan(got) & np.isnan(want)))
         assert not bad.any(), f"{bad.sum()} of {bad.size} cells differ; max abs {np.nanmax(np.abs(got - want))}"

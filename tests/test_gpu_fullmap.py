@@ -105,9 +105,10 @@ def test_cfg2_full_map_against_live_oracle(ctx, mode):
 
 
 def test_cfg2_sigmoid_full_map_properties(ctx):
-    """sigmoid validity is not bit-comparable (device expf vs libm expf, <= 2e-5 relative): full-map properties instead --
-    finite, non-negative, and bounded by the hard_sigmoid-free LOS term in unoccluded cells; a 64-row sample against the
-    oracle at rtol 2e-5."""
+    """sigmoid validity: the device's expf is the oracle's libm algorithm (d2d_kernels.hpp: expf_libm), so the map is
+    comparable bit for bit except where the host's libm runs its FMA build or the fp32 sigmoid is not monotone (see
+    tests/test_gpu_forward.py::_compare): full-map properties -- finite, non-negative -- and a 64-row sample (65 536 cells)
+    against the oracle at rtol 1e-6, bit-equal in >= 99.9 % of the cells."""
     from oracle import c_oracle as CO
 
     tx, walls, X, Y = _workload()
@@ -116,4 +117,7 @@ def test_cfg2_sigmoid_full_map_properties(ctx):
     assert np.isfinite(got).all() and (got >= 0).all()
     rows = np.linspace(0, 1023, 64).astype(int)
     want = CO.power_map(walls, tx, X[rows], Y[rows], min_order=0, max_order=2, prune=True, approx=True, function="sigmoid")
-    np.testing.assert_allclose(got[rows], want, rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(got[rows], want, rtol=1e-6, atol=1e-9)
+    same = got[rows] == want
+    print(f"   sigmoid, 65 536 cells: {int((~same).sum())} differ in some bit, max rel {np.max(np.abs(got[rows] - want) / np.maximum(np.abs(want), 1e-30)):.2e}")
+    assert same.mean() >= 0.999

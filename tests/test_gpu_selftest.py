@@ -32,3 +32,29 @@ def test_bare_division_chain_is_correctly_rounded():
     assert np.array_equal(q_ref, want), "generic expansion is not IEEE"
     bad = np.flatnonzero(q_fast.view(np.uint32) != want.view(np.uint32))
     assert bad.size == 0, f"{bad.size} of {x.size} quotients differ, e.g. {x[bad[:3]]} / {y[bad[:3]]}"
+
+
+def test_device_expf_is_the_host_libms():
+    """The sigmoid activation's expf (d2d_kernels.hpp: expf_libm -- glibc's algorithm in double, rounded once) against the C
+    library of this host (what oracle/d2d_oracle.c calls): bit for bit over the range the sweeps use, the overflow / underflow
+    edges, subnormal results, and the special values."""
+    import ctypes
+
+    from differt2d_amd.engine import Context
+
+    libm = ctypes.CDLL("libm.so.6")
+    libm.expf.restype = ctypes.c_float
+    libm.expf.argtypes = [ctypes.c_float]
+    rng = np.random.default_rng(3)
+    parts = [(rng.random(60000) * (hi - lo) + lo).astype(np.float32) for lo, hi in ((-104.5, 89.5), (-20, 20), (-1, 1), (-1e-3, 1e-3), (-104, -86))]
+    parts.append(np.array([0.0, -0.0, 88.72283, 88.72284, 88.7229, -103.27893, -103.2789, -103.97207, -103.97208, -87.33655, np.inf, -np.inf,
+                           1e-40, -1e-40, 3.4e38, -3.4e38], np.float32))
+    x = np.concatenate(parts)
+    with np.errstate(over="ignore"):
+        want = np.array([libm.expf(float(v)) for v in x], np.float32)
+    with Context(0) as ctx:
+        got = ctx.selftest_expf(x)
+        nan = ctx.selftest_expf(np.array([np.nan], np.float32))
+    bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+    assert bad.size == 0, f"{bad.size} of {x.size} differ, e.g. x = {x[bad[:4]]}: device {got[bad[:4]]}, libm {want[bad[:4]]}"
+    assert np.isnan(nan[0])
