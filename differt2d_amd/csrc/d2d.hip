@@ -32,6 +32,7 @@ template <int MODE> hipError_t launch_vg_m(bool txg, bool grad, dim3 grid, size_
 template <int MODE> hipError_t launch_fwd_listed_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <int MODE> hipError_t launch_fwd_grad_listed_m(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 template <int MODE> hipError_t launch_fwd_split_listed_m(bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <int MODE> hipError_t launch_fwd_coop_m(int max_order, int W, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
 
 #define D2D_DECLARE_MODE(M)                                                                                   \
     template <> hipError_t launch_fwd_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);           \
@@ -41,7 +42,8 @@ template <int MODE> hipError_t launch_fwd_split_listed_m(bool stats, int max_ord
     template <> hipError_t launch_vg_m<M>(bool, bool, dim3, size_t, hipStream_t, const SweepArgs&);              \
     template <> hipError_t launch_fwd_listed_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);       \
     template <> hipError_t launch_fwd_grad_listed_m<M>(int, dim3, size_t, hipStream_t, const SweepArgs&);        \
-    template <> hipError_t launch_fwd_split_listed_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&);
+    template <> hipError_t launch_fwd_split_listed_m<M>(bool, int, dim3, size_t, hipStream_t, const SweepArgs&); \
+    template <> hipError_t launch_fwd_coop_m<M>(int, int, dim3, size_t, hipStream_t, const SweepArgs&);
 D2D_DECLARE_MODE(MODE_HARD)
 D2D_DECLARE_MODE(MODE_HSIG)
 D2D_DECLARE_MODE(MODE_SIG)
@@ -65,6 +67,9 @@ hipError_t launch_fwd_grad(int mode, bool listed, int max_order, dim3 grid, size
 hipError_t launch_fwd_split(int mode, bool listed, bool stats, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
     if (listed) { D2D_BY_MODE(launch_fwd_split_listed_m, stats, max_order, grid, lds, s, a) }
     D2D_BY_MODE(launch_fwd_split_m, stats, max_order, grid, lds, s, a)
+}
+hipError_t launch_fwd_coop(int mode, int max_order, int W, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    D2D_BY_MODE(launch_fwd_coop_m, max_order, W, grid, lds, s, a)
 }
 hipError_t launch_txg(int mode, bool listed, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
     D2D_BY_MODE(launch_txg_m, listed, grad, max_order, grid, lds, s, a)
@@ -180,6 +185,7 @@ struct d2d_ctx {
     long long sched_min_tiles = 2048;   // launches with fewer patches keep the identity schedule
     uint64_t grid_hash = 0, grid_token = 0;  // content hash / caller's version token of the resident grid (valid with have_grid)
     bool grid_hash_valid = false;
+    int last_shape_waves = 0, last_shape_coop = 0;  // diagnostic: d2d_debug_sweep_shape
     long long grid_reuses = 0;  // d2d_set_grid calls that found their grid resident already (diagnostic: d2d_debug_grid_reuses)
     float grid_absmax = 0.0f;   // max |coordinate| of the grid (host scan at d2d_set_grid)
     bool grid_all_finite = false;  // every cell coordinate is below 1e18 in magnitude (what the kernels call comfortably finite)
@@ -194,6 +200,9 @@ struct d2d_ctx {
     bool have_grad = false;  // d_grad holds the per-cell gradient map of a sweep of the CURRENT grid (2 m n values)
     bool want_wave_cycles = false;
     long long split_max_tiles = 8192;   // launches up to this many patches share every patch between 4 waves
+    long long coop_max_tiles = -1;      // ... and up to this many candidate by candidate (power_fwd_coop_kernel); -1: by the validity mode
+    bool split_sigmoid = false;         // sigmoid validity: share patches prefix by prefix like the other modes (slower: A/B and tests)
+    long long coop_waves = -1;          // its waves per patch: -1 by the launch's size and mode (16 / 8 / none), 0 never, else 4, 8 or 16
     long long heavy_split = -1;        // bigger launches with a work history: this many of the dearest patches are cut in four (-1: by the launch's size)
     DevBuf<float> d_heavy_list;
     DevBuf<int> d_heavy_cnt, d_heavy_done;
@@ -803,6 +812,13 @@ int d2d_set_grid(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t 
 
 int d2d_set_grid_versioned(d2d_ctx* c, const float* X, const float* Y, int32_t m, int32_t n, uint64_t version) {
     return set_grid_impl(c, X, Y, m, n, version);
+}
+
+int d2d_debug_sweep_shape(d2d_ctx* c, int32_t* waves_per_patch, int32_t* candidates) {
+    if (!c || !waves_per_patch || !candidates) return fail(D2D_ERR_INVALID, "NULL argument");
+    *waves_per_patch = c->last_shape_waves;
+    *candidates = c->last_shape_coop;
+    return D2D_OK;
 }
 
 int d2d_debug_grid_reuses(d2d_ctx* c, int64_t* count) {
@@ -1488,10 +1504,28 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     constexpr int D2D_SPLIT_W = d2d::SPLIT_W;
     const d2d_host::SplitLds sl = d2d_host::split_lds_bytes(c->N, D2D_SPLIT_W, d2d::SPLIT_LIST);
     const size_t split_base = sl.base, split_lds = sl.total;  // ... + one culling queue per wave
-    const bool split = p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= d2d_host::LDS_LIMIT && tiles <= c->split_max_tiles;
+    // (sigmoid validity: a wave that adds to a list instead of the running sum loses the sum's absorption shortcut, sig_zc_of --
+    // measured at 64^2 .. 640^2 cells of cfg2's scene the shared patches take 7.5 .. 11.6 ms, one wave per patch 5.4 .. 7.8)
+    const bool split = p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= d2d_host::LDS_LIMIT && tiles <= c->split_max_tiles &&
+                       (mode != d2d::MODE_SIG || c->split_sigmoid);
+    // the smallest launches (the grids of the reference's own examples): W waves per patch, candidate by candidate
+    // (power_fwd_coop_kernel).  Measured on cfg2's scene, ms per sweep kernel, best other kernel first:
+    //   hard  128^2 0.096 -> 0.072 (16 waves)   200^2 0.093 -> 0.085 (8)   256^2 0.091 / 0.097 (8): none from there on
+    //   hsig  128^2 0.204 -> 0.119 (16)         320^2 0.180 -> 0.163 (8)   384^2 0.136 -> 0.106 (8)   448^2 0.138 / 0.134
+    //   sig   128^2 6.48 -> 1.28 (16)   200^2 6.26 -> 1.93 (16)   320^2 6.20 -> 3.07 (8)   512^2 5.35 -> 4.35 (4)   640^2 5.6 / 6.3
+    int coop_w = 0;
+    if (p->max_order >= 2 && c->cw.size() >= 2 && a.rl != nullptr && !d_stats && c->coop_waves != 0) {
+        const bool sig = mode == d2d::MODE_SIG;
+        const long long lim = c->coop_max_tiles >= 0 ? c->coop_max_tiles : (mode == d2d::MODE_HARD ? 640 : (sig ? 4096 : 2304));
+        if (c->coop_waves > 0) coop_w = (int)c->coop_waves;
+        else if (sig) coop_w = tiles <= 640 ? 16 : (tiles <= 1600 ? 8 : 4);
+        else coop_w = tiles <= 256 ? 16 : 8;
+        // ("split_max_tiles" = 0 asks for one wave per patch whatever the size: honoured unless the waves are forced)
+        if (d2d_host::coop_lds_bytes(c->N, coop_w, d2d::COOP_C) > d2d_host::LDS_LIMIT || tiles > lim || (c->coop_waves < 0 && tiles > c->split_max_tiles)) coop_w = 0;
+    }
     // the dearest patches of a bigger launch are cut in four (see power_fwd_kernel); they are only known with a work history
     dim3 grid_fwd = grid_patches;
-    if (!split && !d_stats && p->max_order == 2 && c->cw.size() >= 2 && a.sched == c->d_sched.p && sched_from_history && c->heavy_split != 0) {
+    if (!split && !coop_w && !d_stats && p->max_order == 2 && c->cw.size() >= 2 && a.sched == c->d_sched.p && sched_from_history && c->heavy_split != 0) {
         const long long P = d2d::HEAVY_PARTS;
         // -1 (default): launches that are only a few patch latencies long (fewer than 4 patches per wave slot of the chip)
         // are bound by their dearest patches: one patch in 93 is cut there (measured best at 1024^2), else 64 patches
@@ -1523,7 +1557,10 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
     }
     a.cullq_off = (int)(split ? split_base : (size_t)(4 * c->N + 1) * sizeof(float4));
-    if (split) HIP_TRY(d2d::launch_fwd_split(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, grid_patches, split_lds, c->stream, a));
+    c->last_shape_waves = coop_w ? coop_w : (split ? 4 : 1);
+    c->last_shape_coop = coop_w ? 1 : 0;
+    if (coop_w) HIP_TRY(d2d::launch_fwd_coop(mode, p->max_order, coop_w, grid_patches, d2d_host::coop_lds_bytes(c->N, coop_w, d2d::COOP_C), c->stream, a));
+    else if (split) HIP_TRY(d2d::launch_fwd_split(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, grid_patches, split_lds, c->stream, a));
     else {
         // one patch per wave, fwd_waves waves per workgroup (fewer, bigger workgroups are dispatched faster)
         // (0: 4 when a single-wave workgroup's LDS would keep a CU below 32 waves, else 1; STATS and the enumerating build: 1)
@@ -1651,6 +1688,12 @@ int d2d_selftest_expf(d2d_ctx* c, const float* x, int64_t n, float* y) {
 int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return fail(D2D_ERR_INVALID, "d2d_set_option: NULL argument");
     if (!strcmp(name, "split_max_tiles")) c->split_max_tiles = value;
+    else if (!strcmp(name, "coop_max_tiles")) c->coop_max_tiles = value;
+    else if (!strcmp(name, "split_sigmoid")) c->split_sigmoid = value != 0;
+    else if (!strcmp(name, "coop_waves")) {
+        if (value != -1 && value != 0 && value != 4 && value != 8 && value != 16) return fail(D2D_ERR_INVALID, "coop_waves must be -1, 0, 4, 8 or 16, got %lld", (long long)value);
+        c->coop_waves = value;
+    }
     else if (!strcmp(name, "sched_min_tiles")) c->sched_min_tiles = value;
     else if (!strcmp(name, "heavy_split")) c->heavy_split = value;
     else if (!strcmp(name, "time_kernel")) c->time_kernel = value != 0;

@@ -179,6 +179,11 @@ inline SplitLds split_lds_bytes(int n_objects, int W, int list_len) {
     return s;
 }
 
+// candidate-sharing kernel (W waves, power_fwd_coop_kernel): tables + the rounds' slots [W][C][64]
+inline size_t coop_lds_bytes(int n_objects, int W, int C) {
+    return (size_t)(3 * n_objects + 1) * 16 + (size_t)W * (size_t)C * 64 * sizeof(float);
+}
+
 struct HeavyPlan {
     long long H = 0;           // patches cut in `parts` (0: none)
     long long cap = 0;         // list entries per lane and part

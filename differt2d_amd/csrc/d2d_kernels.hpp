@@ -350,7 +350,10 @@ template <int K, int MODE, bool STATS, bool GRAD = false, bool PREF = true, bool
 __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&cand)[D2D_MAX_ORDER],
                                                const float (&imgx)[D2D_MAX_ORDER], const float (&imgy)[D2D_MAX_ORDER],
                                                float txx, float txy, float rxx, float rxy, bool lane_bad, float& acc,
-                                               WaveStats& st, GradCtx* g = nullptr) {
+                                               WaveStats& st, GradCtx* g = nullptr, float acc_floor = -1.0f) {
+    // acc_floor >= 0 (MODE_SIG, fun >= 0): the caller adds this candidate to a sum it does not hold -- `acc` is a scratch
+    // that receives the contribution alone -- but knows that sum to be at least acc_floor when the addition happens
+    const float zc_acc = (acc_floor >= 0.0f) ? acc_floor : acc;
     int on_i = 0, on_w = 0, hit_i = 0, hit_j = -1;  // GRAD: which activation carries the min / max
     bool znan = false;  // GRAD: the reference's autodiff yields NaN for this (cell, candidate), see below
     float px[K + 2], py[K + 2];
@@ -441,7 +444,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     bool off;
                     if (MODE == MODE_HARD) off = !((sw >= 0.0f) && (sw <= 1.0f));
                     else if (MODE == MODE_HSIG) off = fminf(clampact(sw - 0.0f, a.alpha), clampact(1.0f - sw, a.alpha)) == 0.0f;
-                    else off = fminf(a.alpha * (sw - 0.0f), a.alpha * (1.0f - sw)) <= fmaxf(-89.0f, sig_zc_of(a.sig_l2f, acc));
+                    else off = fminf(a.alpha * (sw - 0.0f), a.alpha * (1.0f - sw)) <= fmaxf(-89.0f, sig_zc_of(a.sig_l2f, zc_acc));
                     const bool pt_bad = lane_bad || !(fabsf(ptx) < 1e18f) || !(fabsf(pty) < 1e18f);
                     if (!wave_any(!off || pt_bad)) {
                         if (STATS && i == K - 1) st.c[15] += 1;  // died at the last wall (the first the scan reaches)
@@ -524,7 +527,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // ... or, for this lane's running sum, once the contribution is certainly below a quarter ulp of it (sig_zc_of; not in
     // the value+grad build: the adjoints are not absorbed by the sum)
     bool on_zero = (MODE == MODE_HARD) ? !on_b : (MODE == MODE_HSIG) ? (on_c == 0.0f)
-                   : (on_z <= (GRAD ? -89.0f : fmaxf(-89.0f, sig_zc_of(a.sig_l2f, acc))));
+                   : (on_z <= (GRAD ? -89.0f : fmaxf(-89.0f, sig_zc_of(a.sig_l2f, zc_acc))));
     if (K > 0 && !wave_any(!on_zero || bad)) return;  // valid == 0 in every lane: acc + 0.0
 
     // Lanes for which the occlusion result can still change the output.  (is_valid = all(on_objects,
@@ -2234,6 +2237,214 @@ __global__ void __launch_bounds__(64 * W) power_fwd_split_kernel(SweepArgs a) {
         return;
     }
     split_patch<MODE, STATS, MAXK, W, LISTED>(a, tab, lists, meta, (long)blockIdx.x, false);
+}
+
+// ---- small launches: every patch shared by W waves, candidate by candidate -----------------------------------------------
+// A launch of a few hundred patches cannot fill 1024 SIMDs with one wave -- or four -- per patch, and it is as long as its
+// dearest patch: 58 000 wave-instructions at 300 x 300 cells of cfg2's scene against a mean of 8 600 (d2d_debug_get_work), at
+// the ~8 cycles per instruction of a wave that has its SIMD almost to itself.  Here the W waves of a workgroup share a patch
+// at the finest grain that keeps the reference's sum order:
+//   culling     the 64-candidate batches of an order -- the allowed walls (K = 1), the region's candidate list (K >= 2) --
+//               are dealt to the waves round-robin; each wave runs the full culling test on its batches and leaves the
+//               survivors' masks in LDS: every candidate is culled once per patch;
+//   evaluation  in rounds of W x COOP_C survivors: the survivor of rank r0 + i W + w goes to wave w (INTERLEAVED: a visible
+//               wall costs 20 x what a candidate that dies at on_objects costs, and neighbours in candidate order cost
+//               alike), which stores its contribution -- zero or not -- in slot [w][i] of LDS;
+//   summation   wave 0 adds the round's slots in rank order (adding an exact +0.0 never changes acc, which is never -0.0):
+//               the reference's left-to-right fp32 sum (scene.py:1893-1916), bit for bit; nothing can overflow.
+// Lists longer than COOP_MAXB batches are processed window by window.  LISTED launches only (the region lists exist);
+// patches that cannot use their lists go to the queue of the enumerating kernel like everywhere else.
+constexpr int COOP_C = 8;
+constexpr int COOP_MAXB = 256;
+
+template <int K, int MODE, int W>
+__device__ __forceinline__ void coop_order(const SweepArgs& a, const float4* tab, float* slots, unsigned long long* bmask, int* bchunk,
+                                           float* accpub, const float (&bx)[4], const float (&by)[4], float rxx, float rxy, bool lane_bad,
+                                           float& acc, WaveStats& st, long region) {
+    static_assert(K >= 1 && (W & (W - 1)) == 0, "orders >= 1, a power of two of waves");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // Sigmoid validity with fun >= 0: the cells' sums never shrink, so the sums wave 0 held after the last round are a floor
+    // of the sums every later contribution is added to -- what is certainly below a quarter ulp of the floor is certainly
+    // absorbed (sig_zc_of), in the culling and in the evaluation alike (power_fwd_kernel does this with the sum itself).
+    const bool floor_on = (MODE == MODE_SIG) && a.sig_mono;
+    if (floor_on) {
+        if (wv == 0) accpub[lane] = acc;
+        __syncthreads();
+    }
+    const auto* rlc = cmem(a.rl);
+    const int n = (K == 1) ? a.Nc : cmem(rlc->leaf.cnt[K >= 2 ? K : 2])[region];
+    const int nb = (n + 63) >> 6;
+    const auto* pool = cmem(rlc->lp.pool);
+    const auto* next = cmem(rlc->lp.next);
+    int chunk = (K == 1) ? 0 : rlc->leaf.chunk0[K >= 2 ? K : 2] + (int)region;  // the chunk of the window's first batch
+    for (int b0 = 0; b0 < nb; b0 += COOP_MAXB) {  // (workgroup-uniform)
+        const int nbw = (nb - b0 < COOP_MAXB) ? nb - b0 : COOP_MAXB;
+        // ---- culling: batch b0 + i of the window to wave i % W
+        {
+            float on_lo = a.on_lo, on_hi = a.on_hi;
+            if (floor_on) {
+                float zc = sig_zc_of(a.sig_l2f, accpub[lane]);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) zc = fminf(zc, __shfl_xor(zc, o, 64));
+                if (zc > -89.0f) {
+                    const float wdn = zc / a.alpha * 1.00001f - 1e-30f;  // (negative) s < wdn or s > 1 - wdn: negligible
+                    on_lo = fmaxf(on_lo, wdn);
+                    on_hi = fminf(on_hi, 1.0f - wdn);
+                }
+            }
+            int ch = chunk;
+            for (int i = 0; i < nbw; ++i) {
+                const int off = (b0 + i) << 6;
+                if ((i & (W - 1)) == wv) {
+                    unsigned long long m;
+                    if constexpr (K == 1) {
+                        const int lp = off + lane;
+                        const int wl = cmem(a.cw)[lp < n ? lp : 0];
+                        WallC w[1];
+                        float Ix[1], Iy[1];
+                        const float4 r0 = tab[2 * wl], r1 = tab[2 * wl + 1], fc = tab[2 * a.N + wl];
+                        w[0] = make_wallc(r0, r1, fc, wl);
+                        image_of(r0, a.txx, a.txy, Ix[0], Iy[0]);
+                        const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[wl] : 0ull;
+                        m = __ballot(lp < n && !cull_candidate<1>(bx, by, w, Ix, Iy, a, sh0, on_lo, on_hi));
+                    } else {
+                        const bool have = off + lane < n;
+                        const unsigned long long code = pool[(size_t)ch * RL_CHUNK + (off & (RL_CHUNK - 1)) + (have ? lane : 0)];
+                        float Ix[K], Iy[K];
+                        m = cull_batch<K, false>(a, tab, bx, by, code, have, Ix, Iy, on_lo, on_hi);
+                    }
+                    if (lane == 0) {
+                        bmask[i] = m;
+                        bchunk[i] = ch;
+                    }
+                    D2D_WORK(5 * K);
+                }
+                if (K >= 2 && (off & (RL_CHUNK - 1)) == RL_CHUNK - 64 && off + 64 < n) ch = next[ch];
+            }
+            chunk = ch;  // (every wave walks the whole chain: the next window starts where this one ended)
+        }
+        __syncthreads();
+        int T = 0;
+        for (int i = 0; i < nbw; ++i) T += __builtin_popcountll(bmask[i]);
+        T = __builtin_amdgcn_readfirstlane(T);
+        // ---- evaluation in rounds, summation by wave 0
+        for (int r0 = 0; r0 < T; r0 += W * COOP_C) {  // (workgroup-uniform)
+            const int R = (T - r0 < W * COOP_C) ? T - r0 : W * COOP_C;
+            const float acc_floor = floor_on ? accpub[lane] : -1.0f;
+            int ord = 0;
+            for (int i = 0; i < nbw && ord < r0 + R; ++i) {
+                const unsigned long long mb = bmask[i];
+                unsigned long long m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mb >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(mb & 0xffffffffull));
+                const int nbits = __builtin_popcountll(m);
+                if (ord + nbits <= r0) {
+                    ord += nbits;
+                    continue;
+                }
+                const size_t base = (K == 1) ? (size_t)((b0 + i) << 6)
+                                             : (size_t)__builtin_amdgcn_readfirstlane(bchunk[i]) * RL_CHUNK + (((b0 + i) << 6) & (RL_CHUNK - 1));
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int rel = ord - r0;
+                    ++ord;
+                    if (rel < 0) continue;
+                    if (rel >= R) break;
+                    if ((rel & (W - 1)) != wv) continue;
+                    int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+                    float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
+                    if constexpr (K == 1) {
+                        ce[0] = cmem(a.cw)[base + bit];
+                        image_of(ldc4(a.refl, 2 * ce[0]), a.txx, a.txy, ex[0], ey[0]);
+                    } else {
+                        const unsigned long long cu = pool[base + bit];  // wave-uniform: a scalar load
+#pragma unroll
+                        for (int d = 0; d < K; ++d) {
+                            ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
+                            // the image chain: the same operations on the same operands as everywhere else (geometry.py:1086-1091)
+                            image_of(ldc4(a.refl, 2 * ce[d]), d == 0 ? a.txx : ex[d > 0 ? d - 1 : 0], d == 0 ? a.txy : ey[d > 0 ? d - 1 : 0], ex[d], ey[d]);
+                        }
+                    }
+                    float t = 0.0f;
+                    eval_candidate<K, MODE, false, false, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, lane_bad, t, st, nullptr, acc_floor);
+                    slots[((wv * COOP_C) + (rel / W)) * 64 + lane] = t;
+                }
+            }
+            __syncthreads();
+            if (wv == 0) {
+                for (int rel = 0; rel < R; ++rel) acc = acc + slots[(((rel & (W - 1)) * COOP_C) + (rel / W)) * 64 + lane];  // scene.py:1909, in candidate order
+                if (floor_on) accpub[lane] = acc;
+            }
+            __syncthreads();  // the slots are reused by the next round, the masks by the next window / order
+        }
+        __syncthreads();
+    }
+}
+
+template <int MODE, int MAXK, int W>
+__global__ void __launch_bounds__(64 * W) power_fwd_coop_kernel(SweepArgs a) {
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then the rounds' slots [W][COOP_C][64]
+    __shared__ unsigned long long bmask[COOP_MAXB];
+    __shared__ int bchunk[COOP_MAXB];
+    __shared__ float accpub[64];
+    __shared__ unsigned wave_work[W];
+    for (int i = threadIdx.x; i < 2 * a.N; i += 64 * W) tab[i] = ldc4(a.refl, i);
+    for (int i = threadIdx.x; i < a.N; i += 64 * W) tab[2 * a.N + i] = ldc4(a.flt, i);
+    float* slots = reinterpret_cast<float*>(tab + 3 * a.N);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
+    WaveStats st;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st.c[i] = 0;
+    st.shadow = -1;
+    st.work = 0;
+    const int tile = a.sched ? a.sched[blockIdx.x] : (int)blockIdx.x;
+    const int tcol = tile % tiles_x, trow = tile / tiles_x;
+    const long region = region_of(a, tcol, trow);
+    const int col = tcol * TILE_W + (lane & (TILE_W - 1));
+    const int row = trow * TILE_H + (lane / TILE_W);
+    const bool in_range = (col < a.n) && (row < a.m);
+    const int ccol = col < a.n ? col : a.n - 1;
+    const int crow = row < a.m ? row : a.m - 1;
+    const long idx = (long)crow * a.n + ccol;
+    const float rxx = a.X[idx], rxy = a.Y[idx];
+    const bool lane_bad = !(fabsf(rxx) < 1e18f) || !(fabsf(rxy) < 1e18f) || !(fabsf(a.txx) < 1e18f) || !(fabsf(a.txy) < 1e18f);
+    // not this kernel's patch (every wave of the workgroup sees the same cells): leave it to the enumerating kernel
+    if (cmem(cmem(a.rl)->flag)[region] != 0 || wave_any(lane_bad)) {
+        if (threadIdx.x == 0) a.fb_list[atomicAdd(a.fb_n, 1)] = tile;
+        return;
+    }
+    float acc = 0.0f;  // scene.py:1893
+    float x0 = rxx, x1 = rxx, y0 = rxy, y1 = rxy;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, off, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
+        y0 = fminf(y0, __shfl_xor(y0, off, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+    }
+    const float bx[4] = {x0, x1, x1, x0};
+    const float by[4] = {y0, y0, y1, y1};
+    if (wv == 0 && a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, false>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, nullptr);
+    if (a.min_order <= 1 && a.max_order >= 1) coop_order<1, MODE, W>(a, tab, slots, bmask, bchunk, accpub, bx, by, rxx, rxy, lane_bad, acc, st, region);
+    if (a.min_order <= 2 && a.max_order >= 2) coop_order<2, MODE, W>(a, tab, slots, bmask, bchunk, accpub, bx, by, rxx, rxy, lane_bad, acc, st, region);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) coop_order<3, MODE, W>(a, tab, slots, bmask, bchunk, accpub, bx, by, rxx, rxy, lane_bad, acc, st, region);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) coop_order<4, MODE, W>(a, tab, slots, bmask, bchunk, accpub, bx, by, rxx, rxy, lane_bad, acc, st, region);
+    if (wv == 0 && in_range) {
+        if (a.out_mode == D2D_OUT_ADD) a.out[idx] = a.out[idx] + acc;
+        else a.out[idx] = acc;
+    }
+    if (a.cost_out) {  // the work of the patch = the sum over its waves
+        if (lane == 0) wave_work[wv] = st.work;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned sum = 0;
+#pragma unroll
+            for (int i = 0; i < W; ++i) sum += wave_work[i];
+            a.cost_out[tile] = sum;
+        }
+    }
 }
 
 // Bounding box of the cells of a region, from the level's table (region_box_kernel: {x0, x1, y0, y1}, x0 = NaN when a

@@ -18,6 +18,8 @@ hipError_t launch_fwd_grad(int mode, bool listed, int max_order, dim3 grid, size
 // power_fwd_split_kernel<MODE, STATS, MAXK, 4>: every patch shared by 4 waves (small launches)
 constexpr int SPLIT_W = 4;
 hipError_t launch_fwd_split(int mode, bool listed, bool stats, int max_order, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a);
+// power_fwd_coop_kernel<MODE, MAXK, W>: small launches with region lists, every patch shared by W = 4, 8 or 16 waves candidate by candidate
+hipError_t launch_fwd_coop(int mode, int max_order, int W, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a);
 // power_fwd_txg_kernel<MODE, MAXK, GRADK>: TX grids, culled
 hipError_t launch_txg(int mode, bool listed, bool grad, int max_order, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a);
 // power_vg_kernel<MODE, TXG, GRADK>: exhaustive sweeps (strict_nan value+grad; "txg_exhaustive" values)

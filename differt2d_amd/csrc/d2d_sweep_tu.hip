@@ -1,6 +1,6 @@
 // One translation unit per (kernel family, validity mode): instantiates the sweep kernels of that pair and defines the
 // per-mode launcher that d2d_launch.cpp's dispatchers call.  Compiled several times by the Makefile with
-//   -DD2D_TU_FAMILY={0 fwd, 1 fwd_grad, 2 fwd_split, 3 txg, 4 vg, 5 region lists (mode 0 only),
+//   -DD2D_TU_FAMILY={0 fwd, 1 fwd_grad, 2 fwd_split, 3 txg, 4 vg, 5 region lists (mode 0 only), 9 fwd_coop,
 //   6 fwd / 7 fwd_grad / 8 fwd_split with the orders >= 2 taken from the region lists (LISTED)}  -DD2D_TU_MODE={0 hard, 1 hard_sigmoid, 2 sigmoid}
 #include "d2d_launch.hpp"
 
@@ -136,6 +136,22 @@ hipError_t launch_fwd_split_listed_m<TU_MODE>(bool stats, int max_order, dim3 gr
         else if (max_order == 3) hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, false, 3, SPLIT_W, true>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((power_fwd_split_kernel<TU_MODE, false, 4, SPLIT_W, true>), grid, block, lds, s, a);
     }
+    return hipGetLastError();
+}
+#elif D2D_TU_FAMILY == 9
+template <int MODE> hipError_t launch_fwd_coop_m(int max_order, int W, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a);
+template <int W>
+static void launch_fwd_coop_w(int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    const dim3 block(64 * W);
+    if (max_order <= 2) hipLaunchKernelGGL((power_fwd_coop_kernel<TU_MODE, 2, W>), grid, block, lds, s, a);
+    else if (max_order == 3) hipLaunchKernelGGL((power_fwd_coop_kernel<TU_MODE, 3, W>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((power_fwd_coop_kernel<TU_MODE, 4, W>), grid, block, lds, s, a);
+}
+template <>
+hipError_t launch_fwd_coop_m<TU_MODE>(int max_order, int W, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a) {
+    if (W == 16) launch_fwd_coop_w<16>(max_order, grid, lds, s, a);
+    else if (W == 8) launch_fwd_coop_w<8>(max_order, grid, lds, s, a);
+    else launch_fwd_coop_w<4>(max_order, grid, lds, s, a);
     return hipGetLastError();
 }
 #elif D2D_TU_FAMILY == 5

@@ -188,6 +188,12 @@ class Context:
         L.check(self._lib.d2d_debug_grid_reuses(self._ctx, C.byref(n)))
         return int(n.value)
 
+    def sweep_shape(self) -> tuple:
+        """Diagnostic: (waves per patch, shared candidate by candidate?) of the last RX-grid value sweep (include/d2d.h)."""
+        w, k = C.c_int32(0), C.c_int32(0)
+        L.check(self._lib.d2d_debug_sweep_shape(self._ctx, C.byref(w), C.byref(k)))
+        return int(w.value), bool(k.value)
+
     def launch(self, params: L.Params, tx):
         tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(2)
         L.check(self._lib.d2d_power_map_launch(self._ctx, C.byref(params), tx))

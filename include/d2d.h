@@ -155,6 +155,10 @@ int d2d_set_grid(d2d_ctx* ctx, const float* X, const float* Y, int32_t m, int32_
 int d2d_set_grid_versioned(d2d_ctx* ctx, const float* X, const float* Y, int32_t m, int32_t n, uint64_t version);
 /* Diagnostic: how many d2d_set_grid / d2d_set_grid_versioned calls found their grid resident already. */
 int d2d_debug_grid_reuses(d2d_ctx* ctx, int64_t* count);
+/* Diagnostic: the launch shape of the last RX-grid value sweep -- waves_per_patch = 1 (one wave per patch, the dearest
+ * patches cut in parts), 4 (patches shared by 4 waves prefix by prefix) or, with candidates = 1, the 4 / 8 / 16 waves of
+ * the kernel that shares a patch candidate by candidate (options coop_waves, coop_max_tiles); 0 before any sweep. */
+int d2d_debug_sweep_shape(d2d_ctx* ctx, int32_t* waves_per_patch, int32_t* candidates);
 
 /* Initial guesses of the optimiser-based solvers for the NEXT sweeps: theta0[n_candidates * many][D2D_MAX_ORDER]
  * (n_rows = n_candidates * max(1, params->many)), candidates in enumeration order, the `many` starts of one candidate
@@ -211,7 +215,15 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
                               int64_t* n_waves);
 
 /* Launch-shape tuning of a context; never changes a result bit (tests sweep these to cover every kernel variant).
- *   "split_max_tiles": launches of at most this many 8 x 8 patches share every patch between 4 waves (default 8192; 0 = never)
+ *   "split_max_tiles": launches of at most this many 8 x 8 patches share every patch between 4 waves (default 8192; 0 = never;
+ *                  never with sigmoid validity unless "split_sigmoid" is non-zero: one wave per patch is faster there)
+ *   "coop_waves": the smallest launches share every patch between this many waves CANDIDATE BY CANDIDATE, wave 0 adding the
+ *                  contributions in the reference's order (4, 8 or 16; 0 = never; default -1: by the launch's size and
+ *                  validity mode -- 16 waves up to 256 patches and 8 up to 640 (hard) / 2304 (hard_sigmoid), 16 / 8 / 4 up
+ *                  to 640 / 1600 / 4096 patches with sigmoid validity, and never more than "split_max_tiles");
+ *                  "coop_max_tiles": replaces the upper limit (-1)
+ *   "prep_fused": non-zero (default) = the per-launch preparation runs as 4 kernels (masks of both kinds in one, the
+ *                  schedule's histogram + sort in one); zero = the 7 separate kernels of round 2 (same results)
  *   "sched_min_tiles": launches of at least this many patches start their dearest patches first (default 2048)
  *   "heavy_split": with a work history and max_order == 2, this many of the dearest patches of a launch that is too big to
  *                  share every patch are cut in four parts swept by separate workgroups (0 = none; default -1: one patch

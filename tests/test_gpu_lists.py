@@ -2,8 +2,8 @@
 GPU: the region candidate lists (region_list_kernel / region_refine_kernel and the LISTED sweep kernels) change speed,
 never a bit.  Every case compares a launch that reads the lists with the same launch enumerating every prefix in every
 patch (option region_lists = 0) and, at sizes the oracle finishes in seconds, with the oracle itself.  Covered: all
-validity modes, orders 2..4, both launch shapes (patches shared by 4 waves / one wave per patch with the dearest ones cut
-in parts), region sizes, a list pool that is too small (the patches of the lists that did not fit are handed to the
+validity modes, orders 2..4, the three launch shapes (patches shared by 4 waves prefix by prefix / by 4, 8 or 16 waves candidate by candidate / one wave
+per patch with the dearest ones cut in parts), region sizes, a list pool that is too small (the patches of the lists that did not fit are handed to the
 enumerating kernel), non-finite cells (their patches never use lists), ragged grids, the value+grad sweep, TX grids.
 """
 
@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 
 F = np.float32
 MODES = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")]
-SHAPES = {"shared_patches": {}, "one_wave_per_patch": {"split_max_tiles": 0, "sched_min_tiles": 1}}
+SHAPES = {"shared_patches": {"coop_waves": 0, "split_sigmoid": 1}, "shared_candidates": {"coop_waves": 8, "coop_max_tiles": 1 << 20},
+          "one_wave_per_patch": {"split_max_tiles": 0, "sched_min_tiles": 1}}
+WAVES = {"shared_patches": (4, False), "shared_candidates": (8, True), "one_wave_per_patch": (1, False)}
 
 
 def _ctx(**opts):
@@ -44,6 +46,7 @@ def test_lists_change_no_bit(shape, approx, function):
             kw = dict(min_order=lo, max_order=hi, approx=approx, function=function)
             a, b = on.power_map(tx, X, Y, **kw), off.power_map(tx, X, Y, **kw)
             st = on.debug_region_stats()
+            assert on.sweep_shape() == WAVES[shape]
             assert st["leaf_regions"] == 6 and st["patches_enumerated"] == 0 and st["regions_not_listed"] == 0, st
             assert sum(st["leaf_entries"].values()) > 0
             assert off.debug_region_stats()["leaf_regions"] == 0
@@ -60,7 +63,8 @@ def test_lists_against_the_oracle_and_region_sizes(approx):
     kw = dict(min_order=0, max_order=2, approx=approx, function="hard_sigmoid")
     want = CO.power_map(walls, tx, X, Y, prune=True, **kw)
     for opts in ({}, {"region_size": 1, "region_size_top": 1}, {"region_size": 2, "region_size_top": 6}, {"region_size": 8, "region_size_top": 64},
-                 {"region_slices": 1}, {"region_slices": 64}, {"split_max_tiles": 0, "sched_min_tiles": 1, "heavy_split": 8}):
+                 {"region_slices": 1}, {"region_slices": 64}, {"split_max_tiles": 0, "sched_min_tiles": 1, "heavy_split": 8},
+                 {"coop_waves": 0}, {"coop_waves": 4}, {"coop_waves": 8}, {"coop_waves": 16}, {"coop_waves": 16, "region_size": 8, "region_size_top": 64}):
         with _ctx(**opts) as c:
             c.set_scene(walls)
             got = c.power_map(tx, X, Y, **kw)
