@@ -143,6 +143,13 @@ struct d2d_ctx {
     // wall-to-wall masks (pair_shadow_kernel): scene-only, rebuilt when the scene or one of these parameters changes
     DevBuf<unsigned long long> d_pair;
     bool pair_valid = false;
+    // last-segment masks of the leaf regions (hidden_region_kernel): scene, grid and validity mode only; built by the second
+    // launch in a row that would use them (a one-off map does not pay for them) and kept until one of those changes
+    DevBuf<unsigned long long> d_hidden;
+    bool hidden_valid = false;
+    double hidden_key[12] = {0}, hidden_seen[12] = {0};
+    bool use_hidden_masks = true;       // "hidden_masks" option (A/B and tests; same results)
+    long long hidden_builds = 0;        // diagnostic
     float pair_key[6] = {0, 0, 0, 0, 0, 0};  // patch, seg_tol, approx, act, alpha, dperp
     bool use_pair_masks = true;
     // scene (device)
@@ -608,7 +615,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_stats.release();
     c->d_shadow.release();
     c->d_sched.release();
-    c->d_rl_pool.release(); c->d_rl_box.release(); c->d_rl_next.release(); c->d_rl_idx.release(); c->d_rl_meta.release(); c->d_rl.release();
+    c->d_hidden.release(); c->d_rl_pool.release(); c->d_rl_box.release(); c->d_rl_next.release(); c->d_rl_idx.release(); c->d_rl_meta.release(); c->d_rl.release();
     c->d_sched_key.release();
     c->d_sched_override.release();
     c->d_cost.release();
@@ -693,6 +700,8 @@ int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float
     c->cost_tiles = 0;  // the patch-cost history describes another sweep
     for (int i = 0; i < d2d_ctx::N_SPARE; ++i) c->spare_sets[i].cost_tiles = 0;
     c->pair_valid = false;
+    c->hidden_valid = false;
+    c->hidden_seen[0] = -1.0;
     c->occl_patch = NAN;
     c->N = n_objects;
     c->xys.assign(xys, xys + 4 * (size_t)n_objects);
@@ -818,6 +827,13 @@ int d2d_debug_sweep_shape(d2d_ctx* c, int32_t* waves_per_patch, int32_t* candida
     if (!c || !waves_per_patch || !candidates) return fail(D2D_ERR_INVALID, "NULL argument");
     *waves_per_patch = c->last_shape_waves;
     *candidates = c->last_shape_coop;
+    return D2D_OK;
+}
+
+int d2d_debug_hidden_masks(d2d_ctx* c, int64_t* builds, int32_t* valid) {
+    if (!c || !builds || !valid) return fail(D2D_ERR_INVALID, "NULL argument");
+    *builds = c->hidden_builds;
+    *valid = c->hidden_valid ? 1 : 0;
     return D2D_OK;
 }
 
@@ -1126,6 +1142,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     a.pair_dperp = 0.0f;
     a.pair_prefix_ok = 0;
     bool prep_zeroed = false;
+    bool m_masks_ok = false;  // the masks' certified window and bins (set with the shadow masks below)
+    double m_in_lo = 0.0, m_in_hi = 0.0, m_dom_lo = 0.0, m_dom_w = 0.0;
     const bool txg_culled = txg && !c->txg_exhaustive && !(grad_mode && p->strict_nan);  // TX grid: culled kernels
     if ((!txg || txg_culled) && c->N >= 2 && p->max_order >= 1) {
         // [N] masks, then the {histogram, cursors} of the patch schedule's counting sort, then what the region lists need
@@ -1157,6 +1175,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev_fork, ps));  // (the sort of a big launch needs its counters zeroed: it may start here)
         }
+        m_masks_ok = masks_ok; m_in_lo = in_lo; m_in_hi = in_hi; m_dom_lo = dom_lo; m_dom_w = dom_w;
         if (masks_ok) {
             if (!c->prep_fused) {
                 const int pairs = c->N * c->N;
@@ -1270,6 +1289,36 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             fill(top, rp.top);
             rl.leaf.box = c->d_rl_box.p;
             top.box = c->d_rl_box.p + rp.leaf.regions;
+            // last-segment masks: which bins of which wall are hidden from a whole leaf region (forward RX-grid sweeps)
+            if (!txg && !grad_mode && m_masks_ok && a.shadow && c->use_hidden_masks && std::isfinite(c->scene_absmax) && std::isfinite(c->grid_absmax) &&
+                (size_t)rp.leaf.regions * (size_t)c->N <= ((size_t)1 << 28)) {
+                const float hdperp = 4096.0f * 1.1920929e-07f * std::fmax(c->scene_absmax, c->grid_absmax) * (float)(D2D_MAX_ORDER + 1);
+                const double key[12] = {(double)c->grid_version, (double)rp.leaf.R, (double)c->m, (double)c->n, (double)p->patch, (double)p->seg_tol,
+                                        (double)(p->approx * 4 + p->act), (double)p->alpha, (double)hdperp, m_dom_lo, m_dom_w, (double)c->N};
+                if (hdperp > 0.0f && !(c->hidden_valid && std::memcmp(key, c->hidden_key, sizeof key) == 0)) {
+                    if (std::memcmp(key, c->hidden_seen, sizeof key) == 0) {  // the second launch in a row with this key: build
+                        const size_t nh = (size_t)rp.leaf.regions * (size_t)c->N;
+                        if ((rc = c->d_hidden.ensure(nh))) return rc;
+                        // (a sweep that reads the old masks may still be in flight on the main stream)
+                        for (int i = 0; piped && i < d2d_ctx::N_SPARE; ++i)
+                            if (c->spare_sets[i].swept_pending) HIP_TRY(hipStreamWaitEvent(ps, c->spare_sets[i].ev_swept, 0));
+                        hipLaunchKernelGGL(d2d::hidden_region_kernel, dim3((unsigned)nh), dim3(64), 0, ps, c->d_occl.p, c->d_refl.p, c->d_kind.p, c->N,
+                                           c->d_rl_box.p, (float)(m_in_lo + 1e-4), (float)(m_in_hi - 1e-4), hdperp, (float)m_dom_lo, (float)m_dom_w,
+                                           c->d_hidden.p);
+                        HIP_TRY(hipGetLastError());
+                        std::memcpy(c->hidden_key, key, sizeof key);
+                        c->hidden_valid = true;
+                        c->hidden_builds += 1;
+                    } else {
+                        std::memcpy(c->hidden_seen, key, sizeof key);
+                        c->hidden_valid = false;
+                    }
+                }
+                if (c->hidden_valid && std::memcmp(key, c->hidden_key, sizeof key) == 0) {
+                    rl.leaf.hidden = c->d_hidden.p;
+                    rl.leaf.hidden_dperp = hdperp;
+                }
+            }
             int* at = c->d_rl_idx.p;
             int chunk_at = 0;
             for (int k = rp.k_lo; k <= p->max_order; ++k) {
@@ -1689,6 +1738,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return fail(D2D_ERR_INVALID, "d2d_set_option: NULL argument");
     if (!strcmp(name, "split_max_tiles")) c->split_max_tiles = value;
     else if (!strcmp(name, "coop_max_tiles")) c->coop_max_tiles = value;
+    else if (!strcmp(name, "hidden_masks")) c->use_hidden_masks = value != 0;
     else if (!strcmp(name, "split_sigmoid")) c->split_sigmoid = value != 0;
     else if (!strcmp(name, "coop_waves")) {
         if (value != -1 && value != 0 && value != 4 && value != 8 && value != 16) return fail(D2D_ERR_INVALID, "coop_waves must be -1, 0, 4, 8 or 16, got %lld", (long long)value);

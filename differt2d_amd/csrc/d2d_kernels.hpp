@@ -91,6 +91,11 @@ struct RegionLevel {
     int R;                          // a region is R x R patches
     int regions_x, regions_y;
     const float4* box;              // [regions] bounding boxes of the regions' cells (region_box_kernel)
+    // [regions][N] last-segment masks (hidden_region_kernel; leaf level only, null: none): bit b of word [r][w] = the segment
+    // from any point within hidden_dperp of bin b of wall w to ANY point of region r's box is certainly reported as
+    // intersecting some object by the exact path.  Scene, grid and validity mode only: no end point involved.
+    const unsigned long long* hidden;
+    float hidden_dperp;
 };
 struct RegionLists {
     RegionLevel leaf;  // the level the sweep kernels read (one list per region and order)
@@ -1156,7 +1161,8 @@ __device__ __forceinline__ bool pole_possible(const float (&qx)[4], const float 
 template <int K, bool WIDE = false>
 __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float (&by)[4], const WallC (&w)[K],
                                                const float (&Ix)[K], const float (&Iy)[K], const SweepArgs& a,
-                                               unsigned long long shadow0, float on_lo, float on_hi) {
+                                               unsigned long long shadow0, float on_lo, float on_hi,
+                                               unsigned long long hiddenK = 0ull, float hidden_dperp = 0.0f) {
     const float eps = 1.1920929e-07f;
     const float shadow_dperp = a.shadow_dperp, shadow_lo = a.shadow_lo, shadow_inv = a.shadow_inv;
     float qx[4], qy[4];
@@ -1175,6 +1181,20 @@ __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float
         if (!ok) return false;
         if (WIDE) M *= 4.0f;
         if (smax + M < on_lo || smin - M > on_hi) return true;
+        if (!WIDE && lvl == K - 1 && hiddenK != 0ull) {
+            // Last segment (last wall -> cell): if every point the last interaction can occupy is hidden from the whole
+            // region the box lies in, the segment is occluded in every lane: valid == 0 (hidden_region_kernel; the bins are
+            // the shadow masks').
+            float sa = fmaxf(smin - M, on_lo) - 1e-4f, sb = fminf(smax + M, on_hi) + 1e-4f;
+            float fa_ = (sa - shadow_lo) * shadow_inv, fb_ = (sb - shadow_lo) * shadow_inv;
+            if (fa_ >= 0.0f && fb_ < 64.0f && 256.0f * eps * E <= hidden_dperp) {
+                int ka = (int)fa_, kb = (int)fb_;
+                ka = ka < 0 ? 0 : ka;
+                kb = kb > 63 ? 63 : kb;
+                unsigned long long need = (kb >= 63 ? ~0ull : ((1ull << (kb + 1)) - 1ull)) & ~((1ull << ka) - 1ull);
+                if ((hiddenK & need) == need) return true;
+            }
+        }
         if (K >= 2 && a.pair) {
             // Segment between this wall's interaction point and the next one's (pair_shadow_kernel): if every pair of
             // bins the two points can occupy is certainly occluded by some third object, valid == 0 in every lane.
@@ -1298,7 +1318,8 @@ template <int K, int MODE, bool STATS, bool GRAD = false, bool LIST = false, boo
 __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                    const float (&by)[4], float rxx, float rxy, bool lane_bad, float& acc,
                                                    WaveStats& st, GradCtx* g = nullptr, int p_lo = 0,
-                                                   int p_hi = 0x7fffffff, ListSink* sink = nullptr, EmitSink* emit = nullptr) {
+                                                   int p_hi = 0x7fffffff, ListSink* sink = nullptr, EmitSink* emit = nullptr,
+                                                   const unsigned long long* hidden_row = nullptr, float hidden_dperp = 0.0f) {
     static_assert(!EMIT || K >= 2, "lists exist for orders >= 2");
     const int lane = threadIdx.x & 63;
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
@@ -1525,7 +1546,11 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 unsigned long long sh0 = 0ull;
                 if (a.shadow) sh0 = cmem(a.shadow)[(K == 1) ? wl : cand[0]];
                 if (GRAD && prefix_dead) alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
-                else if (alive && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi)) alive = false;
+                else if (alive) {
+                    // (order 1: the region's last-segment mask of the lane's wall, hidden_region_kernel)
+                    const unsigned long long hk = (K == 1 && !GRAD && hidden_row && a.shadow) ? hidden_row[wl] : 0ull;
+                    if (cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi, hk, hidden_dperp)) alive = false;
+                }
             }
             unsigned long long mask = __ballot(alive);
             if (STATS) st.c[9] += K;
@@ -1609,6 +1634,9 @@ __device__ __forceinline__ void first_wall_range(const SweepArgs& a, int part, i
     hi = (part == parts - 1) ? Nc : boundary((int)(((long)A * (part + 1)) / parts));
 }
 
+#ifndef D2D_HIDDEN_PATCH
+#define D2D_HIDDEN_PATCH 1  // A/B: 0 = the last-segment masks are consulted for the regions' lists (and order 1) only
+#endif
 // One batch of a candidate list, lanes = candidates: decodes the lane's entry, builds its image chain and runs the full
 // tile-culling test against the box (bx, by).  Returns the ballot of the entries that cannot be dropped.
 // TXG (TX grids): the chain is the fixed end point's through the walls in REVERSE order (sweep_order_culled_txg), with the
@@ -1616,7 +1644,7 @@ __device__ __forceinline__ void first_wall_range(const SweepArgs& a, int part, i
 template <int K, bool GRAD, bool TXG = false>
 __device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, const float4* tab, const float (&bx)[4], const float (&by)[4],
                                                          unsigned long long code, bool have, float (&Ix)[K], float (&Iy)[K], float on_lo,
-                                                         float on_hi) {
+                                                         float on_hi, const unsigned long long* hidden_row = nullptr, float hidden_dperp = 0.0f) {
     bool alive = have;
     WallC w[K];
     float ix = a.txx, iy = a.txy;
@@ -1650,7 +1678,8 @@ __device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, con
         alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
     } else if (alive) {
         const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[w[0].idx] : 0ull;
-        if (cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, on_lo, on_hi)) alive = false;
+        const unsigned long long hk = (!GRAD && hidden_row && a.shadow) ? hidden_row[w[K - 1].idx] : 0ull;
+        if (cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, on_lo, on_hi, hk, hidden_dperp)) alive = false;
     }
     return __ballot(alive);
 }
@@ -1670,6 +1699,9 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
     const int chunk0 = rlc->leaf.chunk0[K] + (int)region;
     const auto* pool = cmem(rlc->lp.pool);
     const auto* next = cmem(rlc->lp.next);
+    // the region's last-segment masks once more, now with the bins this PATCH can reach (hidden_region_kernel)
+    const unsigned long long* hidden_row = (D2D_HIDDEN_PATCH && !GRAD && rlc->leaf.hidden) ? rlc->leaf.hidden + (size_t)region * a.N : nullptr;
+    const float hidden_dperp = hidden_row ? rlc->leaf.hidden_dperp : 0.0f;
     int r_lo = 0, r_hi = 0x7fffffff;
     if (parts > 1) {
         int T = 0, chunk = chunk0;
@@ -1678,7 +1710,7 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
             const unsigned long long code = pool[(size_t)chunk * RL_CHUNK + (off & (RL_CHUNK - 1)) + (have ? lane : 0)];
             if ((off & (RL_CHUNK - 1)) == RL_CHUNK - 64 && off + 64 < n) chunk = next[chunk];
             float Ix[K], Iy[K];
-            T += __builtin_popcountll(cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi));
+            T += __builtin_popcountll(cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi, hidden_row, hidden_dperp));
             D2D_WORK(5 * K);
         }
         if (K == 2 && a.min_order <= 1) {
@@ -1714,7 +1746,7 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
                 on_hi = fminf(on_hi, 1.0f - wdn);
             }
         }
-        unsigned long long mask = cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy, on_lo, on_hi);
+        unsigned long long mask = cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy, on_lo, on_hi, hidden_row, hidden_dperp);
         if (STATS) st.c[9] += K;
         D2D_WORK(5 * K);
         int budget = 64;
@@ -1926,8 +1958,11 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
                 sweep_order<0, MODE, false, false>(a, a.txx, a.txy, rxx, rxy, lane_bad, t, st, nullptr);
                 if (!(t == 0.0f)) sink.push(t);
             }
-            if (a.min_order <= 1 && a.max_order >= 1)
-                sweep_order_culled<1, MODE, false, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, 0, 0x7fffffff, &sink);
+            if (a.min_order <= 1 && a.max_order >= 1) {
+                const unsigned long long* hid = LISTED ? cmem(a.rl)->leaf.hidden : nullptr;
+                sweep_order_culled<1, MODE, false, false, true>(a, tab, bx, by, rxx, rxy, lane_bad, dummy, st, nullptr, 0, 0x7fffffff, &sink, nullptr,
+                                                                hid ? hid + (size_t)region * a.N : nullptr, hid ? cmem(a.rl)->leaf.hidden_dperp : 0.0f);
+            }
         }
 #ifdef D2D_AB_TIMELINE
         t_lineC = (unsigned)(__builtin_amdgcn_s_memrealtime() & 0xffffull);
@@ -1988,7 +2023,11 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, GRADK>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, &g);
     unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[11] += tq1 - tq0;      // order 0
-    if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g);
+    if (a.min_order <= 1 && a.max_order >= 1) {
+        const unsigned long long* hid = (LISTED && !GRADK) ? cmem(a.rl)->leaf.hidden : nullptr;
+        sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, 0, 0x7fffffff, nullptr, nullptr,
+                                                  hid ? hid + (size_t)region * a.N : nullptr, hid ? cmem(a.rl)->leaf.hidden_dperp : 0.0f);
+    }
     unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[12] += tq2 - tq1;      // order 1
 #ifdef D2D_AB_TIMELINE
@@ -2192,7 +2231,11 @@ __device__ __forceinline__ void split_patch(const SweepArgs& a, const float4* ta
     const bool writer = wv == 0;
     if (writer) {
         if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, false>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, nullptr);
-        if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled<1, MODE, STATS, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, nullptr);
+        if (a.min_order <= 1 && a.max_order >= 1) {
+            const unsigned long long* hid = LISTED ? cmem(a.rl)->leaf.hidden : nullptr;
+            sweep_order_culled<1, MODE, STATS, false>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, nullptr, 0, 0x7fffffff, nullptr, nullptr,
+                                                      hid ? hid + (size_t)region * a.N : nullptr, hid ? cmem(a.rl)->leaf.hidden_dperp : 0.0f);
+        }
     }
     if (a.min_order <= 2 && a.max_order >= 2) split_order<2, MODE, STATS, W, LISTED>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st, region);
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) split_order<3, MODE, STATS, W, LISTED>(a, tab, lists, meta, bx, by, rxx, rxy, lane_bad, acc, st, region);
@@ -2306,12 +2349,16 @@ __device__ __forceinline__ void coop_order(const SweepArgs& a, const float4* tab
                         w[0] = make_wallc(r0, r1, fc, wl);
                         image_of(r0, a.txx, a.txy, Ix[0], Iy[0]);
                         const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[wl] : 0ull;
-                        m = __ballot(lp < n && !cull_candidate<1>(bx, by, w, Ix, Iy, a, sh0, on_lo, on_hi));
+                        const unsigned long long* hid = rlc->leaf.hidden;
+                        const unsigned long long hk = (hid && a.shadow) ? hid[(size_t)region * a.N + wl] : 0ull;
+                        m = __ballot(lp < n && !cull_candidate<1>(bx, by, w, Ix, Iy, a, sh0, on_lo, on_hi, hk, hid ? rlc->leaf.hidden_dperp : 0.0f));
                     } else {
                         const bool have = off + lane < n;
                         const unsigned long long code = pool[(size_t)ch * RL_CHUNK + (off & (RL_CHUNK - 1)) + (have ? lane : 0)];
                         float Ix[K], Iy[K];
-                        m = cull_batch<K, false>(a, tab, bx, by, code, have, Ix, Iy, on_lo, on_hi);
+                        const unsigned long long* hid = D2D_HIDDEN_PATCH ? rlc->leaf.hidden : nullptr;
+                        m = cull_batch<K, false>(a, tab, bx, by, code, have, Ix, Iy, on_lo, on_hi, hid ? hid + (size_t)region * a.N : nullptr,
+                                                 hid ? rlc->leaf.hidden_dperp : 0.0f);
                     }
                     if (lane == 0) {
                         bmask[i] = m;
@@ -2511,6 +2558,7 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
     const int rx = (int)(region % lv.regions_x), ry = (int)(region / lv.regions_x);
     float bx[4], by[4];
     bool ok = region_box(a, lv.box, region, bx, by);
+    const unsigned long long* hidden_row = (!GRAD && !TXG && lv.hidden) ? lv.hidden + (size_t)region * a.N : nullptr;
     const int up = parent.R / lv.R;
     const long pslot0 = ((long)(ry / up) * parent.regions_x + (rx / up)) * parent.S;
     const int* pcnt = parent.cnt[K] + pslot0;
@@ -2530,7 +2578,7 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
                 const bool have = off + lane < total;
                 const unsigned long long code = buf[have ? off + lane : off];
                 float Ix[K], Iy[K];
-                const unsigned long long mask = cull_batch<K, GRAD, TXG>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi);
+                const unsigned long long mask = cull_batch<K, GRAD, TXG>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi, hidden_row, lv.hidden_dperp);
                 emit_batch(em, code, have && ((mask >> lane) & 1ull), mask);
             }
             total = 0;
@@ -3228,6 +3276,69 @@ __global__ void __launch_bounds__(256) pair_shadow_kernel(const float4* __restri
     }
     const unsigned long long bits = __ballot(ok);
     if (bits && lane == 0) atomicOr(&pair[(size_t)we * N + wl], bits);
+}
+
+// Last-segment masks (scene, grid and validity mode only; built once and kept): one wave per (leaf region r, wall w),
+// lane = bin b of w.  Bit b is set when, for some blocker j, the segment p -> q is CERTAINLY reported as intersecting j by
+// the exact path for every p within dperp of w's bin b (P3, the last interaction point) and every q of the region's
+// bounding box (P4, the cell): the same bilinear-fractional argument and margins as pair_shadow_kernel, the second quad
+// being the box (its corners are exact inputs; the margins derived for a rounded point only widen the bound).
+__global__ void __launch_bounds__(64) hidden_region_kernel(const float4* __restrict__ occl, const float4* __restrict__ refl,
+                                                           const unsigned char* __restrict__ kind, int N, const float4* __restrict__ box,
+                                                           float win_lo, float win_hi, float dperp, float dom_lo, float dom_w,
+                                                           unsigned long long* __restrict__ hidden) {
+    const int b = threadIdx.x & 63;
+    const long rw = blockIdx.x;
+    const long r = rw / N;
+    const int w = (int)(rw % N);
+    const float4 bb = box[r];  // {x0, x1, y0, y1}; x0 = NaN: a cell is not comfortably finite
+    const float4 a0 = refl[2 * w], a1 = refl[2 * w + 1];
+    unsigned long long bits = 0ull;
+    const bool usable = (bb.x <= bb.y) && (bb.z <= bb.w) && (a1.x * a1.x + a1.y * a1.y != 0.0f);
+    if (usable) {
+        const float eps = 1.1920929e-07f;
+        const float pad = dperp * (a1.w > 0.0f ? 1.0f / a1.w : 0.0f);
+        const float tlen = fabsf(a1.x) + fabsf(a1.y);
+        float pxv[4], pyv[4];
+#pragma unroll
+        for (int vp = 0; vp < 4; ++vp) {
+            const float sp = dom_lo + ((vp & 1) ? (float)(b + 1) * dom_w + pad : (float)b * dom_w - pad);
+            const float op = (vp & 2) ? dperp : -dperp;
+            pxv[vp] = a0.x + sp * a1.x + op * a0.z;
+            pyv[vp] = a0.y + sp * a1.y + op * a0.w;
+        }
+        for (int j = 0; j < N; ++j) {
+            if (j == w || kind[j] == D2D_VERTEX) continue;  // the segment ignores the wall it starts on; vertices never occlude
+            const float4 o = occl[j];  // P1, A
+            bool ok = true;
+            int sgn = 0;
+            for (int vp = 0; vp < 4 && ok; ++vp) {
+                const float px = pxv[vp], py = pyv[vp];  // P3 = p
+                const float Cx = o.x - px, Cy = o.y - py;
+                const float fb = o.z * Cy - o.w * Cx;
+                const float errB = 8.0f * eps * (fabsf(o.z * Cy) + fabsf(o.w * Cx)) + 4.0f * eps * tlen * (fabsf(o.z) + fabsf(o.w));
+                for (int vq = 0; vq < 4; ++vq) {
+                    const float qx = (vq & 1) ? bb.y : bb.x, qy = (vq & 2) ? bb.w : bb.z;  // P4 = q
+                    const float Bx = px - qx, By = py - qy;
+                    const float fa = By * Cx - Bx * Cy;
+                    const float fd = o.w * Bx - o.z * By;
+                    const float errA = 8.0f * eps * (fabsf(By * Cx) + fabsf(Bx * Cy)) + 4.0f * eps * tlen * (fabsf(Cx) + fabsf(Cy) + fabsf(Bx) + fabsf(By));
+                    const float errD = 8.0f * eps * (fabsf(o.w * Bx) + fabsf(o.z * By)) + 4.0f * eps * tlen * (fabsf(o.z) + fabsf(o.w));
+                    const float ad = fabsf(fd);
+                    if (!(ad > 8.0f * errD)) { ok = false; break; }
+                    const int sv = fd > 0.0f ? 1 : -1;
+                    if (sgn == 0) sgn = sv;
+                    if (sv != sgn) { ok = false; break; }
+                    const float ta = fa / fd, tb = fb / fd;
+                    const float ea = (errA + 2.0f * errD) / (ad - errD) + 4.0f * eps, eb = (errB + 2.0f * errD) / (ad - errD) + 4.0f * eps;
+                    if (!(ta - ea >= win_lo && ta + ea <= win_hi && tb - eb >= win_lo && tb + eb <= win_hi)) { ok = false; break; }
+                }
+            }
+            bits |= __ballot(ok);
+            if (bits == ~0ull) break;
+        }
+    }
+    if (b == 0) hidden[rw] = bits;
 }
 
 #endif  // D2D_AUX_KERNELS

@@ -194,6 +194,12 @@ class Context:
         L.check(self._lib.d2d_debug_sweep_shape(self._ctx, C.byref(w), C.byref(k)))
         return int(w.value), bool(k.value)
 
+    def hidden_masks(self) -> tuple:
+        """Diagnostic: (times the last-segment masks were built, valid now?) (include/d2d.h)."""
+        n, v = C.c_int64(0), C.c_int32(0)
+        L.check(self._lib.d2d_debug_hidden_masks(self._ctx, C.byref(n), C.byref(v)))
+        return int(n.value), bool(v.value)
+
     def launch(self, params: L.Params, tx):
         tx = np.ascontiguousarray(tx, dtype=np.float32).reshape(2)
         L.check(self._lib.d2d_power_map_launch(self._ctx, C.byref(params), tx))

@@ -159,6 +159,9 @@ int d2d_debug_grid_reuses(d2d_ctx* ctx, int64_t* count);
  * patches cut in parts), 4 (patches shared by 4 waves prefix by prefix) or, with candidates = 1, the 4 / 8 / 16 waves of
  * the kernel that shares a patch candidate by candidate (options coop_waves, coop_max_tiles); 0 before any sweep. */
 int d2d_debug_sweep_shape(d2d_ctx* ctx, int32_t* waves_per_patch, int32_t* candidates);
+/* Diagnostic: how often the last-segment masks of the leaf regions ("hidden_masks" option) were built, and whether the
+ * context holds valid ones now. */
+int d2d_debug_hidden_masks(d2d_ctx* ctx, int64_t* builds, int32_t* valid);
 
 /* Initial guesses of the optimiser-based solvers for the NEXT sweeps: theta0[n_candidates * many][D2D_MAX_ORDER]
  * (n_rows = n_candidates * max(1, params->many)), candidates in enumeration order, the `many` starts of one candidate
@@ -222,6 +225,11 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *                  validity mode -- 16 waves up to 256 patches and 8 up to 640 (hard) / 2304 (hard_sigmoid), 16 / 8 / 4 up
  *                  to 640 / 1600 / 4096 patches with sigmoid validity, and never more than "split_max_tiles");
  *                  "coop_max_tiles": replaces the upper limit (-1)
+ *   "hidden_masks": non-zero (default) = forward RX-grid sweeps with region lists keep, per leaf region and wall, a 64-bin mask
+ *                  of where the wall is certainly hidden from the WHOLE region (scene, grid and validity mode only: built
+ *                  by the second launch in a row that would use it, kept until the scene, the grid or the mode changes);
+ *                  candidates whose last interaction point can only lie in hidden bins leave the region's list, and order-1
+ *                  candidates the patch's culling (same results)
  *   "prep_fused": non-zero (default) = the per-launch preparation runs as 4 kernels (masks of both kinds in one, the
  *                  schedule's histogram + sort in one); zero = the 7 separate kernels of round 2 (same results)
  *   "sched_min_tiles": launches of at least this many patches start their dearest patches first (default 2048)
