@@ -190,13 +190,13 @@ struct HeavyPlan {
     long long list_floats = 0; // heavy_list elements
     long long cnt_ints = 0;    // heavy_cnt elements
 };
-// The dearest `heavy_split` patches of a launch of `tiles` patches (at most a sixteenth of them) are cut in `parts`; a
+// The dearest `heavy_split` patches of a launch of `tiles` patches (at most a quarter of them) are cut in `parts`; a
 // part's list holds as many entries as it has candidates at most (orders 0..2 over Nc allowed walls), and the lists of
 // all parts together must stay below 4 GiB, else nothing is cut.
 inline HeavyPlan heavy_plan(long long tiles, long long Nc, long long heavy_split, long long parts) {
     HeavyPlan hp;
     if (tiles <= 0 || Nc < 2 || heavy_split <= 0 || parts <= 0) return hp;
-    const long long H = heavy_split < tiles / 16 ? heavy_split : tiles / 16;
+    const long long H = heavy_split < tiles / 4 ? heavy_split : tiles / 4;
     if (H <= 0) return hp;
     if (Nc > (1ll << 30)) return hp;
     // what one part can push: its range of first walls (enumerating build), or -- region lists, parts by rank, part 0 a

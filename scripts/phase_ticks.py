@@ -10,6 +10,8 @@ tx, walls, X, Y = workload(grid=g)
 with Context(0) as ctx:
     ctx.set_scene(walls); ctx.set_grid(X, Y)
     for approx in (False, True):
+        for _ in range(3):  # (work history, last-segment masks)
+            ctx.launch(make_params(max_order=2, approx=approx), tx)
         st = ctx.launch_stats(make_params(max_order=2, approx=approx), tx).astype(np.float64)
         waves = (g // 8) ** 2
         names = ["prologue", "order0", "order1", "order2(total)", "order2 exact part"]

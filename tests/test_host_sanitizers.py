@@ -187,7 +187,7 @@ def test_libd2d_host_logic_under_asan_and_ubsan(asan, tmp_path):
             if H == 0:
                 assert (cap, lf, ci) == (0, 0, 0)
                 continue
-            assert H == min(hs, tiles // 16) and cap >= (Nc // parts + 1) * (Nc - 1) + Nc + 1   # covers a part's candidates
+            assert H == min(hs, tiles // 4) and cap >= (Nc // parts + 1) * (Nc - 1) + Nc + 1   # covers a part's candidates
             assert lf == H * parts * cap * 64 and ci == H * parts * 65 and lf * 4 <= 4 << 30
         L.san_heavy_plan(16384, 50, 64, 4, out)
         assert out[0] == 64 and out[1] == -(-50 * 49 // 3) + 52       # the benchmark's own launch (parts by rank: a third each at most)
