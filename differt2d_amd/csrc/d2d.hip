@@ -1582,9 +1582,11 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         if (hs < 0) {
             int cus = 256;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-            // (hard_sigmoid: a soft validity dies later -- three times the exact work per patch -- and the launch stays bound by its
-            // dear patches much further down the ranking: 1536 cut patches, 0.177 -> 0.134 ms at cfg2; 1024: 0.148, 2048: 0.138)
-            hs = (tiles < 4ll * cus * 4 * 6) ? std::max<long long>(64, mode == d2d::MODE_HSIG ? tiles * 3 / 32 : tiles / 93) : 64;
+            // 3 patches in 32 (1536 at cfg2; round 2 cut 1 in 93, the best figure before the last-segment masks thinned the cheap
+            // patches out): the launch stays bound by its dear patches far down the ranking -- hard_sigmoid 0.177 -> 0.134 ms
+            // (1024 cut patches: 0.148, 2048: 0.138); hard, same transmitter every launch: 0.085 either way, a different one
+            // every launch (a work history three positions old ranks the patches less well): 0.158 -> 0.104 ms per step
+            hs = (tiles < 4ll * cus * 4 * 6) ? std::max<long long>(64, tiles * 3 / 32) : 64;
             // sigmoid: a part adds to a list, not to the running sum, and cannot drop the contributions that sum would
             // absorb (sig_zc_of) -- the dearest patches would lose their best shortcut (cfg2: 11.2 ms cut, 10.9 uncut)
             if (mode == d2d::MODE_SIG && a.sig_mono) hs = 0;

