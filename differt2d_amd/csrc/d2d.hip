@@ -206,7 +206,7 @@ struct d2d_ctx {
     bool vjp_reduced = false;  // d_vjp has been all-reduced over ranks: it is a global sum, nothing local may be added to it
     bool have_grad = false;  // d_grad holds the per-cell gradient map of a sweep of the CURRENT grid (2 m n values)
     bool want_wave_cycles = false;
-    long long split_max_tiles = 8192;   // launches up to this many patches share every patch between 4 waves
+    long long split_max_tiles = -1;     // launches up to this many patches share every patch between 4 waves (-1: by the validity mode)
     long long coop_max_tiles = -1;      // ... and up to this many candidate by candidate (power_fwd_coop_kernel); -1: by the validity mode
     bool split_sigmoid = false;         // sigmoid validity: share patches prefix by prefix like the other modes (slower: A/B and tests)
     long long coop_waves = -1;          // its waves per patch: -1 by the launch's size and mode (16 / 8 / none), 0 never, else 4, 8 or 16
@@ -1555,7 +1555,11 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     const size_t split_base = sl.base, split_lds = sl.total;  // ... + one culling queue per wave
     // (sigmoid validity: a wave that adds to a list instead of the running sum loses the sum's absorption shortcut, sig_zc_of --
     // measured at 64^2 .. 640^2 cells of cfg2's scene the shared patches take 7.5 .. 11.6 ms, one wave per patch 5.4 .. 7.8)
-    const bool split = p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= d2d_host::LDS_LIMIT && tiles <= c->split_max_tiles &&
+    // (measured with the last-segment masks in place, sweep kernel, ms -- 4 waves per patch / one: hard 512^2 0.068 / 0.072,
+    // 640^2 0.080 / 0.065; hard_sigmoid 384^2 0.141 / 0.123 (8 waves candidate by candidate: 0.104), 512^2 0.136 / 0.121,
+    // 640^2 0.117 / 0.097: hard launches share their patches up to 5120 of them, hard_sigmoid ones only candidate by candidate)
+    const long long split_lim = c->split_max_tiles >= 0 ? c->split_max_tiles : (mode == d2d::MODE_HARD ? 5120 : 0);
+    const bool split = p->max_order >= 2 && c->cw.size() >= 2 && split_lds <= d2d_host::LDS_LIMIT && tiles <= split_lim &&
                        (mode != d2d::MODE_SIG || c->split_sigmoid);
     // the smallest launches (the grids of the reference's own examples): W waves per patch, candidate by candidate
     // (power_fwd_coop_kernel).  Measured on cfg2's scene, ms per sweep kernel, best other kernel first:
@@ -1570,7 +1574,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         else if (sig) coop_w = tiles <= 640 ? 16 : (tiles <= 1600 ? 8 : 4);
         else coop_w = tiles <= 256 ? 16 : 8;
         // ("split_max_tiles" = 0 asks for one wave per patch whatever the size: honoured unless the waves are forced)
-        if (d2d_host::coop_lds_bytes(c->N, coop_w, d2d::COOP_C) > d2d_host::LDS_LIMIT || tiles > lim || (c->coop_waves < 0 && tiles > c->split_max_tiles)) coop_w = 0;
+        if (d2d_host::coop_lds_bytes(c->N, coop_w, d2d::COOP_C) > d2d_host::LDS_LIMIT || tiles > lim || (c->coop_waves < 0 && c->split_max_tiles >= 0 && tiles > c->split_max_tiles)) coop_w = 0;
     }
     // the dearest patches of a bigger launch are cut in four (see power_fwd_kernel); they are only known with a work history
     dim3 grid_fwd = grid_patches;

@@ -218,8 +218,9 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
                               int64_t* n_waves);
 
 /* Launch-shape tuning of a context; never changes a result bit (tests sweep these to cover every kernel variant).
- *   "split_max_tiles": launches of at most this many 8 x 8 patches share every patch between 4 waves (default 8192; 0 = never;
- *                  never with sigmoid validity unless "split_sigmoid" is non-zero: one wave per patch is faster there)
+ *   "split_max_tiles": launches of at most this many 8 x 8 patches share every patch between 4 waves (0 = never; default -1:
+ *                  5120 with hard validity, never with hard_sigmoid -- those share candidate by candidate, "coop_waves", or
+ *                  run one wave per patch; never with sigmoid validity unless "split_sigmoid" is non-zero)
  *   "coop_waves": the smallest launches share every patch between this many waves CANDIDATE BY CANDIDATE, wave 0 adding the
  *                  contributions in the reference's order (4, 8 or 16; 0 = never; default -1: by the launch's size and
  *                  validity mode -- 16 waves up to 256 patches and 8 up to 640 (hard) / 2304 (hard_sigmoid), 16 / 8 / 4 up

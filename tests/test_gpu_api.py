@@ -476,7 +476,7 @@ def test_repeated_api_calls_reuse_the_resident_grid_and_the_work_history():
         assert np.array_equal(c, a) and not np.array_equal(b, a)
     finally:
         ctx.set_option("sched_min_tiles", 2048)
-        ctx.set_option("split_max_tiles", 8192)
+        ctx.set_option("split_max_tiles", -1)
 
 
 def test_scene_vjp_accumulation_refuses_mixed_sweep_kinds():

@@ -136,11 +136,11 @@ def test_non_finite_cells_go_to_the_queue():
 
 
 def test_automatic_choice_by_launch_size():
-    """Measured thresholds (d2d.hip): patches -> kernel, per validity mode; sigmoid validity never uses
-    the 4-waves-per-patch kernel (one wave per patch beyond the candidate-sharing kernel's range)."""
+    """Measured thresholds (d2d.hip): patches -> kernel, per validity mode; only hard validity uses
+    the 4-waves-per-patch kernel (the others: one wave per patch beyond the candidate-sharing kernel's range)."""
     tx, walls = random_scene(12, seed=2)
     want = {("hard", 64): (16, True), ("hard", 128): (16, True), ("hard", 136): (8, True), ("hard", 200): (8, True), ("hard", 208): (4, False),
-            ("hsig", 128): (16, True), ("hsig", 300): (8, True), ("hsig", 384): (8, True), ("hsig", 392): (4, False),
+            ("hsig", 128): (16, True), ("hsig", 300): (8, True), ("hsig", 384): (8, True), ("hsig", 392): (1, False),
             ("sig", 200): (16, True), ("sig", 208): (8, True), ("sig", 320): (8, True), ("sig", 328): (4, True), ("sig", 512): (4, True),
             ("sig", 520): (1, False)}
     kws = {"hard": dict(approx=False), "hsig": dict(approx=True, function="hard_sigmoid"), "sig": dict(approx=True, function="sigmoid")}
@@ -163,7 +163,7 @@ def test_sigmoid_floor_is_exact():
         for alpha in (100.0, 1000.0, 10.0):
             kw = dict(min_order=0, max_order=3, approx=True, function="sigmoid", alpha=alpha, fun=fun)
             maps = []
-            for opts in ({"coop_waves": 16}, {"coop_waves": 4}, {"coop_waves": 0}, {"coop_waves": 0, "split_sigmoid": 1}, {"region_lists": 0}):
+            for opts in ({"coop_waves": 16}, {"coop_waves": 4}, {"coop_waves": 0}, {"coop_waves": 0, "split_sigmoid": 1, "split_max_tiles": 8192}, {"region_lists": 0}):
                 with _ctx(**opts) as c:
                     c.set_scene(walls)
                     maps.append(c.power_map(tx, X, Y, **kw))

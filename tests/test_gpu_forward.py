@@ -18,8 +18,7 @@ F = np.float32
 MODES = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")]
 
 
-# Launch shapes: these grids are small, so by default every patch is shared between 4 waves (power_fwd_split_kernel) in
-# identity order; the second variant forces what big grids get: one wave per patch, dearest patches first.
+# Launch shapes: every patch shared between 4 waves (power_fwd_split_kernel) in identity order; the second variant forces what big grids get: one wave per patch, dearest patches first.
 @pytest.fixture(scope="module", params=["shared_patches", "one_wave_per_patch_scheduled"])
 def ctx(request):
     from differt2d_amd.engine import Context
@@ -28,6 +27,10 @@ def ctx(request):
         if request.param == "one_wave_per_patch_scheduled":
             c.set_option("split_max_tiles", 0)
             c.set_option("sched_min_tiles", 1)
+        else:  # (the default for grids this small is the candidate-sharing kernel: tests/test_gpu_coop.py)
+            c.set_option("coop_waves", 0)
+            c.set_option("split_max_tiles", 8192)
+            c.set_option("split_sigmoid", 1)
         yield c
 
 
@@ -242,7 +245,7 @@ def test_repeated_sweeps_reschedule_from_the_work_history(ctx):
     finally:
         ctx.set_option("cost_history", 1)
         ctx.set_option("sched_min_tiles", 2048)
-        ctx.set_option("heavy_split", 64)
+        ctx.set_option("heavy_split", -1)
         ctx.set_option("split_max_tiles", 8192)
 
 

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 F = np.float32
 MODES = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")]
-SHAPES = {"auto": {}, "shared_patches": {"coop_waves": 0, "split_sigmoid": 1}, "one_wave_per_patch": {"split_max_tiles": 0, "sched_min_tiles": 1}}
+SHAPES = {"auto": {}, "shared_patches": {"coop_waves": 0, "split_sigmoid": 1, "split_max_tiles": 8192}, "one_wave_per_patch": {"split_max_tiles": 0, "sched_min_tiles": 1}}
 
 
 def _ctx(**opts):

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 F = np.float32
 MODES = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")]
-SHAPES = {"shared_patches": {"coop_waves": 0, "split_sigmoid": 1}, "shared_candidates": {"coop_waves": 8, "coop_max_tiles": 1 << 20},
+SHAPES = {"shared_patches": {"coop_waves": 0, "split_sigmoid": 1, "split_max_tiles": 8192}, "shared_candidates": {"coop_waves": 8, "coop_max_tiles": 1 << 20},
           "one_wave_per_patch": {"split_max_tiles": 0, "sched_min_tiles": 1}}
 WAVES = {"shared_patches": (4, False), "shared_candidates": (8, True), "one_wave_per_patch": (1, False)}
 
