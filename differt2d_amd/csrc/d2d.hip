@@ -1290,11 +1290,11 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             rl.leaf.box = c->d_rl_box.p;
             top.box = c->d_rl_box.p + rp.leaf.regions;
             // last-segment masks: which bins of which wall are hidden from a whole leaf region (forward RX-grid sweeps)
-            if (!txg && !grad_mode && m_masks_ok && a.shadow && c->use_hidden_masks && std::isfinite(c->scene_absmax) && std::isfinite(c->grid_absmax) &&
+            if ((!txg || txg_culled) && !grad_mode && m_masks_ok && a.shadow && c->use_hidden_masks && std::isfinite(c->scene_absmax) && std::isfinite(c->grid_absmax) &&
                 (size_t)rp.leaf.regions * (size_t)c->N <= ((size_t)1 << 28)) {
                 const float hdperp = 4096.0f * 1.1920929e-07f * std::fmax(c->scene_absmax, c->grid_absmax) * (float)(D2D_MAX_ORDER + 1);
                 const double key[12] = {(double)c->grid_version, (double)rp.leaf.R, (double)c->m, (double)c->n, (double)p->patch, (double)p->seg_tol,
-                                        (double)(p->approx * 4 + p->act), (double)p->alpha, (double)hdperp, m_dom_lo, m_dom_w, (double)c->N};
+                                        (double)(p->approx * 4 + p->act + (txg ? 16 : 0)), (double)p->alpha, (double)hdperp, m_dom_lo, m_dom_w, (double)c->N};
                 if (hdperp > 0.0f && !(c->hidden_valid && std::memcmp(key, c->hidden_key, sizeof key) == 0)) {
                     if (std::memcmp(key, c->hidden_seen, sizeof key) == 0) {  // the second launch in a row with this key: build
                         const size_t nh = (size_t)rp.leaf.regions * (size_t)c->N;
@@ -1304,7 +1304,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
                             if (c->spare_sets[i].swept_pending) HIP_TRY(hipStreamWaitEvent(ps, c->spare_sets[i].ev_swept, 0));
                         hipLaunchKernelGGL(d2d::hidden_region_kernel, dim3((unsigned)nh), dim3(64), 0, ps, c->d_occl.p, c->d_refl.p, c->d_kind.p, c->N,
                                            c->d_rl_box.p, (float)(m_in_lo + 1e-4), (float)(m_in_hi - 1e-4), hdperp, (float)m_dom_lo, (float)m_dom_w,
-                                           c->d_hidden.p);
+                                           c->d_hidden.p, txg ? 1 : 0);
                         HIP_TRY(hipGetLastError());
                         std::memcpy(c->hidden_key, key, sizeof key);
                         c->hidden_valid = true;

@@ -1181,13 +1181,14 @@ __device__ __forceinline__ bool cull_candidate(const float (&bx)[4], const float
         if (!ok) return false;
         if (WIDE) M *= 4.0f;
         if (smax + M < on_lo || smin - M > on_hi) return true;
-        if (!WIDE && lvl == K - 1 && hiddenK != 0ull) {
-            // Last segment (last wall -> cell): if every point the last interaction can occupy is hidden from the whole
+        if (lvl == K - 1 && hiddenK != 0ull) {
+            // The segment between the cell and the wall next to it (RX grids: last wall -> cell; TX grids, WIDE: cell -> first
+            // wall, masks built with the roles swapped): if every point that interaction can occupy is hidden from the whole
             // region the box lies in, the segment is occluded in every lane: valid == 0 (hidden_region_kernel; the bins are
             // the shadow masks').
             float sa = fmaxf(smin - M, on_lo) - 1e-4f, sb = fminf(smax + M, on_hi) + 1e-4f;
             float fa_ = (sa - shadow_lo) * shadow_inv, fb_ = (sb - shadow_lo) * shadow_inv;
-            if (fa_ >= 0.0f && fb_ < 64.0f && 256.0f * eps * E <= hidden_dperp) {
+            if (fa_ >= 0.0f && fb_ < 64.0f && (WIDE ? 1024.0f : 256.0f) * eps * E <= hidden_dperp) {
                 int ka = (int)fa_, kb = (int)fb_;
                 ka = ka < 0 ? 0 : ka;
                 kb = kb > 63 ? 63 : kb;
@@ -1660,7 +1661,8 @@ __device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, con
         }
         if (alive) {
             const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[w[0].idx] : 0ull;
-            if (cull_candidate<K, true>(bx, by, w, Ix, Iy, a, sh0, on_lo, on_hi)) alive = false;
+            const unsigned long long hk = (!GRAD && hidden_row && a.shadow) ? hidden_row[w[K - 1].idx] : 0ull;  // (the wall next to the cell)
+            if (cull_candidate<K, true>(bx, by, w, Ix, Iy, a, sh0, on_lo, on_hi, hk, hidden_dperp)) alive = false;
         }
         return __ballot(alive);
     }
@@ -2558,7 +2560,7 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
     const int rx = (int)(region % lv.regions_x), ry = (int)(region / lv.regions_x);
     float bx[4], by[4];
     bool ok = region_box(a, lv.box, region, bx, by);
-    const unsigned long long* hidden_row = (!GRAD && !TXG && lv.hidden) ? lv.hidden + (size_t)region * a.N : nullptr;
+    const unsigned long long* hidden_row = (!GRAD && lv.hidden) ? lv.hidden + (size_t)region * a.N : nullptr;
     const int up = parent.R / lv.R;
     const long pslot0 = ((long)(ry / up) * parent.regions_x + (rx / up)) * parent.S;
     const int* pcnt = parent.cnt[K] + pslot0;
@@ -3282,11 +3284,12 @@ __global__ void __launch_bounds__(256) pair_shadow_kernel(const float4* __restri
 // lane = bin b of w.  Bit b is set when, for some blocker j, the segment p -> q is CERTAINLY reported as intersecting j by
 // the exact path for every p within dperp of w's bin b (P3, the last interaction point) and every q of the region's
 // bounding box (P4, the cell): the same bilinear-fractional argument and margins as pair_shadow_kernel, the second quad
-// being the box (its corners are exact inputs; the margins derived for a rounded point only widen the bound).
+// being the box (its corners are exact inputs; the margins derived for a rounded point only widen the bound).  swap (TX
+// grids): the segment runs from the cell to the path's FIRST wall, so the box is P3 and the wall's bin P4.
 __global__ void __launch_bounds__(64) hidden_region_kernel(const float4* __restrict__ occl, const float4* __restrict__ refl,
                                                            const unsigned char* __restrict__ kind, int N, const float4* __restrict__ box,
                                                            float win_lo, float win_hi, float dperp, float dom_lo, float dom_w,
-                                                           unsigned long long* __restrict__ hidden) {
+                                                           unsigned long long* __restrict__ hidden, int swap) {
     const int b = threadIdx.x & 63;
     const long rw = blockIdx.x;
     const long r = rw / N;
@@ -3313,12 +3316,14 @@ __global__ void __launch_bounds__(64) hidden_region_kernel(const float4* __restr
             bool ok = true;
             int sgn = 0;
             for (int vp = 0; vp < 4 && ok; ++vp) {
-                const float px = pxv[vp], py = pyv[vp];  // P3 = p
+                // RX grids: P3 = p on the wall (the last interaction point), P4 = q in the box (the cell); TX grids (swap): the
+                // cell is the earlier point of the segment, P3 = q, P4 = p
+                const float px = swap ? ((vp & 1) ? bb.y : bb.x) : pxv[vp], py = swap ? ((vp & 2) ? bb.w : bb.z) : pyv[vp];
                 const float Cx = o.x - px, Cy = o.y - py;
                 const float fb = o.z * Cy - o.w * Cx;
                 const float errB = 8.0f * eps * (fabsf(o.z * Cy) + fabsf(o.w * Cx)) + 4.0f * eps * tlen * (fabsf(o.z) + fabsf(o.w));
                 for (int vq = 0; vq < 4; ++vq) {
-                    const float qx = (vq & 1) ? bb.y : bb.x, qy = (vq & 2) ? bb.w : bb.z;  // P4 = q
+                    const float qx = swap ? pxv[vq] : ((vq & 1) ? bb.y : bb.x), qy = swap ? pyv[vq] : ((vq & 2) ? bb.w : bb.z);
                     const float Bx = px - qx, By = py - qy;
                     const float fa = By * Cx - Bx * Cy;
                     const float fd = o.w * Bx - o.z * By;

@@ -164,3 +164,51 @@ def test_cfg2_full_map_with_masks(mode):
             assert c.hidden_masks() == (min(i, 1), i >= 1)
             crc = np.array([zlib.crc32(np.ascontiguousarray(got[r]).tobytes()) for r in range(1024)], dtype=np.uint32)
             assert np.array_equal(crc, gold[f"rx_{mode}_power_crc"]), (i, int((crc != gold[f"rx_{mode}_power_crc"]).sum()))
+
+
+@pytest.mark.parametrize("approx", [False, True])
+def test_tx_grid_masks(approx):
+    """accumulate_on_transmitters_grid_over_paths: the cells are transmitters, the masks are built for the segment from the cell
+    to the path's FIRST wall (roles of P3 / P4 swapped) and consulted where the leaf lists are refined.  A context that
+    alternates between the two grid roles rebuilds them (the role is part of their key)."""
+    from differt2d_amd import _lib as L
+    from oracle import c_oracle as CO
+
+    rx, walls = random_scene(20, seed=9)
+    X, Y = unit_grid(120, 90)
+    for lo, hi in [(0, 2), (2, 3)]:
+        kw = dict(min_order=lo, max_order=hi, approx=approx, function="hard_sigmoid")
+        with _ctx() as on, _ctx(hidden_masks=0) as off:
+            on.set_scene(walls)
+            off.set_scene(walls)
+            b = off.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
+            n_off = sum(off.debug_region_stats()["leaf_entries"].values())
+            a1 = on.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
+            a2 = on.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
+            assert on.hidden_masks() == (1, True) and sum(on.debug_region_stats()["leaf_entries"].values()) < n_off
+            r1 = on.power_map(rx, X, Y, **kw)   # the other role: other masks
+            assert not on.hidden_masks()[1]
+            r2 = on.power_map(rx, X, Y, **kw)
+            assert on.hidden_masks() == (2, True)
+            a3 = on.power_map(rx, X, Y, grid_role=L.GRID_TX, **kw)
+            r0 = off.power_map(rx, X, Y, **kw)
+        assert _same(a1, b) and _same(a2, b) and _same(a3, b) and _same(r1, r0) and _same(r2, r0), (lo, hi)
+        if hi <= 2:
+            assert _same(a2, CO.power_map(walls, rx, X, Y, prune=2, grid_role="tx", **kw))
+
+
+def test_cfg2_full_tx_grid_map_with_masks():
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg2_fullmap_crc.npz"))
+    from differt2d_amd import _lib as L
+
+    tx, walls = random_scene(50, seed=1234)
+    x = np.linspace(0.0, 1.0, 1024).astype(F)
+    X, Y = np.meshgrid(x, x)
+    with _ctx() as c:
+        c.set_scene(walls)
+        for mode, kw in (("hard", dict(approx=False)), ("hsig", dict(approx=True, function="hard_sigmoid"))):
+            for i in range(3):
+                got = c.power_map(tx, X, Y, min_order=0, max_order=2, grid_role=L.GRID_TX, **kw)
+                crc = np.array([zlib.crc32(np.ascontiguousarray(got[r]).tobytes()) for r in range(1024)], dtype=np.uint32)
+                assert np.array_equal(crc, gold[f"tx_{mode}_power_crc"]), (mode, i, int((crc != gold[f"tx_{mode}_power_crc"]).sum()))
+            assert c.hidden_masks()[1]
