@@ -37,7 +37,7 @@ def random_case(rng, big=False):
     tx = pts[0].copy()
     if rng.random() < 0.3:
         tx = (np.round(tx * 4) / 4).astype(F)
-    gx, gy = int(rng.integers(1, 41)), int(rng.integers(1, 41))
+    gx, gy = (int(rng.integers(1, 41)), int(rng.integers(1, 41))) if rng.random() < 0.7 else (int(rng.integers(40, 97)), int(rng.integers(40, 97)))
     lo, hi = (-0.25, 1.25) if rng.random() < 0.3 else (0.0, 1.0)
     X, Y = np.meshgrid(np.linspace(lo, hi, gx).astype(F), np.linspace(lo, hi, gy).astype(F))
     scale = F(10.0 ** rng.integers(-3, 4)) if rng.random() < 0.3 else F(1.0)
@@ -72,7 +72,10 @@ def main():
             ctx.set_scene(walls)
             ctx.set_candidate_mask(allowed)
             # every launch shape: patches shared between 4 waves or one wave each, identity or dearest-first order
-            ctx.set_option("split_max_tiles", 8192 if case % 2 == 0 else 0)
+            # (every fifth case: whatever the library picks by itself -- the candidate-sharing kernel on grids this small)
+            ctx.set_option("split_max_tiles", -1 if case % 5 == 4 else (8192 if case % 2 == 0 else 0))
+            ctx.set_option("coop_waves", -1 if case % 5 == 4 else 0)
+            ctx.set_option("split_sigmoid", 1)
             ctx.set_option("sched_min_tiles", 1 if case % 4 < 2 else 1 << 40)
             # region candidate lists: on (leaf regions of 4, 2 or 1 patches a side) or off (every patch enumerates)
             ctx.set_option("region_lists", 0 if case % 7 == 6 else 1)
@@ -82,11 +85,15 @@ def main():
                 print(f"  .. {case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
             role_tx = case % 3 == 2  # every third case sweeps a TX grid (the cells are transmitters, `tx` the receiver)
             got = ctx.power_map(tx, X, Y, grid_role=L.GRID_TX if role_tx else L.GRID_RX, **kw)
+            # the same launch again: work-history schedule, dearest patches cut in four, last-segment masks (built by the
+            # second launch in a row that would use them) -- same bits
+            again = ctx.power_map(tx, X, Y, grid_role=L.GRID_TX if role_tx else L.GRID_RX, **kw)
             want = CO.power_map(walls, tx, X, Y, allowed=allowed, prune=True, grid_role="tx" if role_tx else "rx", **kw)
             if kw["function"] == "sigmoid" and kw["approx"]:
                 ok = np.allclose(got, want, rtol=2e-5, atol=1e-5 * max(1.0, float(np.nanmax(np.abs(want)))), equal_nan=True)
             else:
                 ok = np.array_equal(got, want, equal_nan=True)
+            ok = ok and np.array_equal(got, again, equal_nan=True)
             if not ok:
                 bad += 1
                 d = np.abs(got - want)
