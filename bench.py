@@ -529,7 +529,9 @@ def main():
                             f"unit square ({Xl.shape[0]}x{Xl.shape[1]} per GPU), orders 0..{max_order} (C={C} candidates per "
                             f"cell), {timed_mode} validity, received_power; BASELINE.json {wl_cfg}",
                 "setup": "scene and grid resident in HBM; 1 untimed launch (buffer allocation, scene-only masks) before the warmup "
-                         "steps; every timed step sweeps the same transmitter (see moving_tx for a different one every step) and "
+                         "steps, in which what depends on the scene and the grid only is built once (wall-to-wall masks, regions' "
+                         "boxes, last-segment masks of the leaf regions: DESIGN.md Phase 0d) -- a transmitter that moves keeps them; "
+                         "every timed step sweeps the same transmitter (see moving_tx for a different one every step) and "
                          "rebuilds everything that depends on it: shadow masks, region candidate lists, patch schedule (on a side "
                          "stream beside the previous step's sweep, as in any back-to-back sequence of launches: DESIGN.md section 4)",
                 "sharding": f"{world} rank(s), 8-row blocks round-robin"

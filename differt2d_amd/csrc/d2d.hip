@@ -1574,7 +1574,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         else if (sig) coop_w = tiles <= 640 ? 16 : (tiles <= 1600 ? 8 : 4);
         else coop_w = tiles <= 256 ? 16 : 8;
         // ("split_max_tiles" = 0 asks for one wave per patch whatever the size: honoured unless the waves are forced)
-        if (d2d_host::coop_lds_bytes(c->N, coop_w, d2d::COOP_C) > d2d_host::LDS_LIMIT || tiles > lim || (c->coop_waves < 0 && c->split_max_tiles >= 0 && tiles > c->split_max_tiles)) coop_w = 0;
+        if (d2d_host::coop_lds_bytes(c->N, coop_w, d2d::COOP_C) + 4096 > d2d_host::LDS_LIMIT ||  /* (+ the kernel's static LDS: masks, chunks, floor) */ tiles > lim || (c->coop_waves < 0 && c->split_max_tiles >= 0 && tiles > c->split_max_tiles)) coop_w = 0;
     }
     // the dearest patches of a bigger launch are cut in four (see power_fwd_kernel); they are only known with a work history
     dim3 grid_fwd = grid_patches;
