@@ -101,6 +101,7 @@ SYMBOLS = [
     ("d2d_debug_grid_reuses", C.c_int, [_ctx, C.POINTER(C.c_int64)]),
     ("d2d_debug_sweep_shape", C.c_int, [_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("d2d_debug_hidden_masks", C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    ("d2d_set_optimizer", C.c_int, [_ctx, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]),
     ("d2d_power_map_launch", C.c_int, [_ctx, C.POINTER(Params), _f32p]),
     ("d2d_set_cotangent", C.c_int, [_ctx, C.c_void_p]),
     ("d2d_power_map_vg_launch", C.c_int, [_ctx, C.POINTER(Params), _f32p, C.c_int32]),

@@ -165,6 +165,8 @@ struct d2d_ctx {
     long long opt_traj_mb = 16384;  // device memory the trajectory store may take; grids that need more are swept in chunks of cells
     bool opt_parallel = true;  // optimiser-based sweeps: candidates side by side (same results as one after the other)
     int bc_steps = -1;
+    double bc_b1 = 0.0, bc_b2 = 0.0;    // ... and the decay rates the tabulated bias corrections belong to
+    double opt_lr = 0.1, opt_b1 = 0.9, opt_b2 = 0.999, opt_eps = 1e-8;  // d2d_set_optimizer (optax.adam's defaults, optimize.py:83)
     std::vector<float> theta0;  // [C][D2D_MAX_ORDER] as set by d2d_set_theta0
     DevBuf<int> d_scand, d_sorder;
     // trace scratch
@@ -382,17 +384,17 @@ d2d::ObjTables obj_tables(d2d_ctx* c) {
     return T;
 }
 
-// optax.adam(0.1) defaults (optimize.py:83): b1 = 0.9, b2 = 0.999, eps = 1e-8; bias corrections 1 - b^t tabulated
-// in double precision and rounded to fp32 (the oracle does the same).
+// optax.adam(0.1) defaults (optimize.py:83): b1 = 0.9, b2 = 0.999, eps = 1e-8 -- or what d2d_set_optimizer said; bias
+// corrections 1 - b^t tabulated in double precision and rounded to fp32 (the oracle does the same).
 int adam_cfg(d2d_ctx* c, const d2d_params* p, d2d::AdamCfg* A) {
     const int steps = p->steps;
     if (steps < 1 || steps > 1000000) return fail(D2D_ERR_INVALID, "steps must lie in 1..1e6, got %d", steps);
     if (p->many < 0 || p->many > 4096) return fail(D2D_ERR_INVALID, "many must lie in 0..4096, got %d", p->many);
-    if (c->bc_steps != steps) {
+    if (c->bc_steps != steps || c->bc_b1 != c->opt_b1 || c->bc_b2 != c->opt_b2) {
         std::vector<float> b1((size_t)steps + 1), b2((size_t)steps + 1);
         for (int t = 1; t <= steps; ++t) {
-            b1[(size_t)t - 1] = (float)(1.0 - std::pow(0.9, (double)t));
-            b2[(size_t)t - 1] = (float)(1.0 - std::pow(0.999, (double)t));
+            b1[(size_t)t - 1] = (float)(1.0 - std::pow(c->opt_b1, (double)t));
+            b2[(size_t)t - 1] = (float)(1.0 - std::pow(c->opt_b2, (double)t));
         }
         int rc;
         if ((rc = c->d_bc1.ensure((size_t)steps + 1)) || (rc = c->d_bc2.ensure((size_t)steps + 1))) return rc;
@@ -402,19 +404,22 @@ int adam_cfg(d2d_ctx* c, const d2d_params* p, d2d::AdamCfg* A) {
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
         c->bc_steps = steps;
+        c->bc_b1 = c->opt_b1;
+        c->bc_b2 = c->opt_b2;
     }
     A->solver = p->solver;
     A->steps = steps;
     A->many = p->many > 1 ? p->many : 1;
     A->bc1 = c->d_bc1.p;
     A->bc2 = c->d_bc2.p;
-    A->lr = 0.1f;
-    A->b1 = 0.9f;
-    A->b2 = 0.999f;
-    A->eps = 1e-8f;
+    // the hyper-parameters are Python floats on the reference's side (weakly typed: rounded to fp32 where they meet an fp32 array)
+    A->lr = (float)c->opt_lr;
+    A->b1 = (float)c->opt_b1;
+    A->b2 = (float)c->opt_b2;
+    A->eps = (float)c->opt_eps;
     // optax.scale_by_adam: (1 - decay) is a Python float (double arithmetic) multiplied into an fp32 array
-    A->omb1 = (float)(1.0 - 0.9);
-    A->omb2 = (float)(1.0 - 0.999);
+    A->omb1 = (float)(1.0 - c->opt_b1);
+    A->omb2 = (float)(1.0 - c->opt_b2);
     return D2D_OK;
 }
 
@@ -1910,6 +1915,19 @@ int d2d_set_theta0(d2d_ctx* c, const float* theta0, int64_t n_rows) {
     if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
     if (n_rows < 0 || (n_rows > 0 && !theta0)) return fail(D2D_ERR_INVALID, "bad theta0 arguments");
     c->theta0.assign(theta0, theta0 + n_rows * D2D_MAX_ORDER);
+    return D2D_OK;
+}
+
+int d2d_set_optimizer(d2d_ctx* c, int32_t kind, double learning_rate, double b1, double b2, double eps) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (kind != D2D_OPT_ADAM) return fail(D2D_ERR_UNSUPPORTED, "optimizer kind %d is not native (D2D_OPT_ADAM is)", (int)kind);
+    if (!std::isfinite(learning_rate) || !(b1 >= 0.0 && b1 < 1.0) || !(b2 >= 0.0 && b2 < 1.0) || !(eps >= 0.0) || !std::isfinite(eps))
+        return fail(D2D_ERR_INVALID, "Adam needs a finite learning rate, decay rates in [0, 1) and eps >= 0 (got %g, %g, %g, %g)", learning_rate, b1,
+                    b2, eps);
+    c->opt_lr = learning_rate;
+    c->opt_b1 = b1;
+    c->opt_b2 = b2;
+    c->opt_eps = eps;
     return D2D_OK;
 }
 

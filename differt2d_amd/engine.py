@@ -335,6 +335,16 @@ class Context:
             t[i, : row.size] = row
         L.check(self._lib.d2d_set_theta0(self._ctx, t.ctypes.data_as(C.c_void_p) if t.size else None, t.shape[0]))
 
+    def set_optimizer(self, optimizer=None):
+        """The optimiser of the MinPath / FermatPath solvers for the next sweeps (include/d2d.h: d2d_set_optimizer).  ``None`` =
+        the reference's default, ``optax.adam(0.1)``; else an :class:`differt2d_amd.optimize.Adam`."""
+        from .optimize import Adam, default_optimizer
+
+        o = default_optimizer() if optimizer is None else optimizer
+        if not isinstance(o, Adam):
+            raise L.D2DUnsupported(-4, f"optimizer {optimizer!r} is not native: differt2d_amd.optimize.adam(learning_rate, b1, b2, eps) is")
+        L.check(self._lib.d2d_set_optimizer(self._ctx, 0, float(o.learning_rate), float(o.b1), float(o.b2), float(o.eps)))
+
     def trace_paths(self, params: L.Params, tx, rx, candidates, xys_in=None, loss_in=None, theta0=None):
         """Solves (or validates ``xys_in``) every candidate for every (tx, rx) pair on the GPU.
 

@@ -444,18 +444,23 @@ def draw_theta0(objects_per_candidate, key, theta0=None, many: int = 1):
 
 
 def _opt_kwargs(kwargs):
-    """(steps, many, theta0) from ``path_cls_kwargs`` (reference optimize.py:44-52, 136-143)."""
+    """(steps, many, theta0, optimizer) from ``path_cls_kwargs`` (reference optimize.py:44-52, 136-143).  ``optimizer``: None
+    (the reference's default, ``optax.adam(0.1)``) or ``differt2d_amd.optimize.adam(learning_rate, b1, b2, eps)``."""
+    from .optimize import Adam
+
     kw = dict(kwargs)
     steps = int(kw.pop("steps", 100))
     many = int(kw.pop("many", 1))
     theta0 = kw.pop("theta0", None)
     if many < 1:
         raise ValueError("many must be >= 1")
-    if kw.pop("optimizer", None) is not None:
-        raise L.D2DUnsupported(-4, "only the default optimiser (optax.adam(0.1)) is implemented natively")
+    optimizer = kw.pop("optimizer", None)
+    if optimizer is not None and not isinstance(optimizer, Adam):
+        raise L.D2DUnsupported(-4, f"optimizer {optimizer!r} is not native: differt2d_amd.optimize.adam(learning_rate, b1, b2, eps) is "
+                                   "(the reference's default is optax.adam(0.1))")
     if kw:
         raise TypeError(f"unexpected keyword arguments: {sorted(kw)}")
-    return steps, many, theta0
+    return steps, many, theta0, optimizer
 
 
 class _OptPath(Path):
@@ -467,11 +472,12 @@ class _OptPath(Path):
 
         objects = list(objects)
         k = len(objects)
-        steps, many, theta0 = _opt_kwargs(kwargs)
+        steps, many, theta0, optimizer = _opt_kwargs(kwargs)
         if theta0 is not None and many == 1 and np.ndim(theta0) == 1:
             theta0 = [theta0]
         th = draw_theta0([objects], key, theta0, many) if k else [np.zeros(0, F)] * many
         ctx = default_context()
+        ctx.set_optimizer(optimizer)
         ctx.set_scene(*objects_to_tables(objects))
         p = make_params(max_order=L.D2D_MAX_ORDER, solver=cls.solver, steps=steps, many=many)
         out = ctx.trace_paths(p, _xy(tx), _xy(rx), [np.arange(k, dtype=np.int32)], theta0=th)

@@ -379,8 +379,9 @@ class Scene(Plottable):
             if path_cls_kwargs:
                 raise TypeError(f"ImagePath takes no path_cls_kwargs, got {sorted(path_cls_kwargs)}")
             return dict(solver=solver), None
-        steps, many, theta0 = _opt_kwargs(path_cls_kwargs or {})
+        steps, many, theta0, optimizer = _opt_kwargs(path_cls_kwargs or {})
         rows = draw_theta0([self.get_interacting_objects(c) for c in candidates], key, theta0, many)
+        self._ctx().set_optimizer(optimizer)  # (every optimiser-based call says which: nothing stale from an earlier one)
         return dict(solver=solver, steps=steps, many=many), rows
 
     def _trace(self, pairs_tx, pairs_rx, candidates, path_cls, path_cls_kwargs, key, validity):

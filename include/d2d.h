@@ -169,6 +169,14 @@ int d2d_debug_hidden_masks(d2d_ctx* ctx, int64_t* builds, int32_t* valid);
  * (differt2d/scene.py:1887-1890, optimize.py:132, 174-178). */
 int d2d_set_theta0(d2d_ctx* ctx, const float* theta0, int64_t n_rows);
 
+/* The optimiser of the MinPath / FermatPath solvers for the NEXT sweeps and traces (differt2d/optimize.py:44-51: any
+ * optax.GradientTransformation; default optax.adam(learning_rate=0.1), optimize.py:83).  Native: Adam with any
+ * hyper-parameters (optax.adam(learning_rate, b1, b2, eps), eps_root = 0) -- they are Python floats on the reference's
+ * side, hence doubles here; the gradients through the solver (reverse mode and forward tangents) follow them.  Any other
+ * kind: D2D_ERR_UNSUPPORTED. */
+#define D2D_OPT_ADAM 0
+int d2d_set_optimizer(d2d_ctx* ctx, int32_t kind, double learning_rate, double b1, double b2, double eps);
+
 /* Launches the fused forward sweep for transmitter tx[2] on the ctx stream (asynchronous).
  * Inputs and outputs stay resident in HBM. params->solver selects ImagePath (fused image-method kernel) or
  * MinPath / FermatPath (per-cell Adam loop of params->steps iterations, hand-derived gradient). */

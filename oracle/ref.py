@@ -593,6 +593,26 @@ def parametric_to_cartesian(objs, theta, tx, rx, xp=NUMPY):
     return pts
 
 
+# Hyper-parameters of the solvers' Adam (tests of d2d_set_optimizer set them through `adam_hyper`; the reference's default is
+# optax.adam(0.1), optimize.py:83).
+_ADAM = dict(lr=0.1, b1=0.9, b2=0.999, eps=1e-8)
+
+
+class adam_hyper:
+    """``with adam_hyper(lr=0.05, b1=0.8): ...`` -- opt_path / opt_path_diff inside use these instead of the defaults."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = dict(_ADAM)
+        _ADAM.update(self.kw)
+
+    def __exit__(self, *exc):
+        _ADAM.clear()
+        _ADAM.update(self.old)
+
+
 def adam_minimize(value_and_grad, x0, steps=100, lr=0.1, b1=0.9, b2=0.999, eps=1e-8, xp=NUMPY):
     """optimize.py:44-97 with optax.adam(0.1) (optax 0.2.4 defaults b1=.9 b2=.999 eps=1e-8,
     eps_root=0): returns (x_final, loss evaluated BEFORE the last update).
@@ -804,7 +824,7 @@ def opt_path(solver, tx, objs, rx, theta0, steps, xp=NUMPY):
         return loss.detach(), [gi.detach() for gi in g]
 
     x0 = [torch.full(batch, float(theta0[i]), dtype=tb.tdtype) for i in range(n_unknowns)]
-    x, last_loss = adam_minimize(vg, x0, steps=steps, xp=tb)
+    x, last_loss = adam_minimize(vg, x0, steps=steps, xp=tb, **_ADAM)
     pts = parametric_to_cartesian(t_objs, x, t_tx, t_rx, tb)
     if solver == "fermat":
         loss = path_loss(t_objs, pts, tb)  # geometry.py:1204
@@ -836,7 +856,7 @@ def opt_path_diff(solver, tx, objs, rx, theta0, steps, tb):
         return loss, list(g)
 
     x0 = [torch.full(tuple(batch), float(theta0[i]), dtype=tb.tdtype).requires_grad_(True) for i in range(n_unknowns)]
-    x, last_loss = adam_minimize(vg, x0, steps=steps, xp=tb)
+    x, last_loss = adam_minimize(vg, x0, steps=steps, xp=tb, **_ADAM)
     pts = parametric_to_cartesian(objs, x, tx, rx, tb)
     loss = path_loss(objs, pts, tb) if solver == "fermat" else last_loss  # geometry.py:1204 / :1284-1288
     return [p.expand(*batch, 2) for p in pts], loss

@@ -500,3 +500,102 @@ def test_cfg5_full_size_value_and_gradient_on_sampled_cells():
     for k_got, k_want in (("tx_bar", "fixed_bar"), ("walls_bar", "xys_bar"), ("phi_bar", "phi_bar")):
         _tight(sub[k_got], z[k_want + "64"], z[k_want + "32"], k_got)
     assert np.abs(z["xys_bar64"][4]).max() > 0 and z["phi_bar64"][4] != 0  # d sum(P) / d (RIS vertices, phi) is not trivially 0
+
+
+# ---- optimizer= (reference optimize.py:44-51): Adam with other hyper-parameters ------------------------------------------------
+
+
+@pytest.mark.parametrize("solver", ["min", "fermat"])
+def test_custom_adam_hyper_parameters_trajectory_and_gradients(solver):
+    """`optimizer=optax.adam(learning_rate, b1, b2, eps)` in the reference's `path_cls_kwargs` -> d2d_set_optimizer: the interaction
+    points after 20 steps and the gradients through the solver follow the hyper-parameters (against the oracle run with the same
+    ones), differ from the default optimiser's, and the default comes back when nothing is asked for."""
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import default_context, make_params
+    from differt2d_amd.optimize import adam
+    from oracle import ref as R
+
+    hyper = dict(lr=0.03, b1=0.8, b2=0.95, eps=1e-6)
+    spec = adam(learning_rate=hyper["lr"], b1=hyper["b1"], b2=hyper["b2"], eps=hyper["eps"])
+    scene = _ris_scene()
+    xys, kind, phi = _scene_tables(scene)
+    objs = _oracle_objs(scene)
+    cands = [np.array(c, np.int32) for c in ([0], [4], [5], [0, 4], [3, 5])]
+    rng = np.random.default_rng(13)
+    theta0 = [rng.random(sum(objs[int(i)].parameters_count() for i in c), dtype=F) for c in cands]
+    tx = np.array([[0.2, 0.2], [0.31, 0.77]], F)
+    rx = np.array([[0.8, 0.6], [0.62, 0.18]], F)
+    ctx = default_context()
+    ctx.set_scene(xys, kind, phi)
+    p = make_params(min_order=0, max_order=4, solver=solver, steps=20, approx=True)
+    th = [np.pad(t, (0, 4 - len(t))) for t in theta0]
+    try:
+        ctx.set_optimizer(spec)
+        got = ctx.trace_paths(p, tx, rx, cands, theta0=th)
+        ctx.set_optimizer(None)
+        dflt = ctx.trace_paths(p, tx, rx, cands, theta0=th)
+        for ci, c in enumerate(cands):
+            inter64 = [R.Obj(objs[int(i)].kind, np.asarray(objs[int(i)].xys, np.float64), objs[int(i)].phi) for i in c]
+            with R.adam_hyper(**hyper):
+                pts64, _ = R.opt_path(solver, tx.astype(np.float64), inter64, rx.astype(np.float64), theta0[ci], 20, R.NUMPY64)
+            pts_d, _ = R.opt_path(solver, tx.astype(np.float64), inter64, rx.astype(np.float64), theta0[ci], 20, R.NUMPY64)
+            n = len(c) + 2
+            np.testing.assert_allclose(got["xys"][:, ci, :n], np.stack(pts64, axis=1), rtol=0, atol=2e-5, err_msg=f"custom {c.tolist()}")
+            np.testing.assert_allclose(dflt["xys"][:, ci, :n], np.stack(pts_d, axis=1), rtol=0, atol=2e-5, err_msg=f"default {c.tolist()}")
+        assert np.nanmax(np.abs(got["xys"] - dflt["xys"])) > 1e-2  # the hyper-parameters matter
+        # gradients through the solver, both kernels
+        scene, xys, kind, phi, X, Y, cands_g, theta0_g = _opt_case(30, solver, True)
+        txp = scene.transmitters["tx"].xy
+        cot = (np.random.default_rng(5).random(X.shape) + 0.5).astype(F)
+        okw = dict(solver=solver, steps=30, grid_role="rx", approx=True)
+        with R.adam_hyper(**hyper):
+            w64 = R.opt_value_and_grads(kind, xys, phi, txp, X, Y, cands_g, theta0_g, dtype="float64", cotangent=cot, **okw)
+            w32 = R.opt_value_and_grads(kind, xys, phi, txp, X, Y, cands_g, theta0_g, dtype="float32", cotangent=cot, **okw)
+        stable = _oracle_stable(w64["value"], w32["value"], w64["grad_cell"], w32["grad_cell"])
+        assert stable.mean() >= 0.8
+        cot_m = (cot * stable).astype(F)
+        if not stable.all():
+            with R.adam_hyper(**hyper):
+                w64 = R.opt_value_and_grads(kind, xys, phi, txp, X, Y, cands_g, theta0_g, dtype="float64", cotangent=cot_m, **okw)
+                w32 = R.opt_value_and_grads(kind, xys, phi, txp, X, Y, cands_g, theta0_g, dtype="float32", cotangent=cot_m, **okw)
+        for grad_mode in (0, 1):
+            ctx.set_option("opt_grad_mode", grad_mode)
+            ctx.set_optimizer(spec)
+            g = _gpu_opt_grads(xys, kind, phi, txp, X, Y, cands_g, theta0_g, cot_m, solver=solver, steps=30, grid_role=L.GRID_RX,
+                               min_order=0, max_order=1, approx=True)
+            _tight(g["grad_rx"][stable], w64["grad_cell"][stable], w32["grad_cell"][stable], "per-cell gradient")
+            _tight(g["tx_bar"], w64["fixed_bar"], w32["fixed_bar"], "fixed end point")
+            _tight(g["walls_bar"], w64["xys_bar"], w32["xys_bar"], "object end points")
+            _tight(g["phi_bar"], w64["phi_bar"], w32["phi_bar"], "phi")
+    finally:
+        ctx.set_option("opt_grad_mode", 0)
+        ctx.set_optimizer(None)
+    # what is not Adam is refused, loudly
+    with pytest.raises(L.D2DError):
+        ctx.set_optimizer("sgd")
+    with pytest.raises(L.D2DError):
+        L.check(ctx._lib.d2d_set_optimizer(ctx._ctx, 0, 0.1, 1.0, 0.999, 1e-8))  # b1 = 1: not a decay rate
+
+
+def test_optimizer_through_the_scene_api():
+    """The reference's call shape: `path_cls_kwargs=dict(steps=..., optimizer=...)` (scene.py:1803-1826 -> geometry.py:1256-1288)."""
+    from differt2d_amd.geometry import MinPath
+    from differt2d_amd.optimize import adam, default_optimizer
+    from differt2d_amd import _lib as L
+
+    scene = _ris_scene()
+    x = np.linspace(0.05, 0.95, 12).astype(F)
+    X, Y = np.meshgrid(x, x)
+    cands = scene.all_path_candidates(min_order=1, max_order=1)
+    rng = np.random.default_rng(2)
+    theta0 = [rng.random(sum(o.parameters_count() for o in scene.get_interacting_objects(c)), dtype=F) for c in cands]
+    from differt2d_amd.utils import received_power
+
+    kw = dict(fun=received_power, path_cls=MinPath, min_order=1, max_order=1, approx=True, reduce_all=True)
+    a = scene.accumulate_on_receivers_grid_over_paths(X, Y, path_cls_kwargs=dict(steps=40, theta0=theta0), **kw)
+    b = scene.accumulate_on_receivers_grid_over_paths(X, Y, path_cls_kwargs=dict(steps=40, theta0=theta0, optimizer=default_optimizer()), **kw)
+    c = scene.accumulate_on_receivers_grid_over_paths(X, Y, path_cls_kwargs=dict(steps=40, theta0=theta0, optimizer=adam(0.01)), **kw)
+    d = scene.accumulate_on_receivers_grid_over_paths(X, Y, path_cls_kwargs=dict(steps=40, theta0=theta0), **kw)
+    assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, d, equal_nan=True) and not np.array_equal(a, c, equal_nan=True)
+    with pytest.raises(L.D2DUnsupported):
+        scene.accumulate_on_receivers_grid_over_paths(X, Y, path_cls_kwargs=dict(steps=40, theta0=theta0, optimizer=object()), **kw)
