@@ -16,15 +16,26 @@ F = np.float32
 
 
 def key_to_generator(key) -> np.random.Generator:
-    """Turns the reference's ``key`` argument into a NumPy generator.
-
-    ``jax.random`` (Threefry) is not available to this implementation, so random draws are NOT
-    bit-compatible with the reference; any int / int array / Generator is accepted as a seed."""
+    """A NumPy generator for callers that ask for NumPy's PRNG explicitly (a ``Generator``, or ``None`` = fresh entropy).
+    The reference's ``key`` arguments -- int seeds, Threefry keys -- are drawn with differt2d_amd/random.py instead
+    (``random_uniform``)."""
     if isinstance(key, np.random.Generator):
         return key
     if key is None:
         return np.random.default_rng()
     return np.random.default_rng(np.asarray(key, dtype=np.uint32).reshape(-1).tolist())
+
+
+def random_uniform(key, shape) -> np.ndarray:
+    """``jax.random.uniform(key, shape)`` for an int seed / Threefry key (the reference's numbers: differt2d_amd/random.py), or
+    the same shape from a ``numpy.random.Generator``."""
+    if isinstance(key, np.random.Generator):
+        return key.random(shape, dtype=F)
+    if key is None:
+        raise TypeError("a `key` is needed to draw random numbers")
+    from . import random as jr
+
+    return jr.uniform(jr.as_key(key), shape)
 
 
 def linspace_f32(start, stop, num: int) -> np.ndarray:
@@ -97,8 +108,7 @@ class Interactable(ABC):
 
     def sample(self, key) -> np.ndarray:
         """A random point on the object (uniform parametric coordinates in [0, 1))."""
-        rng = key_to_generator(key)
-        return self.parametric_to_cartesian(rng.random(self.parameters_count(), dtype=F))
+        return self.parametric_to_cartesian(random_uniform(key, (self.parameters_count(),)))  # reference abc.py:176-178
 
     @abstractmethod
     def cartesian_to_parametric(self, carte_coords) -> np.ndarray:

@@ -422,25 +422,46 @@ class ImagePath(Path):
         return cls(xys=out["xys"][0, 0, : k + 2], loss=out["loss"][0, 0])
 
 
-def draw_theta0(objects_per_candidate, key, theta0=None, many: int = 1):
+def _theta0_rows(key, count: int, many: int):
+    """``minimize_many_random_uniform``'s draws for one path (reference optimize.py:132, 174-178): ``uniform(key, (n,))``, or,
+    ``many > 1``, one draw per key of ``split(key, many)``."""
+    from . import random as jr
+
+    if many == 1:
+        return [jr.uniform(key, (count,))]
+    return [jr.uniform(k, (count,)) for k in jr.split(key, many)]
+
+
+def draw_theta0(objects_per_candidate, key, theta0=None, many: int = 1, per_candidate_keys: bool = False):
     """Initial parametric guesses: ``many`` consecutive rows per candidate, ``U[0, 1)`` per unknown (reference
     optimize.py:132, 174-178).
 
-    The reference splits ``key`` into one Threefry key per candidate (scene.py:1887-1888) and, for ``many > 1``, once
-    more per start; JAX's PRNG is not available here, so a NumPy generator seeded by ``key`` draws the rows in order
-    instead -- same distribution, different numbers.  Pass ``theta0`` explicitly for reproducible comparisons."""
-    from .abc import key_to_generator
+    ``key``: an int seed or a raw Threefry key (``differt2d_amd.random.PRNGKey``) -- the draws are then the reference's own
+    (``jax.random``'s Threefry, restated in differt2d_amd/random.py): with ``per_candidate_keys`` the key is first split into
+    one key per candidate, as the grid sweeps do (scene.py:1585, 1888); else it is the key of the single path
+    (``from_tx_objects_rx``).  A ``numpy.random.Generator`` draws the rows in order from NumPy's PRNG instead.  Pass
+    ``theta0`` to skip the draw."""
+    from . import random as jr
 
-    counts = [sum(o.parameters_count() for o in objs) for objs in objects_per_candidate for _ in range(many)]
+    counts = [sum(o.parameters_count() for o in objs) for objs in objects_per_candidate]
     if theta0 is not None:
         rows = [np.asarray(r, F).reshape(-1) for r in theta0]
-        if len(rows) != len(counts) or any(r.size < c for r, c in zip(rows, counts)):
+        need = [c for c in counts for _ in range(many)]
+        if len(rows) != len(need) or any(r.size < c for r, c in zip(rows, need)):
             raise ValueError("theta0 must hold `many` rows per candidate with at least as many values as unknowns")
         return rows
     if key is None:
         raise TypeError("this path class needs a `key` (or explicit `theta0`) to draw its initial guess")
-    rng = key_to_generator(key)
-    return [rng.random(c, dtype=F) for c in counts]
+    if isinstance(key, np.random.Generator):
+        return [key.random(c, dtype=F) for c in counts for _ in range(many)]
+    key = jr.as_key(key)
+    keys = jr.split(key, len(counts)) if per_candidate_keys else [key] * len(counts)
+    if not per_candidate_keys and len(counts) != 1:
+        raise ValueError("one key per path: split it per candidate (per_candidate_keys)")
+    rows = []
+    for k, c in zip(keys, counts):
+        rows.extend(_theta0_rows(k, c, many))
+    return rows
 
 
 def _opt_kwargs(kwargs):

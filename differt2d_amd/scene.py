@@ -28,7 +28,7 @@ import numpy as np
 
 from . import _lib as L
 from . import logic
-from .abc import Object, Plottable, key_to_generator
+from .abc import Object, Plottable, random_uniform
 from .engine import Context, default_context, make_params
 from .geometry import (
     FermatPath, ImagePath, MinPath, Path, Point, RIS, Vertex, Wall, _opt_kwargs, _validity_kwargs, closest_point,
@@ -250,8 +250,9 @@ class Scene(Plottable):
     @classmethod
     def random_uniform_scene(cls, n_transmitters: int = 1, n_walls: int = 1, n_receivers: int = 1, *, key) -> "Scene":
         """Random scene with the reference's layout (scene.py:718-733): one uniform draw of
-        ``n_transmitters + 2 n_walls + n_receivers`` points. The PRNG is NumPy's (``key`` seeds it), not Threefry."""
-        pts = key_to_generator(key).random((n_transmitters + 2 * n_walls + n_receivers, 2), dtype=F)
+        ``n_transmitters + 2 n_walls + n_receivers`` points -- the reference's own numbers for an int seed / Threefry key
+        (``differt2d_amd.random.PRNGKey(1234)`` = ``jax.random.PRNGKey(1234)``)."""
+        pts = random_uniform(key, (n_transmitters + 2 * n_walls + n_receivers, 2))
         txs = {f"tx_{i}": Point(xy=pts[i, :]) for i in range(n_transmitters)}
         rxs = {f"rx_{i}": Point(xy=pts[-(i + 1), :]) for i in range(n_receivers)}
         walls = [Wall(xys=pts[2 * i + n_transmitters : 2 * i + 2 + n_transmitters, :]) for i in range(n_walls)]
@@ -380,17 +381,41 @@ class Scene(Plottable):
                 raise TypeError(f"ImagePath takes no path_cls_kwargs, got {sorted(path_cls_kwargs)}")
             return dict(solver=solver), None
         steps, many, theta0, optimizer = _opt_kwargs(path_cls_kwargs or {})
-        rows = draw_theta0([self.get_interacting_objects(c) for c in candidates], key, theta0, many)
+        rows = draw_theta0([self.get_interacting_objects(c) for c in candidates], key, theta0, many, per_candidate_keys=True)
         self._ctx().set_optimizer(optimizer)  # (every optimiser-based call says which: nothing stale from an earlier one)
         return dict(solver=solver, steps=steps, many=many), rows
 
     def _trace(self, pairs_tx, pairs_rx, candidates, path_cls, path_cls_kwargs, key, validity):
-        """GPU trace of every candidate for every (tx, rx) pair -> dict of arrays, leading shape (P, C)."""
+        """GPU trace of every candidate for every (tx, rx) pair -> dict of arrays, leading shape (P, C).
+
+        Optimiser-based path classes with a Threefry key: the reference hands every (pair, candidate) its own key from a chain
+        of splits -- ``key, key_path = split(key, 2)`` in pair-major order (scene.py:1204-1219) -- so every pair is traced with
+        its own initial guesses."""
+        from . import random as jr
+        from .geometry import _theta0_rows
+
         ctx = self._ctx()
         self._upload(ctx)
-        extra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, candidates, key)
-        params = make_params(max_order=L.D2D_MAX_ORDER, **extra, **validity)
-        return ctx.trace_paths(params, pairs_tx, pairs_rx, candidates, theta0=theta0)
+        solver = self._solver_of(path_cls)
+        kw = dict(path_cls_kwargs or {})
+        chain = solver != "image" and key is not None and not isinstance(key, np.random.Generator) and kw.get("theta0") is None
+        if not chain:
+            extra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, candidates, key)
+            params = make_params(max_order=L.D2D_MAX_ORDER, **extra, **validity)
+            return ctx.trace_paths(params, pairs_tx, pairs_rx, candidates, theta0=theta0)
+        steps, many, _, optimizer = _opt_kwargs(kw)
+        ctx.set_optimizer(optimizer)
+        params = make_params(max_order=L.D2D_MAX_ORDER, solver=solver, steps=steps, many=many, **validity)
+        counts = [sum(o.parameters_count() for o in self.get_interacting_objects(c)) for c in candidates]
+        key = jr.as_key(key)
+        outs = []
+        for p in range(len(pairs_tx)):
+            rows = []
+            for c in counts:
+                key, key_path = jr.split(key, 2)
+                rows.extend(_theta0_rows(key_path, c, many))
+            outs.append(ctx.trace_paths(params, pairs_tx[p : p + 1], pairs_rx[p : p + 1], candidates, theta0=rows))
+        return {k: np.concatenate([o[k] for o in outs], axis=0) for k in outs[0]}
 
     # ------------------------------------------------------------------- individual paths
     def all_paths(self, path_cls: type = ImagePath, path_cls_kwargs: Optional[Mapping] = None, min_order: int = 0,

@@ -1,0 +1,70 @@
+"""Host logic: the NumPy restatement of JAX's Threefry PRNG (differt2d_amd/random.py) against published known answers -- JAX is
+not importable here, so these are what pins it: the Random123 known-answer vectors of Threefry-2x32-20 (also the vectors of
+JAX's own test suite, tests/random_test.py::testThreefry2x32), `random.split(PRNGKey(0))` as printed in JAX's PRNG design note
+(docs/jep/263-prng.md), and `random.uniform(PRNGKey(0))` = 0.41845703 (the value every JAX tutorial shows)."""
+
+import numpy as np
+
+from differt2d_amd import random as R
+
+U = np.uint32
+
+
+def test_block_function_known_answers():
+    for key, ctr, want in (((0x0, 0x0), (0x0, 0x0), (0x6B200159, 0x99BA4EFE)),
+                           ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+                           ((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3), (0xC4923A9C, 0x483DF7A0))):
+        y0, y1 = R.threefry2x32(np.array(key, U), np.array([ctr[0]], U), np.array([ctr[1]], U))
+        assert (int(y0[0]), int(y1[0])) == want
+
+
+def test_prngkey_split_and_uniform_known_answers():
+    assert R.PRNGKey(0).tolist() == [0, 0] and R.PRNGKey(1234).tolist() == [0, 1234] and R.PRNGKey(2**32 + 5).tolist() == [1, 5]
+    assert R.split(R.PRNGKey(0)).tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]
+    u = R.uniform(R.PRNGKey(0))
+    assert u.dtype == np.float32 and u.shape == () and abs(float(u) - 0.41845703) < 5e-9
+    assert float(u) == float(np.float32(0x359000) / np.float32(2**23))  # 0x6b200159 >> 9 under the exponent of 1.0, minus 1
+
+
+def test_layout_properties():
+    key = R.PRNGKey(1234)
+    # an odd number of counts is padded with one zero count, whose output is dropped
+    a = R.random_bits(key, (5,))
+    y0, y1 = R.threefry2x32(key, np.array([0, 1, 2], U), np.array([3, 4, 0], U))
+    assert a.tolist() == np.concatenate([y0, y1])[:5].tolist()
+    # shapes are filled in row-major order of the flat index
+    assert R.uniform(key, (3, 2)).ravel().tolist() == R.uniform(key, (6,)).tolist()
+    u = R.uniform(key, (1000,))
+    assert u.min() >= 0.0 and u.max() < 1.0 and 0.45 < u.mean() < 0.55
+    assert len({tuple(k) for k in R.split(key, 7).tolist()}) == 7
+    assert R.as_key(1234).tolist() == key.tolist() and R.as_key(key).tolist() == key.tolist()
+    lo_hi = R.uniform(key, (100,), minval=-2.0, maxval=3.0)
+    assert lo_hi.min() >= -2.0 and lo_hi.max() < 3.0
+
+
+def test_key_plumbing_of_the_mirror():
+    """Where the reference draws from `jax.random`: random scenes (scene.py:718-733), `Interactable.sample` (abc.py:176-178), the
+    solvers' initial guesses -- one key per candidate in the grid sweeps (scene.py:1585, 1888), `split(key, many)` inside a
+    candidate (optimize.py:174-178), the key itself for a single path (`from_tx_objects_rx`)."""
+    from differt2d_amd.geometry import Wall, draw_theta0
+    from differt2d_amd.scene import Scene
+
+    key = R.PRNGKey(1234)
+    scene = Scene.random_uniform_scene(n_transmitters=2, n_walls=3, n_receivers=1, key=key)
+    pts = R.uniform(key, (2 + 6 + 1, 2))
+    assert np.array_equal(scene.transmitters["tx_1"].xy, pts[1]) and np.array_equal(scene.receivers["rx_0"].xy, pts[-1])
+    assert np.array_equal(scene.objects[2].xys, pts[2 * 2 + 2 : 2 * 2 + 4])
+    assert np.array_equal(Scene.random_uniform_scene(n_walls=3, key=1234).objects[0].xys, Scene.random_uniform_scene(n_walls=3, key=key).objects[0].xys)
+    w = Wall(xys=[[0.0, 0.0], [2.0, 0.0]])
+    assert np.array_equal(w.sample(key), w.parametric_to_cartesian(R.uniform(key, (1,))))
+    objs = [[w], [w, w], []]
+    rows = draw_theta0(objs, key, many=1, per_candidate_keys=True)
+    keys = R.split(key, 3)
+    assert [r.tolist() for r in rows] == [R.uniform(keys[0], (1,)).tolist(), R.uniform(keys[1], (2,)).tolist(), []]
+    rows = draw_theta0(objs[:2], key, many=3, per_candidate_keys=True)
+    keys = R.split(key, 2)
+    want = [R.uniform(k, (n,)).tolist() for kc, n in ((keys[0], 1), (keys[1], 2)) for k in R.split(kc, 3)]
+    assert [r.tolist() for r in rows] == want
+    assert draw_theta0([[w, w]], key, many=1)[0].tolist() == R.uniform(key, (2,)).tolist()  # a single path: the key itself
+    g = np.random.default_rng(5)
+    assert len(draw_theta0(objs[:2], g, many=2, per_candidate_keys=True)) == 4  # NumPy's PRNG on request
