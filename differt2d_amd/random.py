@@ -6,8 +6,9 @@ non-partitionable layout: the default of the JAX releases DiffeRT2d v0.4.0 runs 
 The reference draws random scenes (scene.py:716-733) and the initial guesses of the MinPath / FermatPath solvers
 (optimize.py:132, 174-178; one key per candidate, scene.py:1585, 1888; a chain of splits in ``all_paths``, scene.py:1210) from
 ``jax.random``; with this module a call with ``key=PRNGKey(1234)`` draws the same numbers here.  JAX itself cannot be
-imported in this repository's containers, so the restatement is pinned by published known answers instead
-(tests/test_random.py): the Random123 / JAX test-suite vectors of the block function, ``random.split(PRNGKey(0))`` from JAX's
+imported in this repository's containers, so the restatement is pinned by known answers instead (tests/test_random.py): the
+reference's own doctest of a keyed draw (abc.py:168-174: Wall.sample(PRNGKey(1234)) = [0.88359046, 1.1781206]), the
+Random123 / JAX test-suite vectors of the block function, ``random.split(PRNGKey(0))`` from JAX's
 PRNG design note, and ``random.uniform(PRNGKey(0))`` = 0.41845703.  Host code by nature: draws are a few numbers per call.
 """
 

@@ -68,3 +68,13 @@ def test_key_plumbing_of_the_mirror():
     assert draw_theta0([[w, w]], key, many=1)[0].tolist() == R.uniform(key, (2,)).tolist()  # a single path: the key itself
     g = np.random.default_rng(5)
     assert len(draw_theta0(objs[:2], g, many=2, per_candidate_keys=True)) == 4  # NumPy's PRNG on request
+
+
+def test_reference_doctest_known_answer():
+    """The reference's OWN known answer for a keyed draw (differt2d/abc.py:168-174, the doctest of `Interactable.sample`):
+    `Wall(xys=[[0, 0], [3, 4]]).sample(key=jax.random.PRNGKey(1234))` -> `Array([0.88359046, 1.1781206], dtype=float32)`."""
+    from differt2d_amd.geometry import Wall
+
+    got = Wall(xys=[[0.0, 0.0], [3.0, 4.0]]).sample(key=R.PRNGKey(1234))
+    assert got.dtype == np.float32 and np.allclose(got, [0.88359046, 1.1781206], rtol=0, atol=6e-8)
+    assert [f"{v:.8g}" for v in got] == ["0.88359046", "1.1781206"]  # as the doctest prints them
