@@ -12,14 +12,17 @@
 //     t = fl(a/d) outside the soft window by a 1e-5 relative margin.
 //
 //   * a candidate is never evaluated at all when conservative geometry proves that exact zero for a whole 8 x 8 patch:
-//     the tile culling (cull_candidate), the first-segment shadow masks (shadow_tx_kernel) and the wall-to-wall masks
-//     (pair_shadow_kernel), each with explicit rounding bounds.
+//     the tile culling (cull_candidate), the first-segment shadow masks (shadow_tx_kernel / shadow_fill_kernel), the
+//     wall-to-wall masks (pair_shadow_kernel) and the last-segment masks of the leaf regions (hidden_region_kernel), each
+//     with explicit rounding bounds.
 //
 // File map: SweepArgs / eval_candidate (exact evaluation + hand-derived adjoint) / sweep_order (plain nested loops) /
 // s_range, cull_candidate, sweep_order_culled (prefix odometer, two-stage culling, survivors in candidate order) /
+// region lists (EmitSink, cull_batch, sweep_order_listed, region_list_kernel, region_refine_kernel) /
 // power_fwd_kernel (one wave per patch; dearest patches cut in four) / power_fwd_split_kernel (small launches: every
-// patch shared by 4 waves) / sweep_order_culled_txg + power_fwd_txg_kernel (TX grids) / patch_* (dearest-first schedule)
-// / shadow_tx_kernel, pair_shadow_kernel (occlusion masks) / power_vg_kernel (exhaustive value+grad) / trace_kernel and
+// patch shared by 4 waves prefix by prefix) / power_fwd_coop_kernel (the smallest: 4 / 8 / 16 waves, candidate by candidate) /
+// sweep_order_culled_txg + power_fwd_txg_kernel (TX grids) / patch_* (dearest-first schedule) / shadow_fill_kernel,
+// pair_shadow_kernel, hidden_region_kernel (occlusion masks) / power_vg_kernel (exhaustive value+grad) / trace_kernel and
 // the literal object code (any mix of Wall / RIS / Vertex) / power_opt_*_kernel (MinPath / FermatPath sweeps).
 //
 // Reference lines followed (DiffeRT2d v0.4.0): see include/d2d.h and oracle/ref.py.
