@@ -1034,6 +1034,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     // Pipelined preparation (see d2d_ctx::PrepSet): this launch takes the set the launch before the previous one used,
     // and builds into it on the side stream, which first waits for the sweep that read it last.
     // (instrumented launches prepare on the main stream: their counters are zeroed there, and the list kernels add to them)
+    // (a lone call has no previous sweep to hide its preparation behind; preparing on the sweep stream whenever that stream is idle
+    // was measured: launch -> synchronise 0.146 -> 0.137 ms at 300^2, but back-to-back launches whose host runs ahead of the GPU
+    // only now and then lose 4-8 %: not kept)
     const bool piped = c->pipeline && c->aux_stream != nullptr && d_stats == nullptr;
     bool set_was_swept = false;  // the set this launch takes was read by a sweep that may still be running (ev_swept says when it is through)
     if (piped) {
@@ -1447,7 +1450,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             HIP_TRY(hipEventRecord(c->evk1, c->stream));         \
             c->have_kernel_time = true;                          \
         }                                                        \
-        if (piped) {                                             \
+        if (c->pipeline && c->aux_stream != nullptr) {           \
+            /* (also behind a launch that prepared on the sweep stream: a later pipelined launch may take its set) */ \
             HIP_TRY(hipEventRecord(c->ev_swept, c->stream));     \
             c->swept_pending = true;                             \
         }                                                        \
