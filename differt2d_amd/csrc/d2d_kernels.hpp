@@ -2650,7 +2650,8 @@ template <int K, int MODE, bool GRAD = false, bool EMIT = false>
 __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const float4* tab, const float (&bx)[4],
                                                        const float (&by)[4], float cx, float cy, bool lane_bad, float& acc,
                                                        WaveStats& st, GradCtx* g = nullptr, int p_lo = 0, int p_hi = 0x7fffffff,
-                                                       EmitSink* emit = nullptr) {
+                                                       EmitSink* emit = nullptr, const unsigned long long* hidden_row = nullptr,
+                                                       float hidden_dperp = 0.0f) {
     static_assert(!EMIT || K >= 2, "lists exist for orders >= 2");
     const int lane = threadIdx.x & 63;
     int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
@@ -2694,7 +2695,9 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
                     image_of(q0, Ix[j - 1], Iy[j - 1], Ix[j], Iy[j]);
                 }
                 const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[wl] : 0ull;
-                if (alive && cull_candidate<K, true>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi)) alive = false;
+                // (order 1: the wall is also the one next to the cell -- the region's masks of the segment cell -> wall)
+                const unsigned long long hk = (K == 1 && !GRAD && hidden_row && a.shadow) ? hidden_row[wl] : 0ull;
+                if (alive && cull_candidate<K, true>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi, hk, hidden_dperp)) alive = false;
             }
             unsigned long long mask = __ballot(alive);
             D2D_WORK(5 * K);
@@ -2751,7 +2754,9 @@ __device__ __forceinline__ void sweep_order_listed_txg(const SweepArgs& a, const
         const unsigned long long code = pool[(size_t)chunk * RL_CHUNK + (off & (RL_CHUNK - 1)) + (have ? lane : 0)];
         if ((off & (RL_CHUNK - 1)) == RL_CHUNK - 64 && off + 64 < n) chunk = next[chunk];
         float Ix[K], Iy[K];
-        unsigned long long mask = cull_batch<K, GRAD, true>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi);
+        const unsigned long long* hid = (D2D_HIDDEN_PATCH && !GRAD) ? rlc->leaf.hidden : nullptr;
+        unsigned long long mask = cull_batch<K, GRAD, true>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi, hid ? hid + (size_t)region * a.N : nullptr,
+                                                            hid ? rlc->leaf.hidden_dperp : 0.0f);
         D2D_WORK(5 * K);
         while (mask) {
             const int b = __builtin_ctzll(mask);
@@ -2828,7 +2833,11 @@ __device__ __forceinline__ void txg_patch(const SweepArgs& a, const float4* tab,
     const float bx[4] = {box_ok ? x0 : qn, x1, x1, x0};
     const float by[4] = {y0, y0, y1, y1};
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, GRADK, true>(a, cx, cy, a.txx, a.txy, lane_bad, acc, st, &g);
-    if (a.min_order <= 1 && a.max_order >= 1) sweep_order_culled_txg<1, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g);
+    if (a.min_order <= 1 && a.max_order >= 1) {
+        const unsigned long long* hid = (LISTED && !GRADK) ? cmem(a.rl)->leaf.hidden : nullptr;
+        sweep_order_culled_txg<1, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g, 0, 0x7fffffff, nullptr,
+                                               hid ? hid + (size_t)region * a.N : nullptr, hid ? cmem(a.rl)->leaf.hidden_dperp : 0.0f);
+    }
     if constexpr (LISTED) {
         if (a.min_order <= 2 && a.max_order >= 2) sweep_order_listed_txg<2, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g, region);
         if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_listed_txg<3, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g, region);
