@@ -238,7 +238,8 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *                  of where the wall is certainly hidden from the WHOLE region (scene, grid and validity mode only: built
  *                  by the second launch in a row that would use it, kept until the scene, the grid or the mode changes);
  *                  candidates whose last interaction point can only lie in hidden bins leave the region's list, and order-1
- *                  candidates the patch's culling (same results)
+ *                  candidates the patch's culling (same results); "hidden_min_tiles": only launches of at least this many
+ *                  patches use them (default 400: smaller ones are latency-bound and lose more to the extra load than they gain)
  *   "prep_fused": non-zero (default) = the per-launch preparation runs as 4 kernels (masks of both kinds in one, the
  *                  schedule's histogram + sort in one); zero = the 7 separate kernels of round 2 (same results)
  *   "sched_min_tiles": launches of at least this many patches start their dearest patches first (default 2048)

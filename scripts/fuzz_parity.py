@@ -67,6 +67,7 @@ def main():
     bad = 0
     t0 = time.time()
     with Context(0) as ctx:
+        ctx.set_option("hidden_min_tiles", 0)  # (the last-segment masks on grids this small too)
         for case in range(n_cases):
             walls, tx, X, Y, kw, allowed = random_case(rng, big=big and case % 2 == 1)
             ctx.set_scene(walls)

@@ -27,6 +27,7 @@ def _ctx(**opts):
     from differt2d_amd.engine import Context
 
     c = Context(0)
+    c.set_option("hidden_min_tiles", 0)  # (the default leaves launches below 400 patches without masks: these grids are small)
     for k, v in opts.items():
         c.set_option(k, v)
     return c
