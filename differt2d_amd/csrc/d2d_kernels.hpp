@@ -2017,8 +2017,17 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
             const int* col = reinterpret_cast<const int*>(D2D_LATE_ARG(float*, heavy_list)) + hq2 * (long)heavy_cap_l * 64 + lane;
-            for (int i = 0; i < nmax; ++i)
-                if (i < n) acc = acc + __int_as_float(__hip_atomic_load(&col[i * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));  // scene.py:1909, in candidate order
+            // eight loads in flight, then their additions in candidate order (scene.py:1909): the finishing part is the critical
+            // path of a cut patch, and one load at a time is one L2 round trip per entry (an entry that does not exist loads
+            // entry 0 instead and adds +0.0, which never changes acc: acc is never -0.0)
+            for (int i0 = 0; i0 < nmax; i0 += 8) {
+                int v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    v[k] = __hip_atomic_load(&col[(i0 + k < n ? i0 + k : 0) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc = acc + (i0 + k < n ? __int_as_float(v[k]) : 0.0f);
+            }
             if (bad) acc = __builtin_nanf("");
             work += (unsigned)__hip_atomic_load(&heavy_cnt[(long)n_heavy_l * HEAVY_PARTS * 64 + hq2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
