@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("D2D_LIB") or os.path.join(CSRC, "libd2d.so")
 D2D_MAX_ORDER = 4
 D2D_NUM_STATS = 16
 D2D_COMM_ID_BYTES = 128
-D2D_ABI_VERSION = 6
+D2D_ABI_VERSION = 7
 
 D2D_WALL, D2D_RIS, D2D_VERTEX = 0, 1, 2
 SOLVER_IMAGE, SOLVER_MINPATH, SOLVER_FERMAT = 0, 1, 2
@@ -114,6 +114,7 @@ SYMBOLS = [
                                          np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.c_int64]),
     ("d2d_debug_get_work", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS"), C.c_int64]),
     ("d2d_debug_region_stats", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]),
+    ("d2d_debug_nan_scan", C.c_int, [_ctx, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]),
     ("d2d_last_kernel_ms", C.c_int, [_ctx, C.POINTER(C.c_float)]),
     ("d2d_power_map_wave_cycles", C.c_int, [_ctx, C.POINTER(Params), _f32p, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS"),
                                             C.c_int64, C.POINTER(C.c_int64)]),

@@ -208,6 +208,10 @@ struct d2d_ctx {
     bool vjp_has_phi = false;  // d_vjp[4N+2 .. 5N+2) holds d/d phi (optimiser-based sweeps); image sweeps: identically 0
     bool vjp_reduced = false;  // d_vjp has been all-reduced over ranks: it is a global sum, nothing local may be added to it
     bool have_grad = false;  // d_grad holds the per-cell gradient map of a sweep of the CURRENT grid (2 m n values)
+    // NaN scan behind the culled value+grad sweeps (d2d_nanscan.hpp): the reference's autodiff NaN positions, all of them
+    bool nan_scan = true;               // "nan_scan" option (0: round 3's behaviour -- only the evaluated candidates' NaN; A/B and tests)
+    bool nan_scan_stats = false;        // "nan_scan_stats" option: count probes / flagged cells / flagged patches (d2d_debug_nan_scan)
+    DevBuf<unsigned long long> d_nan_stats;
     bool want_wave_cycles = false;
     long long split_max_tiles = -1;     // launches up to this many patches share every patch between 4 waves (-1: by the validity mode)
     long long coop_max_tiles = -1;      // ... and up to this many candidate by candidate (power_fwd_coop_kernel); -1: by the validity mode
@@ -1544,6 +1548,21 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         } else {
             HIP_TRY(d2d::launch_vg(mode, txg, true, grid, lds, c->stream, a));
         }
+        if (!p->strict_nan && (!txg || txg_culled) && c->nan_scan && p->max_order >= 1 && !c->cw.empty()) {
+            // The culled sweep has written the gradients of the candidates it evaluated; the reference's autodiff NaN positions
+            // -- an exact zero in the backward scan of ANY candidate, valid or not -- come from a pass of their own
+            // (d2d_nanscan.hpp), which poisons the cells and the patches' rows of VJP partial sums the way the exhaustive
+            // kernel (strict_nan) would have written them.
+            const size_t lds_n = (size_t)(3 * c->N) * sizeof(float4) + (size_t)c->N * sizeof(int) + 16;
+            if (lds_n > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the NaN scan's LDS table", c->N);
+            unsigned long long* ns = nullptr;
+            if (c->nan_scan_stats) {
+                if ((rc = c->d_nan_stats.ensure(4))) return rc;
+                HIP_TRY(hipMemsetAsync(c->d_nan_stats.p, 0, 4 * sizeof(unsigned long long), c->stream));
+                ns = c->d_nan_stats.p;
+            }
+            HIP_TRY(d2d::launch_nan_scan(p->approx != 0, txg, p->max_order, grid_patches, lds_n, c->stream, a, ns));
+        }
         D2D_KERNEL_DONE();
         if (grad_mode == 2) {
             const long rows = (long)tiles;  // one row of partials per patch
@@ -1784,6 +1803,8 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
         c->fwd_waves = value;
     }
     else if (!strcmp(name, "pair_masks")) c->use_pair_masks = value != 0;
+    else if (!strcmp(name, "nan_scan")) c->nan_scan = value != 0;
+    else if (!strcmp(name, "nan_scan_stats")) c->nan_scan_stats = value != 0;
     else if (!strcmp(name, "prep_fused")) c->prep_fused = value != 0;
     else if (!strcmp(name, "opt_parallel")) c->opt_parallel = value != 0;
     else if (!strcmp(name, "opt_grad_mode")) {
@@ -1846,6 +1867,19 @@ int d2d_debug_get_work(d2d_ctx* c, uint32_t* work, int64_t n) {
     if (!c->d_cost.p || c->cost_tiles != n) return fail(D2D_ERR_STATE, "no work history of %lld patches", (long long)n);
     HIP_TRY(hipMemcpyAsync(work, c->d_cost.p, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return D2D_OK;
+}
+
+int d2d_debug_nan_scan(d2d_ctx* c, int64_t* out) {
+    if (!c || !out) return fail(D2D_ERR_INVALID, "NULL argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    out[0] = out[1] = out[2] = 0;
+    if (!c->d_nan_stats.p) return D2D_OK;
+    unsigned long long h[4];
+    HIP_TRY(hipMemcpyAsync(h, c->d_nan_stats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; ++i) out[i] = (int64_t)h[i];
     return D2D_OK;
 }
 

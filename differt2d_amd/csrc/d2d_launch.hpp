@@ -32,4 +32,8 @@ hipError_t launch_region_lists(int K, bool grad, bool txg, dim3 grid, size_t lds
 hipError_t launch_region_refine(int K, bool grad, bool txg, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a, const RegionLevel& lv,
                                 const RegionLevel& parent, const ListPool& lp, int* flag);
 
+// nan_scan_kernel<APPROX, TXG, MAXK> (d2d_nanscan.hpp): the reference's autodiff NaN positions, behind a culled value+grad sweep
+hipError_t launch_nan_scan(bool approx, bool txg, int max_order, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a,
+                           unsigned long long* stats);
+
 }  // namespace d2d

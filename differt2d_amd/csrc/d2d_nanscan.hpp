@@ -1,0 +1,408 @@
+// NaN scan of the value+grad sweeps: where does the reference's reverse-mode autodiff return NaN?
+//
+// jax.grad through ImagePath.from_tx_objects_rx yields NaN for a (cell, candidate) pair in exactly two situations, whether
+// or not the candidate is valid for the cell (DESIGN.md "NaN parity"):
+//   (1) un == 0 in some step of the backward scan: jnp.where(un == 0, 0, vn * u / un) sends a zero cotangent through the
+//       untaken division by zero, 0 * inf = NaN (differt2d/geometry.py:1105);
+//   (2) approx modes only: a zero-length segment of the path inside the differentiated loss, normalize()'s sqrt'(0) * 0
+//       (differt2d/geometry.py:227-228, 647-648); in hard mode the loss only feeds a boolean.
+// Both depend on the image chain and the backward scan of the candidate alone -- not on its wall loop (> 95 % of a
+// candidate's work) -- and both are exact-zero events of fp32 expressions whose real-number zero sets are LINES in the
+// cell's plane.  The culled value+grad sweep never evaluates the candidates that the tile culling proves invalid, so it
+// cannot see their NaN; this pass finds them all:
+//   * lanes = candidates: a conservative test against the patch's bounding box, "can any of the zero events happen for any
+//     cell of the box?" (nan_possible_*), with explicit rounding margins -- a line crosses ~1.5 % of the 8 x 8 patches of a
+//     1024^2 grid;
+//   * lanes = cells, for the survivors: the backward scan itself, operation for operation what eval_candidate<GRAD> and the
+//     exhaustive power_vg_kernel compute (nan_probe), and the flags they would raise;
+//   * flagged cells get a NaN gradient, the patch's row of scene-VJP partial sums a NaN for the fixed end point and for the
+//     walls of the flagged candidates -- what power_vg_kernel (d2d_params.strict_nan) writes, position for position.
+// Launched behind the culled value+grad sweep, in front of the VJP reduction.
+#pragma once
+#include "d2d_kernels.hpp"
+
+namespace d2d {
+
+// The backward scan of eval_candidate<K, MODE, STATS, GRAD = true> (geometry.py:1093-1110), same operations, same order.
+// (txx, txy): px[0]; (rxx, rxy): px[K + 1] where the scan starts; img: the image chain of px[0].
+template <int K, bool APPROX>
+__device__ __forceinline__ bool nan_probe(const SweepArgs& a, const int (&cand)[D2D_MAX_ORDER], const float (&imgx)[D2D_MAX_ORDER],
+                                          const float (&imgy)[D2D_MAX_ORDER], float txx, float txy, float rxx, float rxy) {
+    float px[K + 2], py[K + 2];
+    px[0] = txx;
+    py[0] = txy;
+    px[K + 1] = rxx;
+    py[K + 1] = rxy;
+    bool znan = false;
+    float ptx = rxx, pty = rxy;
+#pragma unroll
+    for (int i = K - 1; i >= 0; --i) {
+        const float4 r0 = ldc4(a.refl, 2 * cand[i]);
+        float ux = ptx - imgx[i], uy = pty - imgy[i];
+        float vx = r0.x - ptx, vy = r0.y - pty;
+        float un = ux * r0.z + uy * r0.w;
+        float vn = vx * r0.z + vy * r0.w;
+        bool z = (un == 0.0f);
+        float den = z ? 1.0f : un;
+        float incx, incy;
+        div2_exact(vn * ux, vn * uy, den, incx, incy);
+        incx = z ? 0.0f : incx;
+        incy = z ? 0.0f : incy;
+        ptx = ptx + incx;
+        pty = pty + incy;
+        px[i + 1] = ptx;
+        py[i + 1] = pty;
+        znan = znan || z;
+    }
+    if (APPROX) {
+#pragma unroll
+        for (int i = 0; i <= K; ++i) znan = znan || (px[i + 1] == px[i] && py[i + 1] == py[i]);
+    }
+    return znan;
+}
+
+__device__ __forceinline__ float4 wallc_r0(const WallC& w) { return make_float4(w.ox, w.oy, w.nx, w.ny); }
+
+// Thin quad around the part [sa, sb] of wall w's line that an fp32 interaction point may occupy (as cull_candidate builds
+// it, without clipping to the wall: a NaN does not care whether the point is on the wall)
+__device__ __forceinline__ void nan_quad(const WallC& w, float sa, float sb, float E, float (&qx)[4], float (&qy)[4]) {
+    const float eps = 1.1920929e-07f;
+    const float d = 64.0f * eps * 2.0f * E;  // the fp32 point may sit this far off the wall's line
+    const float eax = __builtin_fmaf(sa, w.tx, w.ox), eay = __builtin_fmaf(sa, w.ty, w.oy);
+    const float ebx = __builtin_fmaf(sb, w.tx, w.ox), eby = __builtin_fmaf(sb, w.ty, w.oy);
+    const float ddx = d * w.nx, ddy = d * w.ny;
+    const float tl = fabsf(w.tx) + fabsf(w.ty);
+    const float px_ = d * w.tx * w.rsq * tl + 4.0f * eps * (fabsf(sa) + fabsf(sb)) * fabsf(w.tx);
+    const float py_ = d * w.ty * w.rsq * tl + 4.0f * eps * (fabsf(sa) + fabsf(sb)) * fabsf(w.ty);
+    qx[0] = eax - px_ + ddx; qy[0] = eay - py_ + ddy;
+    qx[1] = eax - px_ - ddx; qy[1] = eay - py_ - ddy;
+    qx[2] = ebx + px_ + ddx; qy[2] = eby + py_ + ddy;
+    qx[3] = ebx + px_ - ddx; qy[3] = eby + py_ - ddy;
+}
+
+// RX grids.  Candidate (w[0] .. w[K-1]) with the transmitter's image chain (Ix, Iy); (bx, by): corners of the cells' box.
+// true = some cell of the box MAY raise a flag in nan_probe; false = certainly none does.
+// Level lvl (from the cell inwards) knows a convex region Q that contains the fp32 point the scan step of wall lvl starts
+// from (the box, then thin quads around the previous wall's line): un = (q - I).n and vn = (o - q).n are affine in q, so a
+// common sign at the 4 vertices with a margin above the expressions' rounding holds throughout Q; un != 0 there also makes
+// the step's point a linear-fractional function of q without a pole in Q, whose range over Q the vertices span.
+template <int K, bool APPROX>
+__device__ __forceinline__ bool nan_possible_rx(const float (&bx)[4], const float (&by)[4], const WallC (&w)[K], const float (&Ix)[K],
+                                                const float (&Iy)[K], float fx, float fy) {
+    const float eps = 1.1920929e-07f;
+    float qx[4], qy[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        qx[j] = bx[j];
+        qy[j] = by[j];
+    }
+#pragma unroll
+    for (int lvl = K - 1; lvl >= 0; --lvl) {
+        const WallC& wl = w[lvl];
+        bool pos = true, neg = true, vpos = true, vneg = true, fin = true;
+        float smin = __builtin_inff(), smax = -__builtin_inff(), E = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ux = qx[j] - Ix[lvl], uy = qy[j] - Iy[lvl];
+            const float vx = wl.ox - qx[j], vy = wl.oy - qy[j];
+            const float un = __builtin_fmaf(ux, wl.nx, uy * wl.ny);
+            const float vn = __builtin_fmaf(vx, wl.nx, vy * wl.ny);
+            const float du = 16.0f * eps * __builtin_fmaf(fabsf(wl.nx), fabsf(qx[j]) + fabsf(Ix[lvl]), fabsf(wl.ny) * (fabsf(qy[j]) + fabsf(Iy[lvl])));
+            pos = pos && (un > du);
+            neg = neg && (un < -du);
+            if (APPROX) {
+                // the step's point differs from q by inc = vn u / un, |inc|_inf >= |vn| / sqrt 2: above a few ulps of q's
+                // coordinates the sum cannot round back to q
+                const float dv = 32.0f * eps * ((fabsf(qx[j]) + fabsf(qy[j])) + (fabsf(wl.ox) + fabsf(wl.oy)));
+                vpos = vpos && (vn > dv);
+                vneg = vneg && (vn < -dv);
+            }
+            const float g = vn * __builtin_amdgcn_rcpf(un);
+            const float dx = __builtin_fmaf(g, ux, -vx), dy = __builtin_fmaf(g, uy, -vy);
+            const float s = __builtin_fmaf(wl.ty, dy, wl.tx * dx) * wl.rsq;
+            const float mag = __builtin_fmaf(fabsf(g), fabsf(ux) + fabsf(uy), fabsf(vx) + fabsf(vy));
+            fin = fin && (mag < 1e18f);
+            smin = fminf(smin, s);
+            smax = fmaxf(smax, s);
+            E = fmaxf(E, mag);
+        }
+        if (!((pos || neg) && fin)) return true;
+        if (APPROX && !(vpos || vneg)) return true;
+        E = E + (fabsf(wl.ox) + fabsf(wl.oy)) + (fabsf(Ix[lvl]) + fabsf(Iy[lvl]));
+        const float M = __builtin_fmaf(64.0f * eps * wl.rsq * (fabsf(wl.tx) + fabsf(wl.ty)), 2.0f * E, 1e-30f);
+        if (!(E < 1e18f) || !(fabsf(smin) < 1e18f) || !(fabsf(smax) < 1e18f)) return true;
+        if (lvl == 0) {
+            if (APPROX) {
+                // first segment: the fixed end point on (the fp32 neighbourhood of) the first wall's line?
+                const float fn = __builtin_fmaf(fx - wl.ox, wl.nx, (fy - wl.oy) * wl.ny);
+                const float df = 64.0f * eps * 2.0f * E + 32.0f * eps * ((fabsf(fx) + fabsf(fy)) + (fabsf(wl.ox) + fabsf(wl.oy)));
+                if (!(fabsf(fn) > 2.0f * df)) return true;
+            }
+            break;
+        }
+        nan_quad(wl, smin - M, smax + M, E, qx, qy);
+    }
+    return false;
+}
+
+// TX grids (scene.py:1489-1648): the cells are transmitters -- the image chain is the CELL's (per lane in the exact chain),
+// the scan starts from the fixed receiver F.  Over a box of cells the images J_lvl(c) fill the parallelogram of the
+// corners' images (reflections are affine), the scan's point a region P (F itself, then thin quads), and the two are
+// bounded independently: un = pt.n - J.n is a difference of two affine functions, each spanned by its 4 vertices; the
+// step's point is linear-fractional in pt for fixed J and in J for fixed pt, pole-free once un cannot vanish, so its range
+// over P x J(box) is spanned by the 16 vertex pairs.  Looser than the RX-grid test (pt and c are treated as unrelated), never wrong.
+template <int K, bool APPROX>
+__device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const float (&cy)[4], const WallC (&w)[K], float fx, float fy) {
+    const float eps = 1.1920929e-07f;
+    float Jx[K][4], Jy[K][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float x = cx[v], y = cy[v];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            image_of(wallc_r0(w[i]), x, y, Jx[i][v], Jy[i][v]);
+            x = Jx[i][v];
+            y = Jy[i][v];
+        }
+    }
+    float Px[4], Py[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        Px[j] = fx;
+        Py[j] = fy;
+    }
+#pragma unroll
+    for (int lvl = K - 1; lvl >= 0; --lvl) {
+        const WallC& wl = w[lvl];
+        float amin = __builtin_inff(), amax = -__builtin_inff(), bmin = __builtin_inff(), bmax = -__builtin_inff();
+        float magP = 0.0f, magJ = 0.0f;
+        bool vpos = true, vneg = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pa = __builtin_fmaf(Px[j], wl.nx, Py[j] * wl.ny), jb = __builtin_fmaf(Jx[lvl][j], wl.nx, Jy[lvl][j] * wl.ny);
+            amin = fminf(amin, pa);
+            amax = fmaxf(amax, pa);
+            bmin = fminf(bmin, jb);
+            bmax = fmaxf(bmax, jb);
+            magP = fmaxf(magP, fabsf(Px[j]) + fabsf(Py[j]));
+            magJ = fmaxf(magJ, fabsf(Jx[lvl][j]) + fabsf(Jy[lvl][j]));
+            if (APPROX) {
+                const float vn = __builtin_fmaf(wl.ox - Px[j], wl.nx, (wl.oy - Py[j]) * wl.ny);
+                const float dv = 32.0f * eps * ((fabsf(Px[j]) + fabsf(Py[j])) + (fabsf(wl.ox) + fabsf(wl.oy)));
+                vpos = vpos && (vn > dv);
+                vneg = vneg && (vn < -dv);
+            }
+        }
+        if (!(magP < 1e18f) || !(magJ < 1e18f)) return true;
+        // (the cell's own fp32 images sit within a few ulps per reflection of the corners' hull: inside this margin)
+        const float du = 64.0f * eps * (fabsf(wl.nx) + fabsf(wl.ny)) * (magP + magJ);
+        if (!((amin - bmax > du) || (amax - bmin < -du))) return true;
+        if (APPROX && !(vpos || vneg)) return true;
+        bool fin = true;
+        float smin = __builtin_inff(), smax = -__builtin_inff(), E = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float vx = wl.ox - Px[j], vy = wl.oy - Py[j];
+            const float vn = __builtin_fmaf(vx, wl.nx, vy * wl.ny);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float ux = Px[j] - Jx[lvl][v], uy = Py[j] - Jy[lvl][v];
+                const float un = __builtin_fmaf(ux, wl.nx, uy * wl.ny);
+                const float g = vn * __builtin_amdgcn_rcpf(un);
+                const float dx = __builtin_fmaf(g, ux, -vx), dy = __builtin_fmaf(g, uy, -vy);
+                const float s = __builtin_fmaf(wl.ty, dy, wl.tx * dx) * wl.rsq;
+                const float mag = __builtin_fmaf(fabsf(g), fabsf(ux) + fabsf(uy), fabsf(vx) + fabsf(vy));
+                fin = fin && (mag < 1e18f);
+                smin = fminf(smin, s);
+                smax = fmaxf(smax, s);
+                E = fmaxf(E, mag);
+            }
+        }
+        if (!fin) return true;
+        E = E + (fabsf(wl.ox) + fabsf(wl.oy)) + magJ + magP;
+        const float M = __builtin_fmaf(256.0f * eps * wl.rsq * (fabsf(wl.tx) + fabsf(wl.ty)), 2.0f * E, 1e-30f);
+        if (!(E < 1e18f) || !(fabsf(smin) < 1e18f) || !(fabsf(smax) < 1e18f)) return true;
+        if (lvl == 0) {
+            if (APPROX) {
+                // first segment cell -> first wall: a cell on (the fp32 neighbourhood of) the wall's line?
+                bool cpos = true, cneg = true;
+                const float dq = 64.0f * eps * 2.0f * E;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float cn = __builtin_fmaf(cx[v] - wl.ox, wl.nx, (cy[v] - wl.oy) * wl.ny);
+                    const float dc = 2.0f * (dq + 32.0f * eps * ((fabsf(cx[v]) + fabsf(cy[v])) + (fabsf(wl.ox) + fabsf(wl.oy))));
+                    cpos = cpos && (cn > dc);
+                    cneg = cneg && (cn < -dc);
+                }
+                if (!(cpos || cneg)) return true;
+            }
+            break;
+        }
+        nan_quad(wl, smin - M, smax + M, E, Px, Py);
+    }
+    return false;
+}
+
+// One wave per 8 x 8 patch.  Prefix (w_0 .. w_{K-2}) wave-uniform, lanes = last wall (the odometer of sweep_order_culled
+// without any skip: a NaN does not care about shadows), conservative test per lane, exact probe of the survivors with
+// lanes = cells.  Order of the candidates is irrelevant here: the flags are OR-ed.
+//   flags[0]: a cell of this lane raised a flag; wallnan (LDS, [N]): walls of flagged candidates.
+template <int K, bool APPROX, bool TXG>
+__device__ __forceinline__ void nan_scan_order(const SweepArgs& a, const float4* tab, int* wallnan, const float (&bx)[4], const float (&by)[4],
+                                               float cx, float cy, bool force, bool& cell_nan, bool& any_nan, unsigned long long& n_probe) {
+    static_assert(K >= 1, "order 0 has no scan");
+    const int lane = threadIdx.x & 63;
+    const int Nc = a.Nc;
+    if (Nc < 1 || (K >= 2 && Nc < 2)) return;
+    const int n_chunks = (Nc + 63) >> 6;
+    int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+    float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];
+    int pos[D2D_MAX_ORDER] = {0, 0, 0, 0};
+#pragma unroll
+    for (int d = 1; d < K - 1; ++d) pos[d] = (pos[d - 1] == 0) ? 1 : 0;  // no equal neighbours
+    while (true) {
+        WallC wu[K];  // [0, K-1): the prefix' walls (wave-uniform)
+#pragma unroll
+        for (int d = 0; d < K - 1; ++d) {
+            cand[d] = cmem(a.cw)[pos[d]];
+            const float4 r0 = ldc4(a.refl, 2 * cand[d]);
+            wu[d] = make_wallc(r0, ldc4(a.refl, 2 * cand[d] + 1), ldc4(a.flt, cand[d]), cand[d]);
+            // RX grids: the transmitter's images (the exact chain's own, geometry.py:1086-1091); TX grids: per cell, below
+            if (!TXG) image_of(r0, d == 0 ? a.txx : imgx[d > 0 ? d - 1 : 0], d == 0 ? a.txy : imgy[d > 0 ? d - 1 : 0], imgx[d], imgy[d]);
+        }
+        const float pIx = (K == 1) ? a.txx : imgx[K >= 2 ? K - 2 : 0];
+        const float pIy = (K == 1) ? a.txy : imgy[K >= 2 ? K - 2 : 0];
+        const int last_prefix_pos = (K == 1) ? -1 : pos[K >= 2 ? K - 2 : 0];
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            const int lp = chunk * 64 + lane;
+            bool alive = (lp < Nc) && (lp != last_prefix_pos);
+            if (!force) {
+                const int wl = cmem(a.cw)[lp < Nc ? lp : 0];
+                const float4 r0 = tab[2 * wl], r1 = tab[2 * wl + 1], fc = tab[2 * a.N + wl];
+                WallC w[K];
+#pragma unroll
+                for (int d = 0; d < K - 1; ++d) w[d] = wu[d];
+                w[K - 1] = make_wallc(r0, r1, fc, wl);
+                if constexpr (TXG) {
+                    if (alive) alive = nan_possible_txg<K, APPROX>(bx, by, w, a.txx, a.txy);
+                } else {
+                    float Ix[K], Iy[K];
+#pragma unroll
+                    for (int d = 0; d < K - 1; ++d) {
+                        Ix[d] = imgx[d];
+                        Iy[d] = imgy[d];
+                    }
+                    image_of(r0, pIx, pIy, Ix[K - 1], Iy[K - 1]);
+                    if (alive) alive = nan_possible_rx<K, APPROX>(bx, by, w, Ix, Iy, a.txx, a.txy);
+                }
+            }
+            unsigned long long mask = __ballot(alive);
+            n_probe += (unsigned long long)__builtin_popcountll(mask);
+            while (mask) {
+                const int b = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                cand[K - 1] = cmem(a.cw)[chunk * 64 + b];
+                bool z;
+                if constexpr (TXG) {
+                    // images of the lane's cell (eval_candidate<TXG>: sweep_order_culled_txg builds them the same way)
+                    float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
+#pragma unroll
+                    for (int d = 0; d < K; ++d)
+                        image_of(ldc4(a.refl, 2 * cand[d]), d == 0 ? cx : ex[d > 0 ? d - 1 : 0], d == 0 ? cy : ey[d > 0 ? d - 1 : 0], ex[d], ey[d]);
+                    z = nan_probe<K, APPROX>(a, cand, ex, ey, cx, cy, a.txx, a.txy);
+                } else {
+                    image_of(ldc4(a.refl, 2 * cand[K - 1]), pIx, pIy, imgx[K - 1], imgy[K - 1]);
+                    z = nan_probe<K, APPROX>(a, cand, imgx, imgy, a.txx, a.txy, cx, cy);
+                }
+                cell_nan = cell_nan || z;
+                if (wave_any(z)) {
+                    any_nan = true;
+                    if (lane == 0) {
+#pragma unroll
+                        for (int d = 0; d < K; ++d) wallnan[cand[d]] = 1;
+                    }
+                }
+            }
+        }
+        if (K == 1) break;
+        bool carry = true;
+        int stop = -1;
+#pragma unroll
+        for (int d = K - 2; d >= 0; --d) {
+            if (carry) {
+                pos[d] += 1;
+                if (d > 0 && pos[d] == pos[d - 1]) pos[d] += 1;
+                if (pos[d] < Nc) {
+                    carry = false;
+                    stop = d;
+                }
+            }
+        }
+        if (carry) break;
+#pragma unroll
+        for (int e = 1; e < K - 1; ++e)
+            if (e > stop) pos[e] = (pos[e - 1] == 0) ? 1 : 0;
+    }
+}
+
+// a.grad: [m][n][2] the culled sweep's per-cell gradient; a.partial: its per-patch rows of the scene VJP, or null.
+// stats (may be null): [0] (patch, candidate) pairs probed, [1] flagged cells, [2] patches with a flag.
+template <bool APPROX, bool TXG, int MAXK>
+__global__ void __launch_bounds__(64) nan_scan_kernel(SweepArgs a, unsigned long long* __restrict__ stats) {
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then [N] int flags
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < 2 * a.N; i += 64) tab[i] = ldc4(a.refl, i);
+    for (int i = lane; i < a.N; i += 64) tab[2 * a.N + i] = ldc4(a.flt, i);
+    int* wallnan = reinterpret_cast<int*>(tab + 3 * a.N);
+    for (int i = lane; i < a.N; i += 64) wallnan[i] = 0;
+    __syncthreads();
+    const int tiles_x = (a.n + TILE_W - 1) / TILE_W;
+    const long tile = blockIdx.x;
+    const int tcol = (int)(tile % tiles_x), trow = (int)(tile / tiles_x);
+    const int col = tcol * TILE_W + (lane & (TILE_W - 1));
+    const int row = trow * TILE_H + (lane / TILE_W);
+    const bool in_range = (col < a.n) && (row < a.m);
+    const int ccol = col < a.n ? col : a.n - 1;
+    const int crow = row < a.m ? row : a.m - 1;
+    const long idx = (long)crow * a.n + ccol;
+    const float cx = a.X[idx], cy = a.Y[idx];
+    const bool lane_bad = !(fabsf(cx) < 1e18f) || !(fabsf(cy) < 1e18f) || !(fabsf(a.txx) < 1e18f) || !(fabsf(a.txy) < 1e18f);
+    float x0 = cx, x1 = cx, y0 = cy, y1 = cy;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, off, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
+        y0 = fminf(y0, __shfl_xor(y0, off, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+    }
+    const float bx[4] = {x0, x1, x1, x0};
+    const float by[4] = {y0, y0, y1, y1};
+    // a coordinate that is not comfortably finite: no bound holds, every candidate is probed
+    const bool force = wave_any(lane_bad);
+    bool cell_nan = false, any_nan = false;
+    unsigned long long n_probe = 0ull;
+    if (a.min_order <= 1 && a.max_order >= 1) nan_scan_order<1, APPROX, TXG>(a, tab, wallnan, bx, by, cx, cy, force, cell_nan, any_nan, n_probe);
+    if (a.min_order <= 2 && a.max_order >= 2) nan_scan_order<2, APPROX, TXG>(a, tab, wallnan, bx, by, cx, cy, force, cell_nan, any_nan, n_probe);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) nan_scan_order<3, APPROX, TXG>(a, tab, wallnan, bx, by, cx, cy, force, cell_nan, any_nan, n_probe);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) nan_scan_order<4, APPROX, TXG>(a, tab, wallnan, bx, by, cx, cy, force, cell_nan, any_nan, n_probe);
+    const float qnan = __builtin_nanf("");
+    if (cell_nan && in_range) {
+        a.grad[2 * idx] = qnan;
+        a.grad[2 * idx + 1] = qnan;
+    }
+    if (any_nan && a.partial != nullptr) {
+        __syncthreads();
+        float* dst = a.partial + tile * (4 * a.N + 2);  // the patch's row (fwd_patch / txg_patch / power_vg_kernel)
+        for (int i = lane; i < a.N; i += 64)
+            if (wallnan[i]) dst[4 * i] = dst[4 * i + 1] = dst[4 * i + 2] = dst[4 * i + 3] = qnan;
+        if (lane == 0) dst[4 * a.N] = dst[4 * a.N + 1] = qnan;
+    }
+    const unsigned long long flagged = __ballot(cell_nan && in_range);
+    if (stats && lane == 0) {
+        atomicAdd(&stats[0], n_probe);
+        atomicAdd(&stats[1], (unsigned long long)__builtin_popcountll(flagged));
+        if (any_nan) atomicAdd(&stats[2], 1ull);
+    }
+}
+
+}  // namespace d2d

@@ -1,8 +1,11 @@
 // One translation unit per (kernel family, validity mode): instantiates the sweep kernels of that pair and defines the
 // per-mode launcher that d2d_launch.cpp's dispatchers call.  Compiled several times by the Makefile with
 //   -DD2D_TU_FAMILY={0 fwd, 1 fwd_grad, 2 fwd_split, 3 txg, 4 vg, 5 region lists (mode 0 only), 9 fwd_coop,
-//   6 fwd / 7 fwd_grad / 8 fwd_split with the orders >= 2 taken from the region lists (LISTED)}  -DD2D_TU_MODE={0 hard, 1 hard_sigmoid, 2 sigmoid}
+//   6 fwd / 7 fwd_grad / 8 fwd_split with the orders >= 2 taken from the region lists (LISTED), 10 NaN scan (mode 0 only)}  -DD2D_TU_MODE={0 hard, 1 hard_sigmoid, 2 sigmoid}
 #include "d2d_launch.hpp"
+#if D2D_TU_FAMILY == 10
+#include "d2d_nanscan.hpp"
+#endif
 
 #ifndef D2D_TU_FAMILY
 #error "compile with -DD2D_TU_FAMILY=<0..4> -DD2D_TU_MODE=<0..2>"
@@ -196,6 +199,26 @@ hipError_t launch_region_refine(int K, bool grad, bool txg, dim3 grid, size_t ld
     }
 #undef D2D_RR_K
 #undef D2D_RR
+    return hipGetLastError();
+}
+#elif D2D_TU_FAMILY == 10
+// nan_scan_kernel<APPROX, TXG, MAXK>: depends on hard / approx only (compiled once, -DD2D_TU_MODE=0)
+hipError_t launch_nan_scan(bool approx, bool txg, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a, unsigned long long* stats) {
+    const dim3 block(64);
+#define D2D_NS(A, T)                                                                                         \
+    do {                                                                                                     \
+        if (max_order <= 2) hipLaunchKernelGGL((nan_scan_kernel<A, T, 2>), grid, block, lds, s, a, stats);   \
+        else if (max_order == 3) hipLaunchKernelGGL((nan_scan_kernel<A, T, 3>), grid, block, lds, s, a, stats); \
+        else hipLaunchKernelGGL((nan_scan_kernel<A, T, 4>), grid, block, lds, s, a, stats);                  \
+    } while (0)
+    if (approx) {
+        if (txg) D2D_NS(true, true);
+        else D2D_NS(true, false);
+    } else {
+        if (txg) D2D_NS(false, true);
+        else D2D_NS(false, false);
+    }
+#undef D2D_NS
     return hipGetLastError();
 }
 #else

@@ -282,6 +282,12 @@ class Context:
         return {"pool_chunks_used": int(o[0]), "pool_chunks": int(o[1]), "patches_enumerated": int(o[2]), "regions_not_listed": int(o[3]),
                 "leaf_entries": {2: int(o[4]), 3: int(o[5]), 4: int(o[6])}, "leaf_regions": int(o[7])}
 
+    def debug_nan_scan(self) -> dict:
+        """Diagnostic: counters of the last value+grad launch's NaN scan (needs ``set_option("nan_scan_stats", 1)``)."""
+        o = np.zeros(3, np.int64)
+        L.check(self._lib.d2d_debug_nan_scan(self._ctx, o))
+        return {"probes": int(o[0]), "nan_cells": int(o[1]), "nan_patches": int(o[2])}
+
     def last_kernel_ms(self) -> float:
         """Duration of the sweep kernel of the last launch (needs ``set_option("time_kernel", 1)``)."""
         ms = C.c_float(0.0)

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define D2D_MAX_ORDER 4 /* highest interaction order a sweep accepts */
-#define D2D_ABI_VERSION 6
+#define D2D_ABI_VERSION 7
 
 typedef enum d2d_status {
     D2D_OK = 0,
@@ -86,11 +86,13 @@ typedef struct d2d_params {
                            D2D_GRID_TX: the grid cells are transmitters and the `tx` argument of the launch is the
                            fixed RECEIVER (accumulate_on_transmitters_grid_over_paths, differt2d/scene.py:1489-1648);
                            the per-cell gradient is then taken w.r.t. the transmitter (scene.py:1617-1620) */
-    int32_t strict_nan; /* value+grad sweeps only. 0 (default): candidates that tile culling proves invalid are not
-                           evaluated; gradients are finite wherever the reference's are, and NaN where the reference's
-                           autodiff NaN artefacts come from an evaluated candidate or from a cell lying on a wall's
-                           supporting line. 1: every candidate of every cell is evaluated (about 4x slower) so that NaN
-                           positions coincide with the reference's in all cases (DESIGN.md "NaN parity") */
+    int32_t strict_nan; /* value+grad sweeps only.  The reference's reverse-mode autodiff returns NaN for a cell whenever the
+                           backward scan of ANY candidate -- valid or not -- hits un == 0 (differt2d/geometry.py:1105) or, in
+                           the approx modes, a zero-length segment (normalize, :227-228).  0 (default): candidates that tile
+                           culling proves invalid are not evaluated; a separate NaN scan (conservative test per 8 x 8 patch and
+                           candidate, then the backward scan itself for the few survivors) finds every such cell and poisons
+                           the gradient map and the scene VJP exactly as the exhaustive evaluation does.  1: every candidate of
+                           every cell is evaluated in full (about 40x slower; the cross-check the tests hold 0 against) */
     int32_t many;       /* differt2d/optimize.py:142: random starts per candidate of MinPath / FermatPath, best recorded loss
                            wins (0 or 1 = one start; the path classes default to 1, differt2d/geometry.py:1198, 1282) */
     int32_t reserved[1];
@@ -293,6 +295,9 @@ int d2d_debug_get_schedule(d2d_ctx* ctx, int32_t* order, uint8_t* key, int64_t n
  * [1] pool chunks available, [2] patches left to the enumerating kernel, [3] leaf regions with a list that is not listed,
  * [4] / [5] / [6] entries of the leaf lists of order 2 / 3 / 4, [7] leaf regions.  Waits for the stream. */
 int d2d_debug_region_stats(d2d_ctx* ctx, int64_t* out /* [8] */);
+/* Counters of the last value+grad launch's NaN scan (option "nan_scan_stats" = 1; zeros otherwise): out[0] (patch, candidate)
+ * pairs whose backward scan was probed cell by cell, [1] cells flagged NaN, [2] patches with a flagged cell.  Waits for the stream. */
+int d2d_debug_nan_scan(d2d_ctx* ctx, int64_t* out /* [3] */);
 
 /* The work history behind the schedule: what each of the n patches took in the last culled sweep (units of ~25
  * wave-instructions, counted by the kernels). */
