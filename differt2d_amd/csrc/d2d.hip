@@ -210,6 +210,7 @@ struct d2d_ctx {
     bool have_grad = false;  // d_grad holds the per-cell gradient map of a sweep of the CURRENT grid (2 m n values)
     // NaN scan behind the culled value+grad sweeps (d2d_nanscan.hpp): the reference's autodiff NaN positions, all of them
     bool nan_scan = true;               // "nan_scan" option (0: round 3's behaviour -- only the evaluated candidates' NaN; A/B and tests)
+    long long nan_scan_mode = 1;        // ... 1: two levels (regions of 4 x 4 patches, then patches), 2: one wave per patch (A/B and tests; same flags)
     bool nan_scan_stats = false;        // "nan_scan_stats" option: count probes / flagged cells / flagged patches (d2d_debug_nan_scan)
     DevBuf<unsigned long long> d_nan_stats;
     bool want_wave_cycles = false;
@@ -1305,7 +1306,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             // last-segment masks: which bins of which wall are hidden from a whole leaf region (forward RX-grid sweeps)
             // (launches of a few hundred patches are latency-bound: one more dependent load per culling step costs them more than
             // the masks save -- 64^2 cells: 0.085 -> 0.097 ms with them, 128^2 0.072 -> 0.076, 200^2 equal, 300^2 0.091 -> 0.086)
-            if ((!txg || txg_culled) && !grad_mode && m_masks_ok && a.shadow && c->use_hidden_masks && tiles >= c->hidden_min_tiles && std::isfinite(c->scene_absmax) && std::isfinite(c->grid_absmax) &&
+            if ((!txg || txg_culled) && m_masks_ok && a.shadow && c->use_hidden_masks && tiles >= c->hidden_min_tiles && std::isfinite(c->scene_absmax) && std::isfinite(c->grid_absmax) &&
                 (size_t)rp.leaf.regions * (size_t)c->N <= ((size_t)1 << 28)) {
                 const float hdperp = 4096.0f * 1.1920929e-07f * std::fmax(c->scene_absmax, c->grid_absmax) * (float)(D2D_MAX_ORDER + 1);
                 const double key[12] = {(double)c->grid_version, (double)rp.leaf.R, (double)c->m, (double)c->n, (double)p->patch, (double)p->seg_tol,
@@ -1362,8 +1363,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             al.fb_n = nullptr;
             al.cullq_off = (int)((size_t)(3 * c->N + 1) * sizeof(float4));
             for (int k = rp.k_lo; k <= p->max_order; ++k) {
-                HIP_TRY(d2d::launch_region_lists(k, grad_mode != 0, txg, dim3((unsigned)rp.top.slots), lds_l, ps, al, top, rl.lp));
-                HIP_TRY(d2d::launch_region_refine(k, grad_mode != 0, txg, dim3((unsigned)rp.leaf.regions), lds_r, ps, al, rl.leaf, top, rl.lp, rl.flag));
+                HIP_TRY(d2d::launch_region_lists(k, false, txg, dim3((unsigned)rp.top.slots), lds_l, ps, al, top, rl.lp));
+                HIP_TRY(d2d::launch_region_refine(k, false, txg, dim3((unsigned)rp.leaf.regions), lds_r, ps, al, rl.leaf, top, rl.lp, rl.flag));
             }
             a.rl = c->d_rl.p;
             c->rl_plan = rp;
@@ -1548,12 +1549,18 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         } else {
             HIP_TRY(d2d::launch_vg(mode, txg, true, grid, lds, c->stream, a));
         }
-        if (!p->strict_nan && (!txg || txg_culled) && c->nan_scan && p->max_order >= 1 && !c->cw.empty()) {
+        // (hard validity with fun = 1: nothing is differentiated through the path; order 0 alone: only path_length's own trap)
+        if (!p->strict_nan && (!txg || txg_culled) && c->nan_scan && (p->approx || p->fun_id != D2D_FUN_ONE) &&
+            ((p->max_order >= 1 && !c->cw.empty()) || (p->min_order <= 0 && p->fun_id != D2D_FUN_ONE))) {
             // The culled sweep has written the gradients of the candidates it evaluated; the reference's autodiff NaN positions
             // -- an exact zero in the backward scan of ANY candidate, valid or not -- come from a pass of their own
             // (d2d_nanscan.hpp), which poisons the cells and the patches' rows of VJP partial sums the way the exhaustive
             // kernel (strict_nan) would have written them.
-            const size_t lds_n = (size_t)(3 * c->N) * sizeof(float4) + (size_t)c->N * sizeof(int) + 16;
+            // two levels (a workgroup of 16 waves per region of 4 x 4 patches) when the region's list fits beside the tables
+            const size_t lds_r = (size_t)(3 * c->N) * sizeof(float4) + (size_t)d2d::NAN_LCAP * sizeof(unsigned long long) +
+                                 (size_t)d2d::NAN_W * (size_t)((c->N + 31) / 32) * sizeof(unsigned) + 16;
+            const bool regions = c->nan_scan_mode != 2 && lds_r + 512 <= d2d_host::LDS_LIMIT && c->N <= 4095;
+            const size_t lds_n = regions ? lds_r : (size_t)(3 * c->N) * sizeof(float4) + (size_t)c->N * sizeof(int) + 16;
             if (lds_n > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the NaN scan's LDS table", c->N);
             unsigned long long* ns = nullptr;
             if (c->nan_scan_stats) {
@@ -1561,7 +1568,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
                 HIP_TRY(hipMemsetAsync(c->d_nan_stats.p, 0, 4 * sizeof(unsigned long long), c->stream));
                 ns = c->d_nan_stats.p;
             }
-            HIP_TRY(d2d::launch_nan_scan(p->approx != 0, txg, p->max_order, grid_patches, lds_n, c->stream, a, ns));
+            const dim3 grid_regions((unsigned)(((tiles_x + d2d::NAN_R - 1) / d2d::NAN_R) * ((tiles_y + d2d::NAN_RY - 1) / d2d::NAN_RY)));
+            HIP_TRY(d2d::launch_nan_scan(p->approx != 0, txg, p->max_order, regions, regions ? grid_regions : grid_patches, lds_n, c->stream, a, ns));
         }
         D2D_KERNEL_DONE();
         if (grad_mode == 2) {
@@ -1803,7 +1811,11 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
         c->fwd_waves = value;
     }
     else if (!strcmp(name, "pair_masks")) c->use_pair_masks = value != 0;
-    else if (!strcmp(name, "nan_scan")) c->nan_scan = value != 0;
+    else if (!strcmp(name, "nan_scan")) {
+        if (value < 0 || value > 2) return fail(D2D_ERR_INVALID, "nan_scan must be 0 (off), 1 (two levels) or 2 (one wave per patch), got %lld", (long long)value);
+        c->nan_scan = value != 0;
+        if (value) c->nan_scan_mode = value;
+    }
     else if (!strcmp(name, "nan_scan_stats")) c->nan_scan_stats = value != 0;
     else if (!strcmp(name, "prep_fused")) c->prep_fused = value != 0;
     else if (!strcmp(name, "opt_parallel")) c->opt_parallel = value != 0;

@@ -438,7 +438,9 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             py[i + 1] = pty;
             // jnp.where(un == 0, 0, vn*u/un): reverse mode sends a zero cotangent through the untaken
             // division by zero -> 0/0 = NaN (geometry.py:1105)
-            if (GRAD) znan = znan || z;
+            // (hard validity is a bool: the contribution is differentiated through `fun` alone, and fun = 1 ignores the path --
+            // nothing then reaches the division, the gradient is simply 0)
+            if (GRAD && (MODE != MODE_HARD || a.fun_id != D2D_FUN_ONE)) znan = znan || z;
             if (!GRAD) {
                 // This wall's parametric coordinate (on_objects, geometry.py:589-621) right away: a candidate whose point
                 // is exactly off this wall in every lane is invalid whatever its other walls say, and most candidates
@@ -467,6 +469,14 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         // (geometry.py:227-228, 647-648); in hard mode the loss only feeds a boolean and is not differentiated
 #pragma unroll
         for (int i = 0; i <= K; ++i) znan = znan || (px[i + 1] == px[i] && py[i + 1] == py[i]);
+    }
+    if (GRAD && a.fun_id != D2D_FUN_ONE) {
+        // path_length's guard fails where it is needed: a segment vector of exactly (-eps, -eps) becomes (0, 0) once eps is
+        // added to both components (geometry.py:199-200), and jnp.linalg.norm's derivative at 0 is 0 / 0 -- NaN whatever
+        // cotangent reaches it, a valid candidate's or an invalid one's zero (every path function but the constant one
+        // goes through the length)
+#pragma unroll
+        for (int i = 0; i <= K; ++i) znan = znan || (((px[i + 1] - px[i]) + D2D_EPS == 0.0f) && ((py[i + 1] - py[i]) + D2D_EPS == 0.0f));
     }
     if (GRAD && wave_any(znan)) {
         const float qnan = __builtin_nanf("");
@@ -1342,7 +1352,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
     if (Nc < 1) return;
     // Forward builds: the first walls that are not wholly in the fixed end point's shadow, as a bit mask over positions;
     // the odometer steps from set bit to set bit (a shadowed first wall costs nothing at all).
-    const bool use_fmask = (K >= 2) && !GRAD && Nc <= 256 && a.shadow && a.shadow_prefix_ok;
+    const bool use_fmask = (K >= 2) && Nc <= 256 && a.shadow && a.shadow_prefix_ok;
     unsigned long long fmask[4] = {0ull, 0ull, 0ull, 0ull};
     if (use_fmask) {
 #pragma unroll
@@ -1396,8 +1406,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 iy = Iy[d];
             }
             const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[w[0].idx] : 0ull;
-            const bool bypass = GRAD && ((code >> 60) & 1ull);
-            if (alive2 && !bypass && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi)) alive2 = false;
+            if (alive2 && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi)) alive2 = false;
         }
         unsigned long long mask = __ballot(alive2);
         if (STATS) st.c[9] += K;
@@ -1437,7 +1446,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
     // mutually invisible with it bin for bin) as a bit mask over positions, one 64-lane test per chunk when the first wall
     // changes; the odometer then steps from set bit to set bit instead of visiting all N-1 second walls one by one (two
     // dependent scalar loads each).  Positions beyond 256 walls fall back to plain stepping.
-    const bool use_amask = (K == 3) && !GRAD && Nc <= 256 && a.pair && a.pair_prefix_ok;
+    const bool use_amask = (K == 3) && Nc <= 256 && a.pair && a.pair_prefix_ok;
     unsigned long long amask[4] = {0ull, 0ull, 0ull, 0ull};
     int amask_for = -1;
     auto next_alive = [&](int from) -> int {
@@ -1480,27 +1489,22 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
         // the fixed end point: no candidate starting with it can be valid.  (A valid candidate has un != 0 in every step:
         // un == 0 leaves a zero-length segment, i.e. loss >= 1, which the host checks to be exactly invalid for the
         // current tol / alpha (shadow_prefix_ok); so its first point does lie on the wall's line within rounding.)
-        // Not in the value+grad build: the reference's un == 0 autodiff NaN must still be found in every candidate that
-        // the per-candidate tests (which guarantee un != 0) cannot drop.
-                // The value+grad build does not skip the prefix outright: where a cell sits exactly on the pole of the LAST
-        // reflection (un == 0 in the first step of the backward scan, geometry.py:1105), the reference's autodiff returns
-        // NaN whether or not the candidate is valid.  A dead prefix therefore keeps the candidates whose last-wall pole
-        // may cross the patch (a cheap test, few survivors) and evaluates those exactly.  NaN artefacts that only arise
-        // deeper in a dead prefix's chain are not reproduced (d2d_params.strict_nan is the exhaustive kernel).
+        // (The value+grad build skips it too: the reference's autodiff NaN artefacts, which do not care about validity, are
+        // found by a pass of their own, d2d_nanscan.hpp.)
         bool prefix_dead = (K >= 2) && a.shadow && a.shadow_prefix_ok && (cmem(a.shadow)[cand[0]] == ~0ull);
-        if (K >= 3 && !GRAD && prefix_dead) {
+        if (K >= 3 && prefix_dead) {
             // the FIRST wall is dead: so are all (N-1)^(K-2) prefixes that start with it -- leave the inner positions at
             // their end so that the odometer below moves straight on to the next first wall
 #pragma unroll
             for (int d = 1; d < K - 1; ++d) pos[d] = Nc;
         }
-        if (K >= 3 && !GRAD && a.pair && a.pair_prefix_ok) {
+        if (K >= 3 && a.pair && a.pair_prefix_ok) {
             // two consecutive walls of the prefix whose windows are mutually invisible bin for bin: whatever follows,
             // the segment between them is occluded (or one of its ends is off its wall)
 #pragma unroll
             for (int d = 0; d + 1 < K - 1; ++d) prefix_dead = prefix_dead || (cmem(a.pair)[(size_t)cand[d] * a.N + cand[d + 1]] == ~0ull);
         }
-        for (int chunk = 0; chunk < ((prefix_dead && !GRAD) ? 0 : n_chunks); ++chunk) {
+        for (int chunk = 0; chunk < (prefix_dead ? 0 : n_chunks); ++chunk) {
             // ---- lanes = candidates: lane l <-> last wall = cw[chunk * 64 + l]
             const int lp = chunk * 64 + lane;
             bool alive = (lp < Nc) && (lp != last_prefix_pos);
@@ -1510,11 +1514,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 const WallC wlast = make_wallc(r0, r1, fc, wl);
                 float lx, ly;
                 image_of(r0, pIx, pIy, lx, ly);
-                if (GRAD && prefix_dead) {
-                    // value+grad build, first wall wholly in shadow: keep only the candidates whose last-wall pole may
-                    // cross the patch; they bypass stage 2 (nothing may cull them) and are evaluated exactly
-                    alive = alive && pole_possible(bx, by, lx, ly, wlast.nx, wlast.ny);
-                } else if (alive) {
+                if (alive) {
                     float smin, smax, M, E;
                     const bool ok = s_range(bx, by, lx, ly, wlast, smin, smax, M, E);
                     if (ok && (smax + M < a.on_lo || smin - M > a.on_hi)) alive = false;
@@ -1525,7 +1525,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 D2D_WORK(5);
                 if (qn + cnt > 64) flush();
                 if (alive) {
-                    unsigned long long code = ((unsigned long long)wl << (12 * (K - 1))) | ((GRAD && prefix_dead) ? (1ull << 60) : 0ull);
+                    unsigned long long code = (unsigned long long)wl << (12 * (K - 1));
 #pragma unroll
                     for (int d = 0; d < K - 1; ++d) code |= (unsigned long long)cand[d] << (12 * d);
                     cullq[qn + __builtin_popcountll(m1 & ((1ull << lane) - 1ull))] = code;
@@ -1549,10 +1549,9 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 }
                 unsigned long long sh0 = 0ull;
                 if (a.shadow) sh0 = cmem(a.shadow)[(K == 1) ? wl : cand[0]];
-                if (GRAD && prefix_dead) alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
-                else if (alive) {
+                if (alive) {
                     // (order 1: the region's last-segment mask of the lane's wall, hidden_region_kernel)
-                    const unsigned long long hk = (K == 1 && !GRAD && hidden_row && a.shadow) ? hidden_row[wl] : 0ull;
+                    const unsigned long long hk = (K == 1 && hidden_row && a.shadow) ? hidden_row[wl] : 0ull;
                     if (cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi, hk, hidden_dperp)) alive = false;
                 }
             }
@@ -1664,7 +1663,7 @@ __device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, con
         }
         if (alive) {
             const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[w[0].idx] : 0ull;
-            const unsigned long long hk = (!GRAD && hidden_row && a.shadow) ? hidden_row[w[K - 1].idx] : 0ull;  // (the wall next to the cell)
+            const unsigned long long hk = (hidden_row && a.shadow) ? hidden_row[w[K - 1].idx] : 0ull;  // (the wall next to the cell)
             if (cull_candidate<K, true>(bx, by, w, Ix, Iy, a, sh0, on_lo, on_hi, hk, hidden_dperp)) alive = false;
         }
         return __ballot(alive);
@@ -1678,12 +1677,9 @@ __device__ __forceinline__ unsigned long long cull_batch(const SweepArgs& a, con
         ix = Ix[d];
         iy = Iy[d];
     }
-    const bool bypass = GRAD && ((code >> 60) & 1ull);
-    if (bypass) {
-        alive = alive && pole_possible(bx, by, Ix[K - 1], Iy[K - 1], w[K - 1].nx, w[K - 1].ny);
-    } else if (alive) {
+    if (alive) {
         const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[w[0].idx] : 0ull;
-        const unsigned long long hk = (!GRAD && hidden_row && a.shadow) ? hidden_row[w[K - 1].idx] : 0ull;
+        const unsigned long long hk = (hidden_row && a.shadow) ? hidden_row[w[K - 1].idx] : 0ull;
         if (cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, on_lo, on_hi, hk, hidden_dperp)) alive = false;
     }
     return __ballot(alive);
@@ -1705,7 +1701,7 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
     const auto* pool = cmem(rlc->lp.pool);
     const auto* next = cmem(rlc->lp.next);
     // the region's last-segment masks once more, now with the bins this PATCH can reach (hidden_region_kernel)
-    const unsigned long long* hidden_row = (D2D_HIDDEN_PATCH && !GRAD && rlc->leaf.hidden) ? rlc->leaf.hidden + (size_t)region * a.N : nullptr;
+    const unsigned long long* hidden_row = (D2D_HIDDEN_PATCH && rlc->leaf.hidden) ? rlc->leaf.hidden + (size_t)region * a.N : nullptr;
     const float hidden_dperp = hidden_row ? rlc->leaf.hidden_dperp : 0.0f;
     int r_lo = 0, r_hi = 0x7fffffff;
     if (parts > 1) {
@@ -1824,6 +1820,16 @@ __device__ __forceinline__ long region_of(const SweepArgs& a, int tcol, int trow
 #define D2D_FENCE_FREE_HANDOVER 0
 #endif
 #endif
+// NaN scan of the value+grad sweeps (d2d_nanscan.hpp): waves per workgroup = patches per region (NAN_R x NAN_R), entries of the
+// region's list in LDS, batches tested per round (so that the list cannot overflow)
+#ifndef D2D_NAN_W
+#define D2D_NAN_W 16  // A/B: 8 = regions of 4 x 2 patches (twice the registers per lane, two workgroups per CU)
+#endif
+constexpr int NAN_W = D2D_NAN_W;
+constexpr int NAN_R = 4;            // patches per region along x; NAN_W / NAN_R along y
+constexpr int NAN_RY = NAN_W / NAN_R;
+constexpr int NAN_LCAP = 2048;
+constexpr int NAN_RB = NAN_LCAP / 64;
 constexpr int HEAVY_PARTS = D2D_HEAVY_PARTS;  // the dearest patches of a launch are cut into this many parts (power_fwd_kernel)
 constexpr int TILE_W = 8;  // a wave covers an 8 x 8 patch of RX cells: neighbouring cells share skips
 constexpr int TILE_H = 8;
@@ -1898,37 +1904,6 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
     g.cot = in_range ? (a.cot ? a.cot[idx] : 1.0f) : 0.0f;
     g.wl = wl;
     g.scene = scene;
-    if (GRADK && MODE != MODE_HARD && a.max_order >= 1) {
-        // A cell lying exactly on the supporting line of an allowed wall: every candidate ending on that wall has a
-        // zero-length last segment, and the reference's autodiff then returns NaN (sqrt'(0) * 0) whether or not the
-        // candidate is valid -- also for candidates the culling drops, hence this exhaustive (and cheap) check.
-        bool on_line = false;
-        bool poison_all = false;
-        const bool deep = a.max_order >= 2 && a.Nc >= 2;  // candidates (w0, .., w) exist for every other allowed w0
-        for (int i = 0; i < a.Nc; ++i) {
-            const float4 r0 = ldc4(a.refl, 2 * cmem(a.cw)[i]);
-            float vx = r0.x - rxx, vy = r0.y - rxy;
-            const bool here = (vx * r0.z + vy * r0.w) == 0.0f;
-            on_line = on_line || here;
-            if (scene && wave_any(here)) {
-                poison_all = poison_all || deep;
-                if (lane == 0) {
-                    float* w4 = wl + 4 * cmem(a.cw)[i];
-                    w4[0] = w4[1] = w4[2] = w4[3] = __builtin_nanf("");
-                }
-            }
-        }
-        if (wave_any(on_line)) {
-            const float qnan = __builtin_nanf("");
-            if (on_line) g.grx = g.gry = qnan;
-            if (scene && on_line) g.tbx = g.tby = qnan;
-            if (scene && poison_all && lane == 0)
-                for (int i = 0; i < a.Nc; ++i) {
-                    float* w4 = wl + 4 * cmem(a.cw)[i];
-                    w4[0] = w4[1] = w4[2] = w4[3] = qnan;
-                }
-        }
-    }
     // bounding box of the wave's cells (NaN / inf coordinates make every comparison fail: nothing is culled)
     float x0 = rxx, x1 = rxx, y0 = rxy, y1 = rxy;
 #pragma unroll
@@ -2038,7 +2013,7 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
     unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     if (STATS) st.c[11] += tq1 - tq0;      // order 0
     if (a.min_order <= 1 && a.max_order >= 1) {
-        const unsigned long long* hid = (LISTED && !GRADK) ? cmem(a.rl)->leaf.hidden : nullptr;
+        const unsigned long long* hid = LISTED ? cmem(a.rl)->leaf.hidden : nullptr;
         sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, 0, 0x7fffffff, nullptr, nullptr,
                                                   hid ? hid + (size_t)region * a.N : nullptr, hid ? cmem(a.rl)->leaf.hidden_dperp : 0.0f);
     }
@@ -2572,7 +2547,7 @@ __global__ void __launch_bounds__(64) region_refine_kernel(SweepArgs a, RegionLe
     const int rx = (int)(region % lv.regions_x), ry = (int)(region / lv.regions_x);
     float bx[4], by[4];
     bool ok = region_box(a, lv.box, region, bx, by);
-    const unsigned long long* hidden_row = (!GRAD && lv.hidden) ? lv.hidden + (size_t)region * a.N : nullptr;
+    const unsigned long long* hidden_row = lv.hidden ? lv.hidden + (size_t)region * a.N : nullptr;
     const int up = parent.R / lv.R;
     const long pslot0 = ((long)(ry / up) * parent.regions_x + (rx / up)) * parent.S;
     const int* pcnt = parent.cnt[K] + pslot0;
@@ -2682,7 +2657,7 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
         }
         const int last_prefix_pos = (K == 1) ? -1 : pos[K >= 2 ? K - 2 : 0];
         bool prefix_dead = false;
-        if (K >= 3 && !GRAD && a.pair && a.pair_prefix_ok) {
+        if (K >= 3 && a.pair && a.pair_prefix_ok) {
 #pragma unroll
             for (int d = 0; d + 1 < K - 1; ++d) prefix_dead = prefix_dead || (cmem(a.pair)[(size_t)cand[d] * a.N + cand[d + 1]] == ~0ull);
         }
@@ -2705,7 +2680,7 @@ __device__ __forceinline__ void sweep_order_culled_txg(const SweepArgs& a, const
                 }
                 const unsigned long long sh0 = a.shadow ? cmem(a.shadow)[wl] : 0ull;
                 // (order 1: the wall is also the one next to the cell -- the region's masks of the segment cell -> wall)
-                const unsigned long long hk = (K == 1 && !GRAD && hidden_row && a.shadow) ? hidden_row[wl] : 0ull;
+                const unsigned long long hk = (K == 1 && hidden_row && a.shadow) ? hidden_row[wl] : 0ull;
                 if (alive && cull_candidate<K, true>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi, hk, hidden_dperp)) alive = false;
             }
             unsigned long long mask = __ballot(alive);
@@ -2763,7 +2738,7 @@ __device__ __forceinline__ void sweep_order_listed_txg(const SweepArgs& a, const
         const unsigned long long code = pool[(size_t)chunk * RL_CHUNK + (off & (RL_CHUNK - 1)) + (have ? lane : 0)];
         if ((off & (RL_CHUNK - 1)) == RL_CHUNK - 64 && off + 64 < n) chunk = next[chunk];
         float Ix[K], Iy[K];
-        const unsigned long long* hid = (D2D_HIDDEN_PATCH && !GRAD) ? rlc->leaf.hidden : nullptr;
+        const unsigned long long* hid = D2D_HIDDEN_PATCH ? rlc->leaf.hidden : nullptr;
         unsigned long long mask = cull_batch<K, GRAD, true>(a, tab, bx, by, code, have, Ix, Iy, a.on_lo, a.on_hi, hid ? hid + (size_t)region * a.N : nullptr,
                                                             hid ? rlc->leaf.hidden_dperp : 0.0f);
         D2D_WORK(5 * K);
@@ -2843,7 +2818,7 @@ __device__ __forceinline__ void txg_patch(const SweepArgs& a, const float4* tab,
     const float by[4] = {y0, y0, y1, y1};
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, false, GRADK, true>(a, cx, cy, a.txx, a.txy, lane_bad, acc, st, &g);
     if (a.min_order <= 1 && a.max_order >= 1) {
-        const unsigned long long* hid = (LISTED && !GRADK) ? cmem(a.rl)->leaf.hidden : nullptr;
+        const unsigned long long* hid = LISTED ? cmem(a.rl)->leaf.hidden : nullptr;
         sweep_order_culled_txg<1, MODE, GRADK>(a, tab, bx, by, cx, cy, lane_bad, acc, st, &g, 0, 0x7fffffff, nullptr,
                                                hid ? hid + (size_t)region * a.N : nullptr, hid ? cmem(a.rl)->leaf.hidden_dperp : 0.0f);
     }

@@ -1,13 +1,15 @@
 // NaN scan of the value+grad sweeps: where does the reference's reverse-mode autodiff return NaN?
 //
-// jax.grad through ImagePath.from_tx_objects_rx yields NaN for a (cell, candidate) pair in exactly two situations, whether
+// jax.grad through ImagePath.from_tx_objects_rx yields NaN for a (cell, candidate) pair in three situations, whether
 // or not the candidate is valid for the cell (DESIGN.md "NaN parity"):
 //   (1) un == 0 in some step of the backward scan: jnp.where(un == 0, 0, vn * u / un) sends a zero cotangent through the
 //       untaken division by zero, 0 * inf = NaN (differt2d/geometry.py:1105);
 //   (2) approx modes only: a zero-length segment of the path inside the differentiated loss, normalize()'s sqrt'(0) * 0
-//       (differt2d/geometry.py:227-228, 647-648); in hard mode the loss only feeds a boolean.
-// Both depend on the image chain and the backward scan of the candidate alone -- not on its wall loop (> 95 % of a
-// candidate's work) -- and both are exact-zero events of fp32 expressions whose real-number zero sets are LINES in the
+//       (differt2d/geometry.py:227-228, 647-648); in hard mode the loss only feeds a boolean;
+//   (3) a segment vector of exactly (-eps, -eps): path_length adds eps to both components (geometry.py:199-200) and
+//       differentiates the norm of (0, 0) -- found by the C gradient oracle on lattice scenes (every path function but 1).
+// All depend on the image chain and the backward scan of the candidate alone -- not on its wall loop (> 95 % of a
+// candidate's work) -- and all are exact-zero events of fp32 expressions whose real-number zero sets are LINES in the
 // cell's plane.  The culled value+grad sweep never evaluates the candidates that the tile culling proves invalid, so it
 // cannot see their NaN; this pass finds them all:
 //   * lanes = candidates: a conservative test against the patch's bounding box, "can any of the zero events happen for any
@@ -28,6 +30,7 @@ namespace d2d {
 template <int K, bool APPROX>
 __device__ __forceinline__ bool nan_probe(const SweepArgs& a, const int (&cand)[D2D_MAX_ORDER], const float (&imgx)[D2D_MAX_ORDER],
                                           const float (&imgy)[D2D_MAX_ORDER], float txx, float txy, float rxx, float rxy) {
+    const bool plen = a.fun_id != D2D_FUN_ONE;  // the path function goes through path_length (rule 3 below)
     float px[K + 2], py[K + 2];
     px[0] = txx;
     py[0] = txy;
@@ -52,11 +55,17 @@ __device__ __forceinline__ bool nan_probe(const SweepArgs& a, const int (&cand)[
         pty = pty + incy;
         px[i + 1] = ptx;
         py[i + 1] = pty;
-        znan = znan || z;
+        // (hard validity with fun = 1: nothing is differentiated through the path)
+        if (APPROX || plen) znan = znan || z;
     }
     if (APPROX) {
 #pragma unroll
         for (int i = 0; i <= K; ++i) znan = znan || (px[i + 1] == px[i] && py[i + 1] == py[i]);
+    }
+    if (plen) {
+        // (3) path_length: a segment vector of exactly (-eps, -eps), geometry.py:199-200 (eval_candidate<GRAD> has the same lines)
+#pragma unroll
+        for (int i = 0; i <= K; ++i) znan = znan || (((px[i + 1] - px[i]) + D2D_EPS == 0.0f) && ((py[i + 1] - py[i]) + D2D_EPS == 0.0f));
     }
     return znan;
 }
@@ -86,10 +95,17 @@ __device__ __forceinline__ void nan_quad(const WallC& w, float sa, float sb, flo
 // from (the box, then thin quads around the previous wall's line): un = (q - I).n and vn = (o - q).n are affine in q, so a
 // common sign at the 4 vertices with a margin above the expressions' rounding holds throughout Q; un != 0 there also makes
 // the step's point a linear-fractional function of q without a pole in Q, whose range over Q the vertices span.
+// plen: the path function goes through path_length, whose own trap -- a segment vector of exactly (-eps, -eps), rule (3) --
+// needs two consecutive points within eps sqrt 2 of each other (an ABSOLUTE distance: NAN_ABS below) and, the step being
+// along u, u_x == u_y to rounding; in the approx modes rule (2)'s test (any near-coincidence) covers it, in hard mode the
+// direction condition keeps the survivors few.
+constexpr float NAN_ABS = 1e-6f;
 template <int K, bool APPROX>
 __device__ __forceinline__ bool nan_possible_rx(const float (&bx)[4], const float (&by)[4], const WallC (&w)[K], const float (&Ix)[K],
-                                                const float (&Iy)[K], float fx, float fy) {
+                                                const float (&Iy)[K], float fx, float fy, bool plen) {
     const float eps = 1.1920929e-07f;
+    const float abs3 = plen ? NAN_ABS : 0.0f;
+    const bool near_test = APPROX || plen;
     float qx[4], qy[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -99,7 +115,7 @@ __device__ __forceinline__ bool nan_possible_rx(const float (&bx)[4], const floa
 #pragma unroll
     for (int lvl = K - 1; lvl >= 0; --lvl) {
         const WallC& wl = w[lvl];
-        bool pos = true, neg = true, vpos = true, vneg = true, fin = true;
+        bool pos = true, neg = true, vpos = true, vneg = true, dpos = true, dneg = true, fin = true;
         float smin = __builtin_inff(), smax = -__builtin_inff(), E = 0.0f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -110,12 +126,23 @@ __device__ __forceinline__ bool nan_possible_rx(const float (&bx)[4], const floa
             const float du = 16.0f * eps * __builtin_fmaf(fabsf(wl.nx), fabsf(qx[j]) + fabsf(Ix[lvl]), fabsf(wl.ny) * (fabsf(qy[j]) + fabsf(Iy[lvl])));
             pos = pos && (un > du);
             neg = neg && (un < -du);
-            if (APPROX) {
+            if (near_test) {
                 // the step's point differs from q by inc = vn u / un, |inc|_inf >= |vn| / sqrt 2: above a few ulps of q's
-                // coordinates the sum cannot round back to q
-                const float dv = 32.0f * eps * ((fabsf(qx[j]) + fabsf(qy[j])) + (fabsf(wl.ox) + fabsf(wl.oy)));
+                // coordinates the sum cannot round back to q (nor, plen, stay within eps sqrt 2 of it)
+                const float mq = (fabsf(qx[j]) + fabsf(qy[j])) + (fabsf(wl.ox) + fabsf(wl.oy));
+                const float dv = 32.0f * eps * mq + abs3;
                 vpos = vpos && (vn > dv);
                 vneg = vneg && (vn < -dv);
+                if (!APPROX) {
+                    // rule (3): fl(pt + inc) - pt == (eps, eps) needs both components of inc = (vn / un) u within [eps / 2,
+                    // 3 eps / 2] (the sum is rounded to a grid no coarser than eps, else the rule cannot fire at all): u lies in
+                    // the double cone u_x u_y > 0, 1/3 <= u_x / u_y <= 3 -- bounded by f1 = u_y - u_x / 3.5, f2 = 3.5 u_x - u_y,
+                    // which have the same sign inside it and opposite signs throughout a region that avoids it
+                    const float f1 = uy - ux * (1.0f / 3.5f), f2 = 3.5f * ux - uy;
+                    const float dm = 64.0f * eps * ((fabsf(qx[j]) + fabsf(qy[j])) + (fabsf(Ix[lvl]) + fabsf(Iy[lvl])));
+                    dpos = dpos && (f1 > dm) && (f2 < -dm);
+                    dneg = dneg && (f1 < -dm) && (f2 > dm);
+                }
             }
             const float g = vn * __builtin_amdgcn_rcpf(un);
             const float dx = __builtin_fmaf(g, ux, -vx), dy = __builtin_fmaf(g, uy, -vy);
@@ -127,15 +154,15 @@ __device__ __forceinline__ bool nan_possible_rx(const float (&bx)[4], const floa
             E = fmaxf(E, mag);
         }
         if (!((pos || neg) && fin)) return true;
-        if (APPROX && !(vpos || vneg)) return true;
+        if (near_test && !(vpos || vneg) && (APPROX || !(dpos || dneg))) return true;
         E = E + (fabsf(wl.ox) + fabsf(wl.oy)) + (fabsf(Ix[lvl]) + fabsf(Iy[lvl]));
         const float M = __builtin_fmaf(64.0f * eps * wl.rsq * (fabsf(wl.tx) + fabsf(wl.ty)), 2.0f * E, 1e-30f);
         if (!(E < 1e18f) || !(fabsf(smin) < 1e18f) || !(fabsf(smax) < 1e18f)) return true;
         if (lvl == 0) {
-            if (APPROX) {
+            if (near_test) {
                 // first segment: the fixed end point on (the fp32 neighbourhood of) the first wall's line?
                 const float fn = __builtin_fmaf(fx - wl.ox, wl.nx, (fy - wl.oy) * wl.ny);
-                const float df = 64.0f * eps * 2.0f * E + 32.0f * eps * ((fabsf(fx) + fabsf(fy)) + (fabsf(wl.ox) + fabsf(wl.oy)));
+                const float df = 64.0f * eps * 2.0f * E + 32.0f * eps * ((fabsf(fx) + fabsf(fy)) + (fabsf(wl.ox) + fabsf(wl.oy))) + abs3;
                 if (!(fabsf(fn) > 2.0f * df)) return true;
             }
             break;
@@ -152,8 +179,10 @@ __device__ __forceinline__ bool nan_possible_rx(const float (&bx)[4], const floa
 // step's point is linear-fractional in pt for fixed J and in J for fixed pt, pole-free once un cannot vanish, so its range
 // over P x J(box) is spanned by the 16 vertex pairs.  Looser than the RX-grid test (pt and c are treated as unrelated), never wrong.
 template <int K, bool APPROX>
-__device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const float (&cy)[4], const WallC (&w)[K], float fx, float fy) {
+__device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const float (&cy)[4], const WallC (&w)[K], float fx, float fy, bool plen) {
     const float eps = 1.1920929e-07f;
+    const float abs3 = plen ? NAN_ABS : 0.0f;
+    const bool near_test = APPROX || plen;
     float Jx[K][4], Jy[K][4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -176,6 +205,8 @@ __device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const flo
         const WallC& wl = w[lvl];
         float amin = __builtin_inff(), amax = -__builtin_inff(), bmin = __builtin_inff(), bmax = -__builtin_inff();
         float magP = 0.0f, magJ = 0.0f;
+        float cmin = __builtin_inff(), cmax = -__builtin_inff(), emin = __builtin_inff(), emax = -__builtin_inff();
+        float c2min = __builtin_inff(), c2max = -__builtin_inff(), e2min = __builtin_inff(), e2max = -__builtin_inff();
         bool vpos = true, vneg = true;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -186,18 +217,33 @@ __device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const flo
             bmax = fmaxf(bmax, jb);
             magP = fmaxf(magP, fabsf(Px[j]) + fabsf(Py[j]));
             magJ = fmaxf(magJ, fabsf(Jx[lvl][j]) + fabsf(Jy[lvl][j]));
-            if (APPROX) {
+            if (near_test) {
                 const float vn = __builtin_fmaf(wl.ox - Px[j], wl.nx, (wl.oy - Py[j]) * wl.ny);
-                const float dv = 32.0f * eps * ((fabsf(Px[j]) + fabsf(Py[j])) + (fabsf(wl.ox) + fabsf(wl.oy)));
+                const float dv = 32.0f * eps * ((fabsf(Px[j]) + fabsf(Py[j])) + (fabsf(wl.ox) + fabsf(wl.oy))) + abs3;
                 vpos = vpos && (vn > dv);
                 vneg = vneg && (vn < -dv);
+                if (!APPROX) {
+                    // (rule (3)'s double cone, nan_possible_rx: f1 = u_y - u_x / 3.5 and f2 = 3.5 u_x - u_y with u = P - J, each a
+                    // difference of an affine function of P and one of J)
+                    const float p1 = Py[j] - Px[j] * (1.0f / 3.5f), p2 = 3.5f * Px[j] - Py[j];
+                    const float j1 = Jy[lvl][j] - Jx[lvl][j] * (1.0f / 3.5f), j2 = 3.5f * Jx[lvl][j] - Jy[lvl][j];
+                    cmin = fminf(cmin, p1); cmax = fmaxf(cmax, p1);
+                    emin = fminf(emin, j1); emax = fmaxf(emax, j1);
+                    c2min = fminf(c2min, p2); c2max = fmaxf(c2max, p2);
+                    e2min = fminf(e2min, j2); e2max = fmaxf(e2max, j2);
+                }
             }
         }
         if (!(magP < 1e18f) || !(magJ < 1e18f)) return true;
         // (the cell's own fp32 images sit within a few ulps per reflection of the corners' hull: inside this margin)
         const float du = 64.0f * eps * (fabsf(wl.nx) + fabsf(wl.ny)) * (magP + magJ);
         if (!((amin - bmax > du) || (amax - bmin < -du))) return true;
-        if (APPROX && !(vpos || vneg)) return true;
+        if (near_test && !(vpos || vneg)) {
+            if (APPROX) return true;
+            const float dm = 256.0f * eps * (magP + magJ);  // hard mode, rule (3): can u = P - J enter the double cone?
+            const float f1lo = cmin - emax, f1hi = cmax - emin, f2lo = c2min - e2max, f2hi = c2max - e2min;
+            if (!((f1lo > dm && f2hi < -dm) || (f1hi < -dm && f2lo > dm))) return true;
+        }
         bool fin = true;
         float smin = __builtin_inff(), smax = -__builtin_inff(), E = 0.0f;
 #pragma unroll
@@ -223,10 +269,10 @@ __device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const flo
         const float M = __builtin_fmaf(256.0f * eps * wl.rsq * (fabsf(wl.tx) + fabsf(wl.ty)), 2.0f * E, 1e-30f);
         if (!(E < 1e18f) || !(fabsf(smin) < 1e18f) || !(fabsf(smax) < 1e18f)) return true;
         if (lvl == 0) {
-            if (APPROX) {
+            if (near_test) {
                 // first segment cell -> first wall: a cell on (the fp32 neighbourhood of) the wall's line?
                 bool cpos = true, cneg = true;
-                const float dq = 64.0f * eps * 2.0f * E;
+                const float dq = 64.0f * eps * 2.0f * E + abs3;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const float cn = __builtin_fmaf(cx[v] - wl.ox, wl.nx, (cy[v] - wl.oy) * wl.ny);
@@ -252,6 +298,7 @@ __device__ __forceinline__ void nan_scan_order(const SweepArgs& a, const float4*
                                                float cx, float cy, bool force, bool& cell_nan, bool& any_nan, unsigned long long& n_probe) {
     static_assert(K >= 1, "order 0 has no scan");
     const int lane = threadIdx.x & 63;
+    const bool plen = a.fun_id != D2D_FUN_ONE;
     const int Nc = a.Nc;
     if (Nc < 1 || (K >= 2 && Nc < 2)) return;
     const int n_chunks = (Nc + 63) >> 6;
@@ -284,7 +331,7 @@ __device__ __forceinline__ void nan_scan_order(const SweepArgs& a, const float4*
                 for (int d = 0; d < K - 1; ++d) w[d] = wu[d];
                 w[K - 1] = make_wallc(r0, r1, fc, wl);
                 if constexpr (TXG) {
-                    if (alive) alive = nan_possible_txg<K, APPROX>(bx, by, w, a.txx, a.txy);
+                    if (alive) alive = nan_possible_txg<K, APPROX>(bx, by, w, a.txx, a.txy, plen);
                 } else {
                     float Ix[K], Iy[K];
 #pragma unroll
@@ -293,7 +340,7 @@ __device__ __forceinline__ void nan_scan_order(const SweepArgs& a, const float4*
                         Iy[d] = imgy[d];
                     }
                     image_of(r0, pIx, pIy, Ix[K - 1], Iy[K - 1]);
-                    if (alive) alive = nan_possible_rx<K, APPROX>(bx, by, w, Ix, Iy, a.txx, a.txy);
+                    if (alive) alive = nan_possible_rx<K, APPROX>(bx, by, w, Ix, Iy, a.txx, a.txy, plen);
                 }
             }
             unsigned long long mask = __ballot(alive);
@@ -381,6 +428,11 @@ __global__ void __launch_bounds__(64) nan_scan_kernel(SweepArgs a, unsigned long
     const bool force = wave_any(lane_bad);
     bool cell_nan = false, any_nan = false;
     unsigned long long n_probe = 0ull;
+    if (a.min_order <= 0 && a.max_order >= 0 && a.fun_id != D2D_FUN_ONE) {
+        // order 0 has no scan, but its one segment has rule (3): px[0] = transmitter, px[1] = receiver
+        cell_nan = TXG ? (((a.txx - cx) + D2D_EPS == 0.0f) && ((a.txy - cy) + D2D_EPS == 0.0f)) : (((cx - a.txx) + D2D_EPS == 0.0f) && ((cy - a.txy) + D2D_EPS == 0.0f));
+        any_nan = wave_any(cell_nan);
+    }
     if (a.min_order <= 1 && a.max_order >= 1) nan_scan_order<1, APPROX, TXG>(a, tab, wallnan, bx, by, cx, cy, force, cell_nan, any_nan, n_probe);
     if (a.min_order <= 2 && a.max_order >= 2) nan_scan_order<2, APPROX, TXG>(a, tab, wallnan, bx, by, cx, cy, force, cell_nan, any_nan, n_probe);
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) nan_scan_order<3, APPROX, TXG>(a, tab, wallnan, bx, by, cx, cy, force, cell_nan, any_nan, n_probe);
@@ -402,6 +454,282 @@ __global__ void __launch_bounds__(64) nan_scan_kernel(SweepArgs a, unsigned long
         atomicAdd(&stats[0], n_probe);
         atomicAdd(&stats[1], (unsigned long long)__builtin_popcountll(flagged));
         if (any_nan) atomicAdd(&stats[2], 1ull);
+    }
+}
+
+// ---- the same scan, two levels ------------------------------------------------------------------------------------------
+// One workgroup of NAN_W = 16 waves per region of 4 x 4 patches.  A zero line that crosses a 32 x 32-cell region is ~4 x as
+// likely as one that crosses an 8 x 8 patch, but the region-level test is shared by 16 patches: the batches of an order (prefix,
+// chunk of last walls) are dealt to the waves round-robin and tested against the REGION's box, the survivors go to a list in
+// LDS (unordered: the flags are OR-ed), and every wave then tests only that list against its own patch and probes what is left.
+// Rounds of NAN_LCAP / 64 batches: the list cannot overflow, whatever survives (non-finite coordinates: everything does).
+// (NAN_W, NAN_R, NAN_LCAP, NAN_RB: d2d_kernels.hpp)
+
+// batch `id` of order K: prefix positions (into cw[], no equal neighbours, lexicographic) and the chunk of last walls
+template <int K>
+__device__ __forceinline__ void nan_decode_batch(long long id, int Nc, int n_chunks, int (&pos)[D2D_MAX_ORDER], int& chunk) {
+    if (K == 1) {
+        chunk = (int)id;
+        return;
+    }
+    long long L;
+    if (id < 0x7fffffffLL) {
+        const unsigned u = (unsigned)id;
+        chunk = (int)(u % (unsigned)n_chunks);
+        L = (long long)(u / (unsigned)n_chunks);
+    } else {
+        chunk = (int)(id % n_chunks);
+        L = id / n_chunks;
+    }
+    int dig[D2D_MAX_ORDER] = {0, 0, 0, 0};
+#pragma unroll
+    for (int d = K - 2; d >= 1; --d) {
+        if (L < 0x7fffffffLL) {
+            const unsigned u = (unsigned)L;
+            dig[d] = (int)(u % (unsigned)(Nc - 1));
+            L = (long long)(u / (unsigned)(Nc - 1));
+        } else {
+            dig[d] = (int)(L % (Nc - 1));
+            L = L / (Nc - 1);
+        }
+    }
+    pos[0] = (int)L;
+#pragma unroll
+    for (int d = 1; d <= K - 2; ++d) pos[d] = dig[d] + (dig[d] >= pos[d - 1] ? 1 : 0);
+}
+
+template <int K, bool APPROX, bool TXG>
+__device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float4* tab, unsigned long long* list, int* lcount, unsigned* wallbits,
+                                                 const float (&rbx)[4], const float (&rby)[4], const float (&pbx)[4], const float (&pby)[4],
+                                                 float cx, float cy, bool force, bool patch_exists, bool& cell_nan, bool& any_nan,
+                                                 unsigned long long& n_probe, int& round) {
+    static_assert(K >= 1, "order 0 has no scan");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool plen = a.fun_id != D2D_FUN_ONE;
+    const int Nc = a.Nc;
+    if (Nc < 1 || (K >= 2 && Nc < 2)) return;  // (workgroup-uniform)
+    const int n_chunks = (Nc + 63) >> 6;
+    long long nb = n_chunks;
+    if (K >= 2) {
+        nb *= Nc;
+#pragma unroll
+        for (int d = 1; d <= K - 2; ++d) nb *= (Nc - 1);
+    }
+    for (long long r0 = 0; r0 < nb; r0 += NAN_RB, ++round) {  // (workgroup-uniform)
+        int* const cnt_p = lcount + (round & 1);
+        // ---- region level: batch r0 + t * NAN_W + wv
+#pragma unroll 1
+        for (int t = 0; t < NAN_RB / NAN_W; ++t) {
+            const long long id = r0 + (long long)t * NAN_W + wv;
+            if (id >= nb) break;
+            int pos[D2D_MAX_ORDER] = {0, 0, 0, 0};
+            int chunk = 0;
+            nan_decode_batch<K>(id, Nc, n_chunks, pos, chunk);
+            int cand[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+            float imgx[D2D_MAX_ORDER], imgy[D2D_MAX_ORDER];
+            WallC wu[K];
+#pragma unroll
+            for (int d = 0; d < K - 1; ++d) {
+                cand[d] = cmem(a.cw)[pos[d]];
+                const float4 r0_ = ldc4(a.refl, 2 * cand[d]);
+                wu[d] = make_wallc(r0_, ldc4(a.refl, 2 * cand[d] + 1), ldc4(a.flt, cand[d]), cand[d]);
+                if (!TXG) image_of(r0_, d == 0 ? a.txx : imgx[d > 0 ? d - 1 : 0], d == 0 ? a.txy : imgy[d > 0 ? d - 1 : 0], imgx[d], imgy[d]);
+            }
+            const float pIx = (K == 1) ? a.txx : imgx[K >= 2 ? K - 2 : 0];
+            const float pIy = (K == 1) ? a.txy : imgy[K >= 2 ? K - 2 : 0];
+            const int last_prefix_pos = (K == 1) ? -1 : pos[K >= 2 ? K - 2 : 0];
+            const int lp = chunk * 64 + lane;
+            bool alive = (lp < Nc) && (lp != last_prefix_pos);
+            const int wl = cmem(a.cw)[lp < Nc ? lp : 0];
+            if (!force) {
+                const float4 q0 = tab[2 * wl], q1 = tab[2 * wl + 1], fc = tab[2 * a.N + wl];
+                WallC w[K];
+#pragma unroll
+                for (int d = 0; d < K - 1; ++d) w[d] = wu[d];
+                w[K - 1] = make_wallc(q0, q1, fc, wl);
+                if constexpr (TXG) {
+                    if (alive) alive = nan_possible_txg<K, APPROX>(rbx, rby, w, a.txx, a.txy, plen);
+                } else {
+                    float Ix[K], Iy[K];
+#pragma unroll
+                    for (int d = 0; d < K - 1; ++d) {
+                        Ix[d] = imgx[d];
+                        Iy[d] = imgy[d];
+                    }
+                    image_of(q0, pIx, pIy, Ix[K - 1], Iy[K - 1]);
+                    if (alive) alive = nan_possible_rx<K, APPROX>(rbx, rby, w, Ix, Iy, a.txx, a.txy, plen);
+                }
+            }
+            const unsigned long long mask = __ballot(alive);
+            const int cnt = __builtin_popcountll(mask);
+            if (cnt) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(cnt_p, cnt);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (alive) {
+                    unsigned long long code = (unsigned long long)wl << (12 * (K - 1));
+#pragma unroll
+                    for (int d = 0; d < K - 1; ++d) code |= (unsigned long long)cand[d] << (12 * d);
+                    list[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = code;
+                }
+            }
+        }
+        __syncthreads();
+        const int n = *cnt_p;
+        if (threadIdx.x == 0) lcount[(round + 1) & 1] = 0;  // (the other counter: nobody uses it before the barrier below)
+        // ---- patch level: the region's survivors against this wave's own patch, then the cells
+        if (patch_exists) {
+            for (int off = 0; off < n; off += 64) {
+                const bool have = off + lane < n;
+                const unsigned long long code = list[have ? off + lane : off];
+                bool alive = have;
+                if (!force) {
+                    WallC w[K];
+                    float Ix[K], Iy[K];
+                    float ix = a.txx, iy = a.txy;
+#pragma unroll
+                    for (int d = 0; d < K; ++d) {
+                        const int wd = (int)((code >> (12 * d)) & 0xfffull);
+                        const float4 q0 = tab[2 * wd], q1 = tab[2 * wd + 1], fc = tab[2 * a.N + wd];
+                        w[d] = make_wallc(q0, q1, fc, wd);
+                        if (!TXG) {
+                            image_of(q0, ix, iy, Ix[d], Iy[d]);
+                            ix = Ix[d];
+                            iy = Iy[d];
+                        }
+                    }
+                    if constexpr (TXG) {
+                        if (alive) alive = nan_possible_txg<K, APPROX>(pbx, pby, w, a.txx, a.txy, plen);
+                    } else {
+                        if (alive) alive = nan_possible_rx<K, APPROX>(pbx, pby, w, Ix, Iy, a.txx, a.txy, plen);
+                    }
+                }
+                unsigned long long mask = __ballot(alive);
+                n_probe += (unsigned long long)__builtin_popcountll(mask);
+                while (mask) {
+                    const int b = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(code & 0xffffffffull), b);
+                    const unsigned hi32 = (K >= 3) ? (unsigned)__builtin_amdgcn_readlane((int)(code >> 32), b) : 0u;
+                    const unsigned long long cu = ((unsigned long long)hi32 << 32) | lo32;
+                    int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+                    float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
+#pragma unroll
+                    for (int d = 0; d < K; ++d) {
+                        ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
+                        // RX grids: the transmitter's image chain (wave-uniform); TX grids: the lane's cell's (geometry.py:1086-1091)
+                        image_of(ldc4(a.refl, 2 * ce[d]), d == 0 ? (TXG ? cx : a.txx) : ex[d > 0 ? d - 1 : 0], d == 0 ? (TXG ? cy : a.txy) : ey[d > 0 ? d - 1 : 0],
+                                 ex[d], ey[d]);
+                    }
+                    const bool z = TXG ? nan_probe<K, APPROX>(a, ce, ex, ey, cx, cy, a.txx, a.txy) : nan_probe<K, APPROX>(a, ce, ex, ey, a.txx, a.txy, cx, cy);
+                    cell_nan = cell_nan || z;
+                    if (wave_any(z)) {
+                        any_nan = true;
+                        if (lane == 0) {
+#pragma unroll
+                            for (int d = 0; d < K; ++d) wallbits[ce[d] >> 5] |= 1u << (ce[d] & 31);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the list is rewritten by the next round
+    }
+}
+
+template <bool APPROX, bool TXG, int MAXK>
+__global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a, unsigned long long* __restrict__ stats) {
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, the region's list [NAN_LCAP], then [NAN_W][ceil(N / 32)] flag bits
+    __shared__ float pbox[NAN_W][4];
+    __shared__ int lcount[2];
+    __shared__ int sbad;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * a.N; i += 64 * NAN_W) tab[i] = ldc4(a.refl, i);
+    for (int i = threadIdx.x; i < a.N; i += 64 * NAN_W) tab[2 * a.N + i] = ldc4(a.flt, i);
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(tab + 3 * a.N);
+    const int nwords = (a.N + 31) >> 5;
+    unsigned* wallbits_all = reinterpret_cast<unsigned*>(list + NAN_LCAP);
+    for (int i = threadIdx.x; i < NAN_W * nwords; i += 64 * NAN_W) wallbits_all[i] = 0u;
+    if (threadIdx.x == 0) {
+        lcount[0] = lcount[1] = 0;
+        sbad = 0;
+    }
+    __syncthreads();
+    unsigned* wallbits = wallbits_all + wv * nwords;
+    const int tiles_x = (a.n + TILE_W - 1) / TILE_W, tiles_y = (a.m + TILE_H - 1) / TILE_H;
+    const int regions_x = (tiles_x + NAN_R - 1) / NAN_R;
+    const int rx = (int)(blockIdx.x % regions_x), ry = (int)(blockIdx.x / regions_x);
+    const int tcol = rx * NAN_R + (wv & (NAN_R - 1)), trow = ry * NAN_RY + (wv / NAN_R);
+    const bool patch_exists = tcol < tiles_x && trow < tiles_y;
+    const long tile = (long)trow * tiles_x + tcol;
+    const int col = tcol * TILE_W + (lane & (TILE_W - 1));
+    const int row = trow * TILE_H + (lane / TILE_W);
+    const bool in_range = (col < a.n) && (row < a.m);
+    const int ccol = col < a.n ? col : a.n - 1;  // (a patch beyond the grid's edge repeats cells of this region's last column / row)
+    const int crow = row < a.m ? row : a.m - 1;
+    const long idx = (long)crow * a.n + ccol;
+    const float cx = a.X[idx], cy = a.Y[idx];
+    const bool lane_bad = !(fabsf(cx) < 1e18f) || !(fabsf(cy) < 1e18f) || !(fabsf(a.txx) < 1e18f) || !(fabsf(a.txy) < 1e18f);
+    float x0 = cx, x1 = cx, y0 = cy, y1 = cy;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, off, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, off, 64));
+        y0 = fminf(y0, __shfl_xor(y0, off, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+    }
+    const float pbx[4] = {x0, x1, x1, x0};
+    const float pby[4] = {y0, y0, y1, y1};
+    if (lane == 0) {
+        pbox[wv][0] = x0; pbox[wv][1] = x1; pbox[wv][2] = y0; pbox[wv][3] = y1;
+    }
+    if (wave_any(lane_bad) && lane == 0) atomicOr(&sbad, 1);
+    __syncthreads();
+    float r0 = pbox[lane & (NAN_W - 1)][0], r1 = pbox[lane & (NAN_W - 1)][1], r2 = pbox[lane & (NAN_W - 1)][2], r3 = pbox[lane & (NAN_W - 1)][3];
+#pragma unroll
+    for (int off = NAN_W / 2; off > 0; off >>= 1) {
+        r0 = fminf(r0, __shfl_xor(r0, off, 64));
+        r1 = fmaxf(r1, __shfl_xor(r1, off, 64));
+        r2 = fminf(r2, __shfl_xor(r2, off, 64));
+        r3 = fmaxf(r3, __shfl_xor(r3, off, 64));
+    }
+    const float rbx[4] = {r0, r1, r1, r0};
+    const float rby[4] = {r2, r2, r3, r3};
+    // a coordinate that is not comfortably finite anywhere in the region: no bound holds, every candidate is probed
+    const bool force = sbad != 0;
+    bool cell_nan = false, any_nan = false;
+    unsigned long long n_probe = 0ull;
+    int round = 0;
+    if (a.min_order <= 0 && a.max_order >= 0 && a.fun_id != D2D_FUN_ONE) {
+        // order 0 has no scan, but its one segment has rule (3): px[0] = transmitter, px[1] = receiver
+        cell_nan = TXG ? (((a.txx - cx) + D2D_EPS == 0.0f) && ((a.txy - cy) + D2D_EPS == 0.0f)) : (((cx - a.txx) + D2D_EPS == 0.0f) && ((cy - a.txy) + D2D_EPS == 0.0f));
+        any_nan = wave_any(cell_nan);
+    }
+    if (a.min_order <= 1 && a.max_order >= 1)
+        nan_region_order<1, APPROX, TXG>(a, tab, list, lcount, wallbits, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+    if (a.min_order <= 2 && a.max_order >= 2)
+        nan_region_order<2, APPROX, TXG>(a, tab, list, lcount, wallbits, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+    if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3)
+        nan_region_order<3, APPROX, TXG>(a, tab, list, lcount, wallbits, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+    if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4)
+        nan_region_order<4, APPROX, TXG>(a, tab, list, lcount, wallbits, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+    const float qnan = __builtin_nanf("");
+    if (cell_nan && in_range && patch_exists) {
+        a.grad[2 * idx] = qnan;
+        a.grad[2 * idx + 1] = qnan;
+    }
+    if (any_nan && patch_exists && a.partial != nullptr) {
+        __builtin_amdgcn_wave_barrier();
+        float* dst = a.partial + tile * (4 * a.N + 2);  // the patch's row (fwd_patch / txg_patch / power_vg_kernel)
+        for (int i = lane; i < a.N; i += 64)
+            if ((wallbits[i >> 5] >> (i & 31)) & 1u) dst[4 * i] = dst[4 * i + 1] = dst[4 * i + 2] = dst[4 * i + 3] = qnan;
+        if (lane == 0) dst[4 * a.N] = dst[4 * a.N + 1] = qnan;
+    }
+    const unsigned long long flagged = __ballot(cell_nan && in_range && patch_exists);
+    if (stats && lane == 0) {
+        atomicAdd(&stats[0], n_probe);
+        atomicAdd(&stats[1], (unsigned long long)__builtin_popcountll(flagged));
+        if (any_nan && patch_exists) atomicAdd(&stats[2], 1ull);
     }
 }
 

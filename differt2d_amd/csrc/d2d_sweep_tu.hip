@@ -169,13 +169,9 @@ hipError_t launch_region_lists(int K, bool grad, bool txg, dim3 grid, size_t lds
         else if (K == 3) D2D_RL(3, G, T); \
         else D2D_RL(4, G, T);             \
     } while (0)
-    if (txg) {
-        if (grad) D2D_RL_K(true, true);
-        else D2D_RL_K(false, true);
-    } else {
-        if (grad) D2D_RL_K(true, false);
-        else D2D_RL_K(false, false);
-    }
+    (void)grad;  // (the value+grad sweeps read the forward sweeps' lists: their NaN positions come from d2d_nanscan.hpp)
+    if (txg) D2D_RL_K(false, true);
+    else D2D_RL_K(false, false);
 #undef D2D_RL_K
 #undef D2D_RL
     return hipGetLastError();
@@ -190,34 +186,37 @@ hipError_t launch_region_refine(int K, bool grad, bool txg, dim3 grid, size_t ld
         else if (K == 3) D2D_RR(3, G, T); \
         else D2D_RR(4, G, T);             \
     } while (0)
-    if (txg) {
-        if (grad) D2D_RR_K(true, true);
-        else D2D_RR_K(false, true);
-    } else {
-        if (grad) D2D_RR_K(true, false);
-        else D2D_RR_K(false, false);
-    }
+    (void)grad;
+    if (txg) D2D_RR_K(false, true);
+    else D2D_RR_K(false, false);
 #undef D2D_RR_K
 #undef D2D_RR
     return hipGetLastError();
 }
 #elif D2D_TU_FAMILY == 10
 // nan_scan_kernel<APPROX, TXG, MAXK>: depends on hard / approx only (compiled once, -DD2D_TU_MODE=0)
-hipError_t launch_nan_scan(bool approx, bool txg, int max_order, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a, unsigned long long* stats) {
-    const dim3 block(64);
-#define D2D_NS(A, T)                                                                                         \
-    do {                                                                                                     \
-        if (max_order <= 2) hipLaunchKernelGGL((nan_scan_kernel<A, T, 2>), grid, block, lds, s, a, stats);   \
-        else if (max_order == 3) hipLaunchKernelGGL((nan_scan_kernel<A, T, 3>), grid, block, lds, s, a, stats); \
-        else hipLaunchKernelGGL((nan_scan_kernel<A, T, 4>), grid, block, lds, s, a, stats);                  \
+hipError_t launch_nan_scan(bool approx, bool txg, int max_order, bool regions, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a,
+                           unsigned long long* stats) {
+    const dim3 block(regions ? 64 * NAN_W : 64);
+#define D2D_NS(KERNEL, A, T)                                                                        \
+    do {                                                                                            \
+        if (max_order <= 2) hipLaunchKernelGGL((KERNEL<A, T, 2>), grid, block, lds, s, a, stats);    \
+        else if (max_order == 3) hipLaunchKernelGGL((KERNEL<A, T, 3>), grid, block, lds, s, a, stats); \
+        else hipLaunchKernelGGL((KERNEL<A, T, 4>), grid, block, lds, s, a, stats);                   \
     } while (0)
-    if (approx) {
-        if (txg) D2D_NS(true, true);
-        else D2D_NS(true, false);
-    } else {
-        if (txg) D2D_NS(false, true);
-        else D2D_NS(false, false);
-    }
+#define D2D_NS_AT(KERNEL)                    \
+    do {                                     \
+        if (approx) {                        \
+            if (txg) D2D_NS(KERNEL, true, true);   \
+            else D2D_NS(KERNEL, true, false);      \
+        } else {                             \
+            if (txg) D2D_NS(KERNEL, false, true);  \
+            else D2D_NS(KERNEL, false, false);     \
+        }                                    \
+    } while (0)
+    if (regions) D2D_NS_AT(nan_scan_region_kernel);
+    else D2D_NS_AT(nan_scan_kernel);
+#undef D2D_NS_AT
 #undef D2D_NS
     return hipGetLastError();
 }

@@ -42,8 +42,8 @@ ACT_IDS = {"hard_sigmoid": 0, "sigmoid": 1}
 
 def build(force: bool = False) -> str:
     """Compile the C oracle in place (gcc, a few hundred ms)."""
-    src = os.path.join(_HERE, "d2d_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("d2d_oracle.c", "d2d_oracle_grad.c", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(_LIB_PATH) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libd2d_oracle.so"])
     return _LIB_PATH
 
@@ -68,6 +68,9 @@ def lib():
         L.orc_eval_candidates.argtypes = [fp, C.c_int, C.c_void_p, C.POINTER(OrcParams), fp, fp, fp, fp,
                                           np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")]
         L.orc_max_threads.restype = C.c_int
+        L.orc_power_map_grad.restype = C.c_int
+        L.orc_power_map_grad.argtypes = [fp, C.c_int, C.c_void_p, C.POINTER(OrcParams), fp, fp, fp, C.c_long, fp,
+                                         np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -124,6 +127,42 @@ def power_and_count_maps(walls, tx, X, Y, allowed=None, nthreads=0, **kw):
     if rc != 0:
         raise RuntimeError(f"orc_power_map_ex failed: {rc}")
     return out, cnt
+
+
+def power_map_grad(walls, tx, X, Y, allowed=None, nthreads=0, with_gabs=False, with_kink=False, with_amp=False, **kw):
+    """Value map and per-cell gradient d facc / d cell (oracle/d2d_oracle_grad.c: forward-mode dual numbers through the C
+    oracle's op chain, the reference's two reverse-mode NaN traps stated as rules).  Returns (value[shape] float32,
+    grad[shape + (2,)] float64, NaN where the reference's autodiff yields NaN) and, with_gabs, the per-cell sum of the
+    candidates' |gradient contributions| (the magnitude an fp32 evaluation's rounding scales with); with_kink: a bool map of
+    the cells where a minimum / maximum tied between arguments with different tangents (the gradient there is JAX's
+    convention -- the mean -- and an evaluation with another rounding may not see the tie at all); with_amp: the largest
+    |u| / |u.n| of the backward scans behind the cell's gradient (a pole of the image method nearby: ill-conditioned)."""
+    walls = np.ascontiguousarray(walls, dtype=np.float32).reshape(-1, 2, 2)
+    Xc = np.ascontiguousarray(X, dtype=np.float32)
+    Yc = np.ascontiguousarray(Y, dtype=np.float32)
+    value = np.empty(Xc.shape, dtype=np.float32)
+    grad = np.empty(Xc.shape + (2,), dtype=np.float64)
+    gabs = np.empty(Xc.shape, dtype=np.float64) if with_gabs else None
+    kink = np.zeros(Xc.shape, dtype=np.uint8) if with_kink else None
+    amp = np.zeros(Xc.shape, dtype=np.float64) if with_amp else None
+    p = make_params(**kw)
+    keep, ptr = _allowed_ptr(allowed)
+    rc = lib().orc_power_map_grad(walls.reshape(-1) if walls.size else np.zeros(1, np.float32), walls.shape[0], ptr,
+                                  C.byref(p), np.ascontiguousarray(tx, dtype=np.float32), Xc.reshape(-1), Yc.reshape(-1),
+                                  Xc.size, value.reshape(-1), grad.reshape(-1),
+                                  None if gabs is None else gabs.ctypes.data_as(C.c_void_p),
+                                  None if kink is None else kink.ctypes.data_as(C.c_void_p),
+                                  None if amp is None else amp.ctypes.data_as(C.c_void_p), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"orc_power_map_grad failed: {rc}")
+    out = (value, grad)
+    if with_gabs:
+        out += (gabs,)
+    if with_kink:
+        out += (kink.astype(bool),)
+    if with_amp:
+        out += (amp,)
+    return out
 
 
 def eval_candidates(walls, tx, rx, allowed=None, **kw):

@@ -3,7 +3,7 @@
 
 usage: kernel_lab.py <case> [launches]
   cfg3      value + gradient + scene VJP of cfg2's sweep            power_fwd_kernel<MODE, false, 2, GRADK = true, LISTED = true, 1>
-  cfg3_hsig the same in hard_sigmoid validity
+  cfg3_hsig the same in hard_sigmoid validity; cfg3_txg / cfg3_txg_hsig: the cells are transmitters (env D2D_NAN_SCAN = 0 / 1 / 2: the NaN scan)
   txg       cfg2-sized TX grid (cells are transmitters)            power_fwd_txg_kernel
   cfg4      200 walls, 2048^2, orders 0..3, hard                   power_fwd_kernel<0, false, 3, false, true, 4>
   sigmoid   cfg2 in sigmoid validity                               power_fwd_kernel<2, ...>
@@ -49,8 +49,12 @@ with Context(0) as ctx:
             kw.update(approx=True)
         if case == "sigmoid":
             kw.update(approx=True, function="sigmoid")
-        if case == "txg":
+        if case in ("txg", "cfg3_txg", "cfg3_txg_hsig"):
             kw.update(grid_role=L.GRID_TX)
+        if case == "cfg3_txg_hsig":
+            kw.update(approx=True)
+        if os.environ.get("D2D_NAN_SCAN"):  # 0 off, 1 two levels (default), 2 one wave per patch
+            ctx.set_option("nan_scan", int(os.environ["D2D_NAN_SCAN"]))
         p = make_params(**kw)
         launch = (lambda: ctx.launch_vg(p, tx, scene_vjp=True)) if case.startswith("cfg3") else (lambda: ctx.launch(p, tx))
     ctx.set_option("time_kernel", 1)

@@ -109,6 +109,7 @@ def fuzz(n_cases, seed):
                 continue
             role = L.GRID_TX if done % 3 == 2 else L.GRID_RX
             ctx.set_option("region_lists", 0 if done % 7 == 6 else 1)
+            ctx.set_option("nan_scan", 2 if done % 5 == 4 else 1)  # (one wave per patch / two levels: the same flags)
             ctx.set_option("sched_min_tiles", 1 if done % 4 < 2 else 1 << 40)
             ctx.set_scene(walls)
             ctx.set_candidate_mask(allowed)

@@ -23,27 +23,30 @@ def test_culled_and_exhaustive_gradient_kernels_agree_on_random_scenes():
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     from fuzz_parity import random_case
 
+    from differt2d_amd import _lib as L
     from differt2d_amd.engine import Context
 
     rng = np.random.default_rng(99)
     with Context(0) as ctx:
         done = 0
-        while done < 40:
+        while done < 120:
             walls, tx, X, Y, kw, allowed = random_case(rng)
-            if kw["fun"] == "one" or len(walls) == 0:
+            if len(walls) == 0:
                 continue
             ctx.set_scene(walls)
             ctx.set_candidate_mask(allowed)
-            a = ctx.value_and_grads(tx, X, Y, strict_nan=False, **kw)
-            b = ctx.value_and_grads(tx, X, Y, strict_nan=True, **kw)
+            role = L.GRID_TX if done % 3 == 2 else L.GRID_RX
+            ctx.set_option("nan_scan", 2 if done % 5 == 4 else 1)  # (the scan's two shapes: the same flags)
+            a = ctx.value_and_grads(tx, X, Y, strict_nan=False, grid_role=role, **kw)
+            b = ctx.value_and_grads(tx, X, Y, strict_nan=True, grid_role=role, **kw)
             assert np.array_equal(a["value"], b["value"], equal_nan=True)
-            # wherever the exhaustive kernel is finite the culled one must agree; it may be finite where the exhaustive
-            # one reports one of the reference's autodiff NaN artefacts inside a culled candidate (never the reverse)
+            # NaN positions coincide (the default sweep's NaN scan finds the reference's autodiff artefacts inside the
+            # candidates its culling never evaluates), and everything else agrees
+            for k in ("grad_rx", "tx_bar", "walls_bar"):
+                assert np.array_equal(np.isnan(a[k]), np.isnan(b[k])), (k, done, kw)
             fin = np.isfinite(b["grad_rx"])
-            assert np.isfinite(a["grad_rx"][fin]).all()
             scale = max(1e-30, float(np.abs(b["grad_rx"][fin]).max())) if fin.any() else 1.0
             assert np.abs(a["grad_rx"][fin] - b["grad_rx"][fin]).max(initial=0.0) <= 1e-5 * scale
-            assert not (np.isnan(a["grad_rx"]) & fin).any()
             done += 1
 
 

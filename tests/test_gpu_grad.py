@@ -170,10 +170,90 @@ def test_cfg3_full_size_value_and_grad(ctx, approx):
     scale = np.abs(blk["grad_rx"][fin]).max()
     assert np.abs(full["grad_rx"][sl][fin] - blk["grad_rx"][fin]).max() <= 1e-6 * scale
     # The reference's autodiff NaN artefacts (un == 0 exactly, see DESIGN.md "NaN parity") do occur among 2.6e9
-    # (cell, candidate) pairs: a handful of cells, which -- as in the reference -- poison the summed scene VJP.
+    # (cell, candidate) pairs: 35 cells in hard mode, 105 in hard_sigmoid mode, which -- as in the reference -- poison the
+    # summed scene VJP (test_cfg3_full_map_nan_positions_equal_the_exhaustive_kernels holds every one of them to its place).
     nan_cells = np.isnan(full["grad_rx"]).any(-1)
     print("NaN cells:", int(nan_cells.sum()), "of", nan_cells.size)
-    assert nan_cells.mean() < 1e-4
+    assert 0 < nan_cells.sum() < 1000
+
+
+@pytest.mark.parametrize("mode", ["hard", "hsig"])
+@pytest.mark.parametrize("role", ["rx", "tx"])
+def test_cfg3_full_map_nan_positions_equal_the_exhaustive_kernels(role, mode):
+    """"NaN positions must coincide".  The reference's reverse mode yields NaN wherever the backward
+    scan of ANY candidate hits un == 0 (geometry.py:1105) or, in the approx modes, a zero-length segment (:227-228) -- valid
+    candidate or not.  The default sweep (tile culling + the NaN scan, d2d_nanscan.hpp) against the exhaustive kernel
+    (strict_nan: every candidate of every cell evaluated) on the WHOLE 1024 x 1024 map of configs[2], both grid roles:
+    identical NaN positions in the per-cell gradient, in tx_bar and in walls_bar; identical values; equal finite gradients."""
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import Context
+
+    kw = dict(approx=False) if mode == "hard" else dict(approx=True, function="hard_sigmoid")
+    tx, walls = random_scene(50, seed=1234)
+    x = np.linspace(0.0, 1.0, 1024).astype(F)
+    X, Y = np.meshgrid(x, x)
+    kws = dict(min_order=0, max_order=2, grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw)
+    with Context(0) as c:
+        c.set_scene(walls)
+        for _ in range(2):  # (the second launch runs on the work history, with the last-segment masks in use)
+            a = c.value_and_grads(tx, X, Y, strict_nan=False, **kws)
+        b = c.value_and_grads(tx, X, Y, strict_nan=True, **kws)
+        c.set_option("nan_scan", 2)  # the scan's other shape (one wave per patch): the same flags
+        a2 = c.value_and_grads(tx, X, Y, strict_nan=False, **kws)
+    assert np.array_equal(a["value"], b["value"])
+    n_nan = int(np.isnan(b["grad_rx"]).any(-1).sum())
+    print(f"{role} {mode}: {n_nan} NaN cells, walls_bar NaN entries {int(np.isnan(b['walls_bar']).sum())}")
+    assert n_nan >= 30, "the exhaustive kernel is expected to show the reference's NaN artefacts on this map"
+    for got in (a, a2):
+        for k in ("grad_rx", "tx_bar", "walls_bar"):
+            assert np.array_equal(np.isnan(got[k]), np.isnan(b[k])), f"{k}: NaN positions differ"
+        fin = ~np.isnan(b["grad_rx"])
+        assert np.array_equal(got["grad_rx"][fin], b["grad_rx"][fin])
+        for k in ("tx_bar", "walls_bar"):
+            f2 = ~np.isnan(b[k])
+            if f2.any():
+                np.testing.assert_allclose(got[k][f2], b[k][f2], rtol=1e-6, atol=1e-6 * float(np.abs(b[k][f2]).max()))
+
+
+@pytest.mark.parametrize("mode", ["hard", "hsig"])
+@pytest.mark.parametrize("role", ["rx", "tx"])
+def test_cfg3_rows_against_the_c_gradient_oracle(role, mode):
+    """An independent checker at scale: 128 full rows of configs[2] (131 072 contiguous cells: the 64 rows around the
+    transmitter and every 16th row of the map) against oracle/d2d_oracle_grad.c -- forward-mode dual numbers through the C
+    oracle's op chain, no adjoint code, nothing shared with the kernels (validated against reverse-mode autodiff of
+    oracle/ref.py in tests/test_oracle_grad_c.py) -- computed live on the host cores.  The GPU sweeps the WHOLE grid.
+    Values bit for bit; NaN positions identical; every gradient entry within 1e-5 of the cell's gradient scale
+    (sum over the candidates of |contribution gradient|: what an fp32 evaluation's rounding scales with) + 1e-5 relative."""
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import Context
+    from oracle import c_oracle as CO
+
+    kw = dict(approx=False) if mode == "hard" else dict(approx=True, function="hard_sigmoid")
+    tx, walls = random_scene(50, seed=1234)
+    x = np.linspace(0.0, 1.0, 1024).astype(F)
+    X, Y = np.meshgrid(x, x)
+    i0 = min(max(int(tx[1] * 1023) - 32, 0), 1024 - 64)
+    rows = np.unique(np.concatenate([np.arange(i0, i0 + 64), np.arange(0, 1024, 16)]))
+    with Context(0) as c:
+        c.set_scene(walls)
+        got = c.value_and_grads(tx, X, Y, min_order=0, max_order=2, grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw)
+    value, grad, gabs = CO.power_map_grad(walls, tx, X[rows], Y[rows], min_order=0, max_order=2, prune=1, grid_role=role,
+                                          with_gabs=True, **kw)
+    # (the exact shortcut of the oracle against its unpruned evaluation on four of the rows)
+    v0, g0 = CO.power_map_grad(walls, tx, X[rows[30:34]], Y[rows[30:34]], min_order=0, max_order=2, prune=0, grid_role=role, **kw)
+    assert np.array_equal(v0, value[30:34]) and np.array_equal(g0, grad[30:34], equal_nan=True)
+    assert np.array_equal(got["value"][rows], value), "value map differs from the oracle's"
+    g = got["grad_rx"][rows].astype(np.float64)
+    assert np.array_equal(np.isnan(g), np.isnan(grad)), f"NaN positions differ: GPU {int(np.isnan(g).sum())}, oracle {int(np.isnan(grad).sum())}"
+    fin = ~np.isnan(grad)
+    err = np.abs(g - grad)
+    bar = 1e-5 * gabs[..., None] + 1e-5 * np.abs(grad) + 1e-30
+    worst = float(np.nanmax(np.where(fin, err / bar, 0.0)))
+    lit = gabs > 0
+    print(f"{role} {mode}: {rows.size} rows, {int(lit.sum())} cells with a path, {int(np.isnan(grad).any(-1).sum())} NaN cells, "
+          f"worst error / bar {worst:.3f}; max |grad| {float(np.nanmax(np.abs(grad))):.3e}")
+    assert lit.sum() > 10000
+    assert (err[fin] <= bar[fin]).all(), f"{int((err[fin] > bar[fin]).sum())} entries beyond the bar, worst {worst:.2f} x"
 
 
 def test_tx_grid_culled_and_exhaustive_gradients_agree(ctx):
@@ -193,15 +273,71 @@ def test_tx_grid_culled_and_exhaustive_gradients_agree(ctx):
         a = ctx.value_and_grads(rx, X, Y, strict_nan=False, **kw)
         b = ctx.value_and_grads(rx, X, Y, strict_nan=True, **kw)
         assert np.array_equal(a["value"], b["value"], equal_nan=True)
+        for k in ("grad_rx", "tx_bar", "walls_bar"):
+            assert np.array_equal(np.isnan(a[k]), np.isnan(b[k])), (case, k)
         fin = np.isfinite(b["grad_rx"])
-        assert fin.mean() > 0.9 and np.isfinite(a["grad_rx"][fin]).all()
+        assert fin.mean() > 0.9
         scale = max(1e-30, float(np.abs(b["grad_rx"][fin]).max()))
         assert np.abs(a["grad_rx"][fin] - b["grad_rx"][fin]).max() <= 1e-5 * scale
-        assert not (np.isnan(a["grad_rx"]) & fin).any()
         for k in ("tx_bar", "walls_bar"):
             f2 = np.isfinite(b[k])
-            if f2.all():
-                np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=1e-5 * max(1e-30, float(np.abs(b[k]).max())))
+            if f2.any():
+                np.testing.assert_allclose(a[k][f2], b[k][f2], rtol=1e-5, atol=1e-5 * max(1e-30, float(np.abs(b[k][f2]).max())))
+
+
+def test_lattice_scenes_against_the_c_gradient_oracle(ctx):
+    """Walls snapped to a coarse lattice, a transmitter on a lattice point, cells on walls' lines: exact zeros in the backward
+    scan are common.  Values, NaN positions and gradients of the default sweep and of the exhaustive kernel against
+    oracle/d2d_oracle_grad.c, all modes and path functions (fun = 1 in hard mode: nothing is differentiated, no NaN), both roles."""
+    from differt2d_amd import _lib as L
+    from oracle import c_oracle as CO
+
+    rng = np.random.default_rng(5)
+    nan_seen = checked = 0
+    for case in range(24):
+        n = int(rng.integers(3, 9))
+        walls = (np.round(rng.random((n, 2, 2)) * 4) / 4).astype(F)
+        walls[(walls[:, 0] == walls[:, 1]).all(-1)] += F(0.125)
+        tx = (np.round(rng.random(2) * 8) / 8).astype(F)
+        xs = np.linspace(0, 1, int(rng.integers(9, 34))).astype(F)
+        X, Y = np.meshgrid(xs, xs[: int(rng.integers(5, xs.size + 1))])
+        approx, function = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")][case % 3]
+        fun = ["received_power", "one", "length", "length_squared"][(case // 3) % 4]
+        role = "tx" if case % 2 else "rx"
+        kw = dict(min_order=0, max_order=2, approx=approx, function=function, fun=fun, alpha=float(rng.choice([100.0, 16.0])))
+        value, grad, gabs, kink = CO.power_map_grad(walls, tx, X, Y, grid_role=role, with_gabs=True, with_kink=True, **kw)
+        # Which cells have a gradient worth comparing -- decided by the oracle alone: its own result must survive a nudge of
+        # the fixed end point and of the cell by one ulp.  (A lattice scene puts end points ON walls' lines: the interaction
+        # points are then rounding noise, fp32 and fp64 autodiff of oracle/ref.py disagree in the first digit, and so do any
+        # two fp32 evaluation orders.)
+        up = lambda a: np.nextafter(np.asarray(a, F), F(np.inf))
+        stable = np.ones(X.shape, bool)
+        for tx2, X2, Y2 in ((up(tx), X, Y), (tx, up(X), up(Y))):
+            v2, g2 = CO.power_map_grad(walls, tx2, X2, Y2, grid_role=role, **kw)
+            with np.errstate(invalid="ignore"):
+                stable &= np.abs(v2 - value) <= 1e-3 * np.abs(value) + 1e-9
+                stable &= (np.abs(g2 - grad) <= 1e-2 * gabs[..., None] + 1e-9).all(-1)
+        ctx.set_scene(walls)
+        for strict in (False, True):
+            got = ctx.value_and_grads(tx, X, Y, strict_nan=strict, grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw)
+            if function == "sigmoid":
+                np.testing.assert_allclose(got["value"], value, rtol=1e-6, atol=1e-7)
+            else:
+                assert np.array_equal(got["value"], value, equal_nan=True), (case, strict)
+            g = got["grad_rx"].astype(np.float64)
+            assert np.array_equal(np.isnan(g), np.isnan(grad)), (case, strict, kw, role, int(np.isnan(g).sum()), int(np.isnan(grad).sum()))
+            # Gradients: wherever the oracle met no tie of a minimum / maximum between arguments with different tangents.
+            # (At such a kink JAX returns the mean of the two one-sided derivatives; the image-method kernel sends the
+            # cotangent to the first of the equal arguments -- DESIGN.md, "known deviations" -- and a lattice scene is
+            # made of kinks.)  sigmoid at alpha = 100 amplifies every rounding of its argument: a wider bar there.
+            fin = np.isfinite(grad).all(-1) & np.isfinite(g).all(-1) & ~kink & stable
+            rel = 3e-4 if function == "sigmoid" else 1e-5
+            bar = rel * gabs[..., None] + rel * np.abs(grad) + 1e-6
+            bad = (np.abs(g - grad) > bar).any(-1) & fin
+            assert not bad.any(), (case, strict, kw, role, int(bad.sum()), np.argwhere(bad)[:3].tolist())
+            checked += int(fin.sum())
+        nan_seen += int(np.isnan(grad).any(-1).sum())
+    assert nan_seen > 20 and checked > 2000
 
 
 def _tight(got, want, want32, name, report):
