@@ -13,6 +13,9 @@ N > 1     = one process per GPU: either launched by torch.distributed.run (RANK 
             and max-over-ranks through RCCL.  Rows are dealt to ranks in 8-row blocks
             round-robin (differt2d_amd/parallel.py).  cfg2: WEAK scaling, the grid becomes (1024 N) x 1024 cells over the
             same unit square, 1024 x 1024 per rank.  cfg4: STRONG scaling, the 2048 x 2048 grid is split over the ranks.
+            The default cfg2 line also carries, at every N, configs[3] split over the ranks (`strong_cfg4`) and, at N > 1,
+            configs[1]'s own 1024 x 1024 grid split over the ranks (`strong_cfg2`) and what the gather adds to a step
+            (`gather_cost`: the same steps with and without it).
             Each step ends with ONE RCCL gather of the value map to rank 0 (--gather root, ncclSend/ncclRecv; or --gather
             all, ncclAllGather), on a second stream so that it overlaps the next step's sweep.  If the communicator cannot
             be created the run FAILS (exit code 3): a number without the gather is not the configured workload.
@@ -29,7 +32,8 @@ roofline  = the kernel is FP32-VALU bound (~1e6 FLOP per H
             inside this run (rocprofv3 PMC passes: profiles/, scripts/profile_gpu.sh).
 extras    = (N = 1, outside the timed region, skipped by --no-extras) the same map in hard_sigmoid and sigmoid validity, a
             moving-TX sequence (a different transmitter every step: the schedule's work history is then always one step
-            stale), the first launch after set_grid, value+grad in both strict_nan modes, and `parity`: mismatch counts
+            stale), the first launch after set_grid, value+grad (default = culling + NaN scan, the exhaustive cross-check,
+            and without the scan), and `parity`: mismatch counts
             of the timed configuration's map against the oracle (committed full-map row CRCs + the cpu_baseline's rows).
 cpu_baseline = the oracle's C/OpenMP restatement on a bounded row sample of the same grid (rank 0, N = 1).
 Prints ONE JSON line on rank 0.
@@ -250,13 +254,14 @@ def api_leg(tx, walls, resident_ms, sizes=(300, 1024), n_calls=12):
     return out
 
 
-def strong_leg(ctx, world, rank, distributed, do_gather, timed, steps=5):
-    """BASELINE.json configs[3] (200 walls, 2048 x 2048, orders 0..3) with its rows split over the ranks: the STRONG-scaling
-    companion of the timed (weak) workload, in the same process, for the N = 1, 2, 4, 8 sequence."""
+def strong_leg(ctx, world, rank, distributed, do_gather, timed, which="cfg4", steps=5):
+    """A BASELINE.json configuration with its rows split over the ranks -- configs[3] (200 walls, 2048 x 2048, orders 0..3) or
+    configs[1] (the timed workload's own 1024 x 1024 grid) -- the STRONG-scaling companion of the timed (weak) workload, in the
+    same process, for the N = 1, 2, 4, 8 sequence.  Reference semantics: ONE assembled map (scene.py:1927-1953)."""
     from differt2d_amd.engine import make_params
     from differt2d_amd.parallel import RowShards
 
-    n_walls, grid, max_order = WORKLOADS["cfg4"][:3]
+    n_walls, grid, max_order, cfg = WORKLOADS[which][:4]
     tx, walls, X, Y = workload(n_walls, grid)
     shards = RowShards(X.shape[0], world)
     ctx.set_scene(walls)
@@ -271,10 +276,15 @@ def strong_leg(ctx, world, rank, distributed, do_gather, timed, steps=5):
     step()
     ctx.synchronize()
     wall, _ = timed(step, steps, 2)
+    out = {}
+    if world > 1:  # what the gather adds to a step
+        wall0, _ = timed(lambda: ctx.launch(p, tx), steps, 2)
+        out["ms_per_step_without_gather"] = wall0 * 1e3 / steps
     C = num_candidates(n_walls, 0, max_order)
-    return {"workload": f"{n_walls} walls, {grid}x{grid} RX grid split over {world} rank(s), orders 0..{max_order} (C={C}), hard validity; "
-                        "BASELINE.json configs[3]", "scaling": "strong", "steps": steps, "ms_per_step": wall * 1e3 / steps,
-            "candidates_per_s": X.size * C / (wall / steps)}
+    out.update({"workload": f"{n_walls} walls, {grid}x{grid} RX grid split over {world} rank(s), orders 0..{max_order} (C={C}), hard validity; "
+                            f"BASELINE.json {cfg}", "scaling": "strong", "steps": steps, "ms_per_step": wall * 1e3 / steps,
+                "candidates_per_s": X.size * C / (wall / steps)})
+    return out
 
 
 def main():
@@ -403,6 +413,12 @@ def main():
 
     wall, sequence_ms = timed(step, steps, warmup)
     ms_per_step = wall * 1e3 / steps
+    gather_cost = None
+    if gather:  # what the RCCL gather adds to a step: the same steps without it (never the headline: the workload includes it)
+        wall0, _ = timed(lambda: ctx.launch(params, tx), steps, warmup)
+        gather_cost = {"ms_per_step_with_gather": ms_per_step, "ms_per_step_without_gather": wall0 * 1e3 / steps,
+                       "what": f"--gather {args.gather}: the map's gather runs on a second stream behind the sweep and overlaps the next "
+                               "step's sweep; the difference is what it adds to a step"}
     kernel_ms = kernel_ms_of(params, tx, min(steps, 50))
     rccl_ranks, kernel_ms_per_rank = 1, [kernel_ms]
     if distributed:
@@ -465,17 +481,29 @@ def main():
                                   "what": "wall time launch -> synchronize of one map; the first figure is the very first launch of "
                                           "the process's context, the second a launch after set_grid with buffers and masks in place "
                                           "(no work history: geometric-proxy schedule)"}
-        # ---- value + gradient (BASELINE.json configs[2]), both NaN-parity modes, in the timed validity mode
+        # ---- value + gradient (BASELINE.json configs[2]) in the timed validity mode: the default sweep (tile culling + the NaN
+        # scan: NaN positions identical to the reference's), the exhaustive cross-check, and the sweep without the scan (A/B)
         vg = {}
-        for label, strict in (("culled", False), ("strict_nan", True)):
+        for label, strict, scan in (("default", False, 1), ("strict_nan", True, 1), ("without_nan_scan", False, 0)):
             p = make_params(min_order=0, max_order=max_order, strict_nan=strict, **mode_kw[timed_mode])
             n = max(3, n_x // 2) if not strict else 5
-            w, _ = timed(lambda p=p: ctx.launch_vg(p, tx, scene_vjp=True), n, 1)
-            vg[label] = {"ms_per_step": w * 1e3 / n, "steps": n, "candidates_per_s": cells_total * C / (w / n)}
-        vg["what"] = ("value + per-cell d/d rx + VJP w.r.t. TX position and wall end points (hand-derived reverse mode). "
-                      "`culled` (default): NaN where the reference's autodiff NaN artefacts come from an evaluated candidate or a "
-                      "cell on a wall's line; `strict_nan`: every candidate evaluated, NaN positions identical to the reference's "
-                      "in all cases (DESIGN.md 'NaN parity')")
+            ctx.set_option("nan_scan", scan)
+            w, _ = timed(lambda p=p: ctx.launch_vg(p, tx, scene_vjp=True), n, 2)
+            ctx.set_option("time_kernel", 1)
+            ks = []
+            for _ in range(min(n, 10)):
+                ctx.launch_vg(p, tx, scene_vjp=True)
+                ks.append(ctx.last_kernel_ms())
+            ctx.set_option("time_kernel", 0)
+            vg[label] = {"ms_per_step": w * 1e3 / n, "kernels_ms": float(np.mean(ks)), "steps": n, "candidates_per_s": cells_total * C / (w / n)}
+        ctx.set_option("nan_scan", 1)
+        vg["what"] = ("value + per-cell d/d rx + VJP w.r.t. TX position and wall end points (hand-derived reverse mode). `default`: "
+                      "candidates that tile culling proves invalid are not evaluated; the reference's autodiff NaN positions -- an exact "
+                      "zero in the backward scan of ANY candidate, a zero-length segment in the loss, a segment of exactly (-eps, -eps) "
+                      "in path_length -- come from a scan of their own and coincide with the exhaustive kernel's on the whole map "
+                      "(tests/test_gpu_grad.py::test_cfg3_full_map_nan_positions_equal_the_exhaustive_kernels). `strict_nan`: every "
+                      "candidate of every cell evaluated (the cross-check). `without_nan_scan`: round 3's default (A/B; only the "
+                      "evaluated candidates' NaN). kernels_ms: sweep + scan on their stream (HIP events)")
         extras["value_and_grad"] = vg
     elif not args.no_extras:
         def step_vg():
@@ -496,9 +524,13 @@ def main():
         final_map = ctx.get_map()  # rank 0's shard of the timed configuration (N = 1: the whole map)
         stats = ctx.launch_stats(params, tx)  # instrumented build, outside the timed region (deterministic counts)
         list_stats = ctx.debug_region_stats()  # the region candidate lists of that launch (none for orders < 2)
+    if gather_cost is not None:
+        extras["gather_cost"] = gather_cost
     if not args.no_extras and args.workload == "cfg2" and default_shape:
         # (collective at N > 1: every rank takes part; replaces the context's scene and grid, hence after everything else)
-        extras["strong_cfg4"] = strong_leg(ctx, world, rank, distributed, do_gather, timed)
+        if world > 1:  # (at N = 1 the timed workload IS cfg2 on one rank)
+            extras["strong_cfg2"] = strong_leg(ctx, world, rank, distributed, do_gather, timed, "cfg2", steps=min(steps, 50))
+        extras["strong_cfg4"] = strong_leg(ctx, world, rank, distributed, do_gather, timed, "cfg4")
     if not args.no_extras and world == 1 and args.workload == "cfg2" and default_shape:
         extras["api"] = api_leg(tx, walls, ms_per_step)
 

@@ -194,6 +194,7 @@ struct d2d_ctx {
     bool txg_exhaustive = false;        // TX-grid value sweeps with the exhaustive kernel (A/B and tests)
     long long sched_min_tiles = 2048;   // launches with fewer patches keep the identity schedule
     uint64_t grid_hash = 0, grid_token = 0;  // content hash / caller's version token of the resident grid (valid with have_grid)
+    uint64_t grid_fp = 0;                    // strided sample of the resident grid's arrays (checked beside the token)
     bool grid_hash_valid = false;
     int last_shape_waves = 0, last_shape_coop = 0;  // diagnostic: d2d_debug_sweep_shape
     long long grid_reuses = 0;  // d2d_set_grid calls that found their grid resident already (diagnostic: d2d_debug_grid_reuses)
@@ -698,6 +699,11 @@ int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float
             same = same && std::memcmp(&c->phi[(size_t)j], &ph, sizeof(float)) == 0;
         }
         if (same) {
+            // what a d2d_set_scene has always meant for the results held by the context: a scene VJP summed so far (D2D_OUT_ADD)
+            // is closed -- a caller who sets the scene again starts a new sum -- and the last launch's kernel time is stale
+            c->have_vjp = false;
+            c->vjp_reduced = false;
+            c->have_kernel_time = false;
             bool all = true;
             for (int j = 0; j < n_objects; ++j) all = all && c->allowed[(size_t)j] != 0;
             if (all) return D2D_OK;
@@ -785,8 +791,27 @@ static int set_grid_impl(d2d_ctx* c, const float* X, const float* Y, int32_t m, 
     size_t cells = (size_t)m * (size_t)n;
     bool same = c->have_grid && c->m == m && c->n == n && c->d_X.p && c->d_Y.p && c->d_out.p;
     uint64_t h = 0;
+    // a strided sample of both arrays (<= 2 x 509 words): the caller's version token says "the same immutable arrays", but an
+    // owning array's flag can be flipped, written through and flipped back -- the sample catches what a token cannot
+    uint64_t fp = ((uint64_t)(uint32_t)m << 32) | (uint32_t)n;
+    {
+        const size_t step = cells > 509 ? cells / 509 : 1;
+        for (size_t i = 0; i < cells; i += step) {
+            uint32_t a, b;
+            std::memcpy(&a, X + i, 4);
+            std::memcpy(&b, Y + i, 4);
+            fp = (fp ^ (((uint64_t)a << 32) | b)) * 0x9E3779B97F4A7C15ull;
+            fp ^= fp >> 29;
+        }
+        if (cells) {
+            uint32_t a, b;
+            std::memcpy(&a, X + cells - 1, 4);
+            std::memcpy(&b, Y + cells - 1, 4);
+            fp = (fp ^ (((uint64_t)a << 32) | b)) * 0xC2B2AE3D27D4EB4Full;
+        }
+    }
     if (token != 0) {
-        same = same && c->grid_token == token;
+        same = same && c->grid_token == token && c->grid_fp == fp;
     } else {
         h = d2d_host::hash_floats(Y, cells, d2d_host::hash_floats(X, cells, ((uint64_t)(uint32_t)m << 32) | (uint32_t)n));
         same = same && c->grid_hash_valid && c->grid_hash == h;
@@ -813,6 +838,7 @@ static int set_grid_impl(d2d_ctx* c, const float* X, const float* Y, int32_t m, 
             if (ay > c->grid_absmax) c->grid_absmax = ay;
         }
         c->grid_token = token;
+        c->grid_fp = fp;
         c->grid_hash = h;
         c->grid_hash_valid = token == 0;
     }
@@ -953,9 +979,25 @@ static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, in
             }
             const long long per_cell = std::max<long long>(1, off[(size_t)C]);  // floats per cell, all candidates
             const long long cells_pad = ((long long)a.cells + 63) / 64 * 64;
-            const long long budget = std::max<long long>(c->opt_traj_mb, 1) << 20;
+            // The budget: "opt_traj_mb", but never more than half of what the device has free right now (other ranks may share
+            // it; the store that is resident already counts as free) -- and when even that cannot be had, chunks of half the
+            // cells, down to one wave's worth, before giving up (a hard error where round 2's forward tangents ran)
+            long long budget = std::max<long long>(c->opt_traj_mb, 1) << 20;
+            {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                    const long long avail = (long long)free_b + (long long)(c->d_traj.n * sizeof(float));
+                    budget = std::min<long long>(budget, std::max<long long>(avail / 2, 64ll << 20));
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
             chunk_cells = std::min<long long>(cells_pad, std::max<long long>(64, budget / (4 * per_cell) / 64 * 64));
-            if ((rc = c->d_traj.ensure((size_t)(chunk_cells * per_cell)))) return rc;
+            while (c->d_traj.ensure((size_t)(chunk_cells * per_cell)) != D2D_OK) {
+                (void)hipGetLastError();
+                if (chunk_cells <= 64) return fail(D2D_ERR_HIP, "the solver's trajectory store does not fit the device even for 64 cells (%lld floats per cell)", per_cell);
+                chunk_cells = std::max<long long>(64, chunk_cells / 2 / 64 * 64);
+            }
             if ((rc = c->d_traj_off.ensure((size_t)C + 1))) return rc;
             HIP_TRY(hipMemcpyAsync(c->d_traj_off.p, off.data(), ((size_t)C + 1) * sizeof(long long), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));  // (the host vector goes out of scope)

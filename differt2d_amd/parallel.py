@@ -16,8 +16,8 @@ than assembling the final map:
 Data plane AND barrier / max-over-ranks: RCCL directly on the library's device buffers (``d2d_comm_*``, xGMI on
 an MI355X node).  Rendezvous (shipping the 128-byte unique id): a file in /tmp (:func:`file_rendezvous`), so the
 GPU processes import no torch -- torch bundles its own libamdhip64 / librccl under the system ROCm's SONAMEs and
-must stay out of a process that drives the system RCCL.  The ``GlooHostComm`` backend moves host arrays through
-``torch.distributed``/gloo instead and exists for the CPU tests of the partition logic.
+must stay out of a process that drives the system RCCL.  (The CPU tests of the partition logic move host arrays through
+``torch.distributed``/gloo instead: ``tests/gloo_comm.py``, test infrastructure, not part of this package.)
 """
 
 from __future__ import annotations
@@ -175,38 +175,6 @@ class FileHostComm:
 
     def barrier(self):
         self.allreduce([1.0], "sum")
-
-
-class GlooHostComm:
-    """Host-array all-gather / all-reduce over an initialised ``torch.distributed`` group (CPU tests)."""
-
-    def __init__(self):
-        import torch
-        import torch.distributed as dist
-
-        self.torch, self.dist = torch, dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-
-    def allgather(self, local: np.ndarray) -> np.ndarray:
-        t = self.torch.from_numpy(np.ascontiguousarray(local))
-        outs = [self.torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(outs, t)
-        return np.stack([o.numpy() for o in outs])
-
-    def gather(self, local: np.ndarray, root: int = 0) -> Optional[np.ndarray]:
-        """``[world, ...]`` on ``root``, ``None`` elsewhere."""
-        t = self.torch.from_numpy(np.ascontiguousarray(local))
-        outs = [self.torch.empty_like(t) for _ in range(self.world)] if self.rank == root else None
-        self.dist.gather(t, outs, dst=root)
-        return np.stack([o.numpy() for o in outs]) if self.rank == root else None
-
-    def allreduce_sum(self, local: np.ndarray) -> np.ndarray:
-        t = self.torch.from_numpy(np.array(local, dtype=np.float64))
-        self.dist.all_reduce(t)
-        return t.numpy()
-
-    def barrier(self):
-        self.dist.barrier()
 
 
 def sharded_map(X: np.ndarray, Y: np.ndarray, compute_shard: Callable[[np.ndarray, np.ndarray], np.ndarray], comm,

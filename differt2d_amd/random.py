@@ -1,22 +1,56 @@
 """
 The reference's random numbers on the host: JAX's default PRNG -- Threefry-2x32, 20 rounds (Salmon et al., "Parallel random
-numbers: as easy as 1, 2, 3", SC'11) -- with the key plumbing of ``jax.random`` (jax/_src/prng.py, the original,
-non-partitionable layout: the default of the JAX releases DiffeRT2d v0.4.0 runs on), restated in NumPy.
+numbers: as easy as 1, 2, 3", SC'11) -- with the key plumbing of ``jax.random`` (jax/_src/prng.py), restated in NumPy, in
+BOTH of JAX's counter layouts:
+
+* **partitionable** (``jax_threefry_partitionable=True``: the default since JAX 0.5.0, hence of the jax 0.5.2 the reference's
+  ``uv.lock`` pins) -- the element's 64-bit flat index as the two counter words (high, low), 32 output bits = ``y0 ^ y1``,
+  ``split`` = ``stack(y0, y1)`` per index.  The default here.
+* **original** (JAX < 0.5, or the flag switched off) -- the counts split in two halves, outputs concatenated.  The reference's
+  own doctest of a keyed draw (abc.py:168-174, marked ``+SKIP``) was recorded under this one.
+
+``set_threefry_partitionable(False)`` / ``with threefry_partitionable(False):`` / the environment variable
+``D2D_THREEFRY_PARTITIONABLE=0`` select the original layout.
 
 The reference draws random scenes (scene.py:716-733) and the initial guesses of the MinPath / FermatPath solvers
 (optimize.py:132, 174-178; one key per candidate, scene.py:1585, 1888; a chain of splits in ``all_paths``, scene.py:1210) from
 ``jax.random``; with this module a call with ``key=PRNGKey(1234)`` draws the same numbers here.  JAX itself cannot be
 imported in this repository's containers, so the restatement is pinned by known answers instead (tests/test_random.py): the
-reference's own doctest of a keyed draw (abc.py:168-174: Wall.sample(PRNGKey(1234)) = [0.88359046, 1.1781206]), the
-Random123 / JAX test-suite vectors of the block function, ``random.split(PRNGKey(0))`` from JAX's
-PRNG design note, and ``random.uniform(PRNGKey(0))`` = 0.41845703.  Host code by nature: draws are a few numbers per call.
+Random123 / JAX test-suite vectors of the block function; original layout: the reference's own doctest of a keyed draw
+(abc.py:168-174: Wall.sample(PRNGKey(1234)) = [0.88359046, 1.1781206]), ``random.split(PRNGKey(0))`` from JAX's PRNG design
+note, ``random.uniform(PRNGKey(0))`` = 0.41845703, ``split(PRNGKey(42))`` and ``normal(PRNGKey(42))`` = -0.18471177 of JAX's
+tutorial before 0.5; partitionable layout: ``split(key(42))`` = [1832780943 270669613], [64467757 2916123636] and
+``normal(key(42))`` = -0.028304616 of the same tutorial since.  Host code by nature: draws are a few numbers per call.
 """
 
 from __future__ import annotations
 
+import contextlib
+import os
+
 import numpy as np
 
-__all__ = ["PRNGKey", "as_key", "split", "uniform", "random_bits", "threefry2x32", "threefry_2x32"]
+__all__ = ["PRNGKey", "as_key", "split", "uniform", "random_bits", "threefry2x32", "threefry_2x32",
+           "set_threefry_partitionable", "threefry_partitionable"]
+
+_PARTITIONABLE = os.environ.get("D2D_THREEFRY_PARTITIONABLE", "1").strip().lower() not in ("0", "false", "no", "off")
+
+
+def set_threefry_partitionable(on: bool) -> bool:
+    """``jax.config.update("jax_threefry_partitionable", on)``; returns the previous setting."""
+    global _PARTITIONABLE
+    old, _PARTITIONABLE = _PARTITIONABLE, bool(on)
+    return old
+
+
+@contextlib.contextmanager
+def threefry_partitionable(on: bool = True):
+    """``with jax.threefry_partitionable(on):``"""
+    old = set_threefry_partitionable(on)
+    try:
+        yield
+    finally:
+        set_threefry_partitionable(old)
 
 _U32 = np.uint32
 _ROT = ((13, 15, 26, 6), (17, 29, 16, 24))
@@ -72,17 +106,33 @@ def threefry_2x32(key, count) -> np.ndarray:
     return (out[:-1] if odd else out).reshape(count.shape)
 
 
+def _iota_2x32(n: int):
+    """``iota_2x32_shape``: the 64-bit flat index of each of ``n`` elements as (high, low) 32-bit words."""
+    i = np.arange(n, dtype=np.uint64)
+    return (i >> np.uint64(32)).astype(_U32), (i & np.uint64(0xFFFFFFFF)).astype(_U32)
+
+
 def split(key, num: int = 2) -> np.ndarray:
-    """``jax.random.split``: ``num`` new keys, shape (num, 2)."""
-    return threefry_2x32(key, np.arange(2 * int(num), dtype=_U32)).reshape(int(num), 2)
+    """``jax.random.split``: ``num`` new keys, shape (num, 2) (``_threefry_split_foldlike`` / ``_threefry_split_original``)."""
+    num = int(num)
+    if _PARTITIONABLE:
+        hi, lo = _iota_2x32(num)
+        y0, y1 = threefry2x32(as_key(key), hi, lo)
+        return np.stack([y0, y1], axis=-1)
+    return threefry_2x32(key, np.arange(2 * num, dtype=_U32)).reshape(num, 2)
 
 
 def random_bits(key, shape) -> np.ndarray:
-    """32 random bits per element (``_threefry_random_bits``, original layout: counter = the element's flat index)."""
+    """32 random bits per element (``_threefry_random_bits_partitionable``: counter = the element's 64-bit flat index, bits =
+    ``y0 ^ y1``; ``_threefry_random_bits_original``: the flat indices split in two halves)."""
     shape = tuple(int(s) for s in (shape if np.ndim(shape) else (shape,)))
     n = int(np.prod(shape)) if shape else 1
     if n >= 2**32:
         raise ValueError("more than 2^32 - 1 elements per draw are not supported")
+    if _PARTITIONABLE:
+        hi, lo = _iota_2x32(n)
+        y0, y1 = threefry2x32(as_key(key), hi, lo)
+        return (y0 ^ y1).reshape(shape)
     return threefry_2x32(key, np.arange(n, dtype=_U32)).reshape(shape)
 
 

@@ -18,6 +18,7 @@ No CPU implementation of the path solve / validity exists in this package.
 from __future__ import annotations
 
 import dataclasses
+import weakref
 import json
 import operator
 from collections.abc import Iterator, Mapping, Sequence
@@ -91,16 +92,29 @@ def all_path_candidates(num_nodes: int, min_order: int = 0, max_order: int = 1, 
 
 
 def _probe_paths():
-    """Synthetic (transmitter, receiver, path, interacting objects) tuples of orders 0..3 with incommensurate lengths."""
-    from .geometry import Wall
+    """Synthetic (transmitter, receiver, path, interacting objects) tuples of orders 0..3 with incommensurate lengths -- each
+    path TWICE: once with plain end points and unit walls through its interaction points, once with end points that are not the
+    path's, and objects of other kinds, lengths and orientations.  A path function that is one of the closed forms depends on
+    the path alone and returns the same number for both."""
+    from .geometry import RIS, Vertex, Wall
 
     rng = np.random.default_rng(20260)
     out = []
-    for k in (0, 1, 1, 2, 3, 0, 2):
+    for k in (0, 1, 1, 2, 3, 0, 2, 1, 3):
         pts = (rng.random((k + 2, 2)) * F(3.0) - F(1.0)).astype(F)
         walls = [Wall(xys=np.stack([pts[i + 1] - F(0.5), pts[i + 1] + F(0.5)])) for i in range(k)]
-        out.append((Point(xy=pts[0]), Point(xy=pts[-1]), Path(xys=pts), walls))
+        other = []
+        for i in range(k):
+            d = (rng.random(2) * F(2.0) - F(1.0)).astype(F) * F(0.25 + 2.0 * rng.random())
+            kind = (RIS, Vertex, Wall)[i % 3]
+            other.append(Vertex(xy=pts[i + 1]) if kind is Vertex else kind(xys=np.stack([pts[i + 1] - d, pts[i + 1] + F(0.3) * d])))
+        shift = (rng.random(2) * F(0.7) + F(0.1)).astype(F)
+        out.append(((Point(xy=pts[0]), Point(xy=pts[-1]), Path(xys=pts), walls),
+                    (Point(xy=pts[0] + shift), Point(xy=pts[-1] - shift), Path(xys=pts), other)))
     return out
+
+
+_FUN_VERDICTS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
 def _recognise_fun(fun, fun_args, fun_kwargs):
@@ -109,15 +123,40 @@ def _recognise_fun(fun, fun_args, fun_kwargs):
     evaluated on a handful of synthetic paths and compared with ``1``, ``length``, ``length ** 2`` and the
     ``r_coef ** n / (height ** 2 + length ** 2)`` family (utils.py:17-54; the two constants are fitted from the first probes
     and verified on the others).  Returns (native name, make_params kwargs) or None; a callable that raises on the
-    probes, depends on anything but the path's length and order, or matches nothing is left to the host."""
+    probes, depends on anything but the path's length and order -- the end points it is handed, the kinds, lengths or
+    orientations of the interacting objects: every path is probed with two different sets of them -- or matches nothing is
+    left to the host.  The verdict is kept per callable (and arguments), so the probes run once; ``fun._d2d_native = False``
+    opts a callable out."""
+    try:
+        ckey = (tuple(fun_args), tuple(sorted((fun_kwargs or {}).items())))
+        hash(ckey)
+        cached = _FUN_VERDICTS.get(fun, {}).get(ckey, "?")
+        if cached != "?":
+            return cached
+    except TypeError:  # unhashable arguments, or a callable that cannot be weakly referenced: probe every time
+        ckey = None
+    verdict = _recognise_fun_uncached(fun, fun_args, fun_kwargs)
+    if ckey is not None:
+        try:
+            _FUN_VERDICTS.setdefault(fun, {})[ckey] = verdict
+        except TypeError:
+            pass
+    return verdict
+
+
+def _recognise_fun_uncached(fun, fun_args, fun_kwargs):
     probes = _probe_paths()
     try:
-        vals = [np.asarray(fun(a, b, path, inter, *fun_args, **(fun_kwargs or {})), dtype=np.float64) for a, b, path, inter in probes]
+        both = [[np.asarray(fun(a, b, path, inter, *fun_args, **(fun_kwargs or {})), dtype=np.float64) for a, b, path, inter in pair]
+                for pair in probes]
     except Exception:  # noqa: BLE001 -- whatever the callable needs, the probes do not provide it
         return None
-    if any(v.shape != () or not np.isfinite(v) for v in vals):
+    if any(v.shape != () or not np.isfinite(v) for pair in both for v in pair):
         return None
-    vals = np.array([float(v) for v in vals])
+    if any(float(u) != float(v) for u, v in both):
+        return None  # depends on the end points or on the objects, not on the path alone
+    probes = [pair[0] for pair in probes]
+    vals = np.array([float(pair[0]) for pair in both])
     r = np.array([float(path.length()) for _, _, path, _ in probes])
     ks = np.array([path.xys.shape[0] - 2 for _, _, path, _ in probes])
     close = lambda want: bool(np.allclose(vals, want, rtol=2e-6, atol=0.0))
@@ -147,6 +186,8 @@ def _recognise_fun(fun, fun_args, fun_kwargs):
 def _native_fun(fun, fun_args, fun_kwargs):
     """(fun name, kwargs for make_params) if ``fun`` is fused natively, else None."""
     name = getattr(fun, "_d2d_native", None)
+    if name is False:
+        return None  # opted out: the host evaluates it
     if name is None:
         return _recognise_fun(fun, fun_args, fun_kwargs) if callable(fun) else None
     if fun_args:

@@ -239,16 +239,22 @@ def test_cfg3_rows_against_the_c_gradient_oracle(role, mode):
         got = c.value_and_grads(tx, X, Y, min_order=0, max_order=2, grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw)
     value, grad, gabs = CO.power_map_grad(walls, tx, X[rows], Y[rows], min_order=0, max_order=2, prune=1, grid_role=role,
                                           with_gabs=True, **kw)
-    # (the exact shortcut of the oracle against its unpruned evaluation on four of the rows)
-    v0, g0 = CO.power_map_grad(walls, tx, X[rows[30:34]], Y[rows[30:34]], min_order=0, max_order=2, prune=0, grid_role=role, **kw)
-    assert np.array_equal(v0, value[30:34]) and np.array_equal(g0, grad[30:34], equal_nan=True)
     assert np.array_equal(got["value"][rows], value), "value map differs from the oracle's"
     g = got["grad_rx"][rows].astype(np.float64)
     assert np.array_equal(np.isnan(g), np.isnan(grad)), f"NaN positions differ: GPU {int(np.isnan(g).sum())}, oracle {int(np.isnan(grad).sum())}"
     fin = ~np.isnan(grad)
     err = np.abs(g - grad)
-    bar = 1e-5 * gabs[..., None] + 1e-5 * np.abs(grad) + 1e-30
+    # 1e-5 of the cell's own gradient scale, or 1e-6 of the largest gradient in the cell's row: the floor covers the ties of
+    # min / max at exactly saturated activations (fl(c / 6) == 1 with c < 6: JAX halves a small derivative there, the kernel
+    # -- which sends a tie's cotangent to the first of the equal arguments, DESIGN.md "known deviation" -- returns 0)
+    rowscale = np.nanmax(np.abs(grad), axis=(1, 2), keepdims=True)
+    bar = 1e-5 * gabs[..., None] + 1e-5 * np.abs(grad) + 1e-6 * rowscale
     worst = float(np.nanmax(np.where(fin, err / bar, 0.0)))
+    # the oracle's exact shortcut (prune) against its plain evaluation on four rows around the transmitter: the same NaN
+    # cells, the same gradients up to those ties
+    v0, g0 = CO.power_map_grad(walls, tx, X[rows[30:34]], Y[rows[30:34]], min_order=0, max_order=2, prune=0, grid_role=role, **kw)
+    assert np.array_equal(v0, value[30:34]) and np.array_equal(np.isnan(g0), np.isnan(grad[30:34]))
+    assert (np.nan_to_num(np.abs(g0 - grad[30:34])) <= 1e-6 * rowscale[30:34]).all()
     lit = gabs > 0
     print(f"{role} {mode}: {rows.size} rows, {int(lit.sum())} cells with a path, {int(np.isnan(grad).any(-1).sum())} NaN cells, "
           f"worst error / bar {worst:.3f}; max |grad| {float(np.nanmax(np.abs(grad))):.3e}")

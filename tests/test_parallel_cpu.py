@@ -50,7 +50,8 @@ def _worker(rank, world, port, q):
         import torch.distributed as dist
 
         from conftest import random_scene, unit_grid
-        from differt2d_amd.parallel import GlooHostComm, sharded_map
+        from differt2d_amd.parallel import sharded_map
+        from gloo_comm import GlooHostComm
         from oracle import c_oracle as CO
 
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -231,7 +232,8 @@ def _sweep_worker(rank, world, port, q):
         torch.set_num_threads(1)
         from conftest import random_scene, unit_grid
         from differt2d_amd.engine import make_params
-        from differt2d_amd.parallel import GlooHostComm, ShardedSweep
+        from differt2d_amd.parallel import ShardedSweep
+        from gloo_comm import GlooHostComm
         from oracle import ref as R
 
         dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -1,13 +1,66 @@
 """Host logic: the NumPy restatement of JAX's Threefry PRNG (differt2d_amd/random.py) against published known answers -- JAX is
 not importable here, so these are what pins it: the Random123 known-answer vectors of Threefry-2x32-20 (also the vectors of
-JAX's own test suite, tests/random_test.py::testThreefry2x32), `random.split(PRNGKey(0))` as printed in JAX's PRNG design note
-(docs/jep/263-prng.md), and `random.uniform(PRNGKey(0))` = 0.41845703 (the value every JAX tutorial shows)."""
+JAX's own test suite, tests/random_test.py::testThreefry2x32); ORIGINAL layout (JAX < 0.5): `random.split(PRNGKey(0))` as
+printed in JAX's PRNG design note (docs/jep/263-prng.md), `random.uniform(PRNGKey(0))` = 0.41845703 and
+`random.normal(PRNGKey(0))` = -0.20584226 (the values every older JAX tutorial shows), `split(PRNGKey(42))` and
+`normal(PRNGKey(42))` = -0.18471177 of the "Pseudorandom numbers" tutorial; PARTITIONABLE layout (the default since JAX 0.5.0,
+i.e. of the jax 0.5.2 the reference locks): `split(key(42))` and `normal(key(42))` = -0.028304616 of the same tutorial since."""
 
 import numpy as np
+import pytest
 
 from differt2d_amd import random as R
 
 U = np.uint32
+
+
+@pytest.fixture(autouse=True)
+def _original_layout_unless_said():
+    """Most known answers below (and the reference's own doctest) were recorded under the original layout."""
+    with R.threefry_partitionable(False):
+        yield
+
+
+def _normal(key):
+    """jax.random.normal(key): sqrt(2) * erf_inv(uniform(key, minval=nextafter(-1, 0), maxval=1))"""
+    from scipy.special import erfinv
+
+    u = R.uniform(key, (), minval=float(np.nextafter(np.float32(-1.0), np.float32(0.0))), maxval=1.0)
+    return float(np.float32(np.sqrt(2.0)) * np.float32(erfinv(np.float64(u))))
+
+
+def test_both_layouts_against_the_jax_tutorials_known_answers():
+    k42, k0 = R.PRNGKey(42), R.PRNGKey(0)
+    with R.threefry_partitionable(False):
+        assert R.split(k42).tolist() == [[2465931498, 3679230171], [255383827, 267815257]]
+        assert abs(_normal(k42) - (-0.18471177)) < 1e-7 and abs(_normal(k0) - (-0.20584226)) < 1e-7
+    with R.threefry_partitionable(True):
+        assert R.split(k42).tolist() == [[1832780943, 270669613], [64467757, 2916123636]]
+        assert abs(_normal(k42) - (-0.028304616)) < 1e-8 and abs(_normal(k0) - 1.6226422) < 2e-7
+        # the layout itself: counter = (high, low) word of the flat index, bits = y0 ^ y1, split = (y0, y1) per index
+        y0, y1 = R.threefry2x32(k42, np.zeros(5, U), np.arange(5, dtype=U))
+        assert R.random_bits(k42, (5,)).tolist() == (y0 ^ y1).tolist()
+        assert R.split(k42, 5).tolist() == np.stack([y0, y1], -1).tolist()
+        assert R.uniform(k42, (3, 2)).ravel().tolist() == R.uniform(k42, (6,)).tolist()
+        u = R.uniform(k42, (1000,))
+        assert u.min() >= 0.0 and u.max() < 1.0 and 0.45 < u.mean() < 0.55
+
+
+def test_default_layout_is_the_locked_jax_s():
+    """The reference's uv.lock pins jax 0.5.2, whose default is the partitionable layout (switched on in 0.5.0)."""
+    import importlib
+    import os
+
+    old = os.environ.pop("D2D_THREEFRY_PARTITIONABLE", None)
+    try:
+        assert importlib.reload(R)._PARTITIONABLE is True
+        os.environ["D2D_THREEFRY_PARTITIONABLE"] = "0"
+        assert importlib.reload(R)._PARTITIONABLE is False
+    finally:
+        os.environ.pop("D2D_THREEFRY_PARTITIONABLE", None)
+        if old is not None:
+            os.environ["D2D_THREEFRY_PARTITIONABLE"] = old
+        importlib.reload(R)
 
 
 def test_block_function_known_answers():
