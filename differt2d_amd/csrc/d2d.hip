@@ -183,6 +183,9 @@ struct d2d_ctx {
 #ifdef D2D_AB_TIMELINE
     DevBuf<unsigned> d_timeline;
     long long timeline_n = 0;
+    DevBuf<unsigned long long> d_tl_ring;
+    bool tl_ring_on = false;
+    long long tl_seq = 0;
 #endif
     DevBuf<unsigned> d_cost;            // what every patch cost in the last culled sweep of this grid (ticks >> 6)
     long long cost_tiles = 0;           // 0 = no history (scene, grid or candidate mask changed since)
@@ -1706,12 +1709,21 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         if (!a.rl || d_stats) wpb = 1;
         const dim3 g((grid_fwd.x + wpb - 1) / wpb, wpb);
 #ifdef D2D_AB_TIMELINE  // diagnostic build: one start / end stamp per workgroup, read back by d2d_debug_get_work
-        if ((rc = c->d_timeline.ensure(2 * (size_t)grid_fwd.x + 64))) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_timeline.p, 0, (2 * (size_t)grid_fwd.x + 64) * sizeof(unsigned), c->stream));
-        c->timeline_n = 2 * (long long)grid_fwd.x;
-        if (!d_stats) a.grad = reinterpret_cast<float*>(c->d_timeline.p);
+        if (c->tl_ring_on) {
+            // ... or only the first start / the end of every launch (an unperturbed pipelined sequence: scripts/launch_gaps.py)
+            a.tl_ring = c->d_tl_ring.p;
+            a.tl_seq = (int)(c->tl_seq++);
+        } else {
+            if ((rc = c->d_timeline.ensure(2 * (size_t)grid_fwd.x + 64))) return rc;
+            HIP_TRY(hipMemsetAsync(c->d_timeline.p, 0, (2 * (size_t)grid_fwd.x + 64) * sizeof(unsigned), c->stream));
+            c->timeline_n = 2 * (long long)grid_fwd.x;
+            if (!d_stats) a.grad = reinterpret_cast<float*>(c->d_timeline.p);
+        }
 #endif
         HIP_TRY(d2d::launch_fwd(mode, a.rl != nullptr, d_stats != nullptr, p->max_order, g, tab_lds + (wpb - 1) * 512, c->stream, a));
+#ifdef D2D_AB_TIMELINE
+        if (c->tl_ring_on) hipLaunchKernelGGL(d2d::tl_end_kernel, dim3(1), dim3(1), 0, c->stream, c->d_tl_ring.p, a.tl_seq);
+#endif
     }
     if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
         d2d::SweepArgs af = a;
@@ -1853,6 +1865,19 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
         c->fwd_waves = value;
     }
     else if (!strcmp(name, "pair_masks")) c->use_pair_masks = value != 0;
+#ifdef D2D_AB_TIMELINE
+    else if (!strcmp(name, "tl_ring")) {
+        c->tl_ring_on = value != 0;
+        c->tl_seq = 0;
+        if (c->tl_ring_on) {
+            int rc2 = c->d_tl_ring.ensure(512);
+            if (rc2) return rc2;
+            std::vector<unsigned long long> init(512);
+            for (int i = 0; i < 256; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+            HIP_TRY(hipMemcpy(c->d_tl_ring.p, init.data(), 512 * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        }
+    }
+#endif
     else if (!strcmp(name, "nan_scan")) {
         if (value < 0 || value > 2) return fail(D2D_ERR_INVALID, "nan_scan must be 0 (off), 1 (two levels) or 2 (one wave per patch), got %lld", (long long)value);
         c->nan_scan = value != 0;
@@ -1911,6 +1936,12 @@ int d2d_debug_get_work(d2d_ctx* c, uint32_t* work, int64_t n) {
     int rc = set_device(c);
     if (rc) return rc;
 #ifdef D2D_AB_TIMELINE
+    if (n == -7) {  // the launches' ring: 256 x {first start, end} as 1024 words
+        if (!c->d_tl_ring.p) return fail(D2D_ERR_STATE, "tl_ring is off");
+        HIP_TRY(hipMemcpyAsync(work, c->d_tl_ring.p, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return (int)0;
+    }
     if (n < 0) {  // the stamps of the last forward launch's workgroups (work[0 .. min(-n, timeline_n))
         const long long m = std::min<long long>(-n, c->timeline_n);
         HIP_TRY(hipMemcpyAsync(work, c->d_timeline.p, (size_t)m * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));

@@ -168,6 +168,10 @@ struct SweepArgs {
     int* __restrict__ heavy_done;     // [n_heavy] quarters finished (zero between launches)
     unsigned* __restrict__ cost_out;  // [n_patches] work this patch took (feeds the next launch's schedule), or null
 
+#ifdef D2D_AB_TIMELINE
+    unsigned long long* tl_ring;  // diagnostic build: [256][2] first start / end (100 MHz real-time counter) of the last 256 forward launches
+    int tl_seq;
+#endif
     unsigned long long* stats; // [D2D_NUM_STATS] executed-work counters (STATS build only), may be null
     unsigned long long* wave_cycles;  // [n_patches] shader clock ticks spent per patch (STATS build only), may be null
 };
@@ -1873,6 +1877,7 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
     const long tile = from_queue ? b0 : (a.sched ? (long)a.sched[tile0] : tile0);
 #ifdef D2D_AB_TIMELINE
     const unsigned long long t_line0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, common to all XCDs
+    if (a.tl_ring && lane == 0 && !from_queue && b0_in == 0) a.tl_ring[2 * (a.tl_seq & 255)] = t_line0;  // (workgroup 0 starts first, or nearly so)
 #endif
     const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     const int tcol = (int)(tile % tiles_x), trow = (int)(tile / tiles_x);
@@ -3110,6 +3115,10 @@ __global__ void __launch_bounds__(256) region_box_kernel(const float* __restrict
     }
 }
 
+#ifdef D2D_AB_TIMELINE
+// (the launch's end: a one-thread kernel behind the sweep on its stream -- 21 000 atomics on one word took 340 us)
+__global__ void tl_end_kernel(unsigned long long* __restrict__ ring, int seq) { ring[2 * (seq & 255) + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 // The lists' descriptor as the sweep kernels read it (a.rl), written in stream order from a by-value argument.
 __global__ void write_region_lists_kernel(RegionLists* __restrict__ dst, RegionLists v) { *dst = v; }
 
