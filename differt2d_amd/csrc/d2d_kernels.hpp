@@ -3011,12 +3011,15 @@ __global__ void __launch_bounds__(256) patch_order_kernel(const unsigned char* _
 }
 
 // The two passes above in ONE workgroup (launches of up to SORT1_MAX patches: 1024^2 has 16 384): keys, histogram, offsets and
-// scatter all in LDS, nothing to zero beforehand and nothing for a second kernel to wait for.  Each of the 16 waves counts
-// into its own 256 bins, so a wave's atomics only contend with themselves; within a key the patches are placed wave by wave
-// (wave w takes the patches t with (t / 64) % 16 == w), inside a wave in atomic order: the schedule may differ from run to
-// run, the results cannot.  Beside a sweep that fills the chip this is one workgroup of 1024 threads instead of 2 x 16 of 256.
+// scatter all in LDS, nothing to zero beforehand and nothing for a second kernel to wait for.  Each wave counts into its own 256
+// bins, so a wave's atomics only contend with themselves; within a key the patches are placed wave by wave, inside a wave in
+// atomic order: the schedule may differ from run to run, the results cannot.
 constexpr int SORT1_THREADS = 1024;
+constexpr int SORT1_BATCH = 16;  // loads in flight per thread
 constexpr long SORT1_MAX = 1 << 16;
+// Round 4: the patches' work counters / keys are fetched sixteen at a time per thread (the plain loop was one dependent round
+// trip to memory per patch).  (Four waves instead of sixteen -- a 1024-thread workgroup needs sixteen free wave slots on ONE CU,
+// beside a sweep that fills the chip -- were measured too: 48 us against 20, the kernel is as fast as it has waves.)
 __global__ void __launch_bounds__(SORT1_THREADS) patch_sort_kernel(unsigned char* __restrict__ key, const unsigned* __restrict__ cost,
                                                                    int* __restrict__ sched, long n_tiles, const RegionLists* __restrict__ lists,
                                                                    int tiles_x, int k_lo, int k_hi) {
@@ -3027,25 +3030,43 @@ __global__ void __launch_bounds__(SORT1_THREADS) patch_sort_kernel(unsigned char
     for (int i = threadIdx.x; i < W * SCHED_KEYS; i += SORT1_THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
     // pass 1: keys (work history, list lengths, or given) and per-wave histograms
-    for (long t = threadIdx.x; t < n_tiles; t += SORT1_THREADS) {
-        unsigned char k;
-        if (lists) {
-            const int R = lists->leaf.R;
-            const long region = (long)((int)(t / tiles_x) / R) * lists->leaf.regions_x + ((int)(t % tiles_x) / R);
-            unsigned len = 4;
-            for (int o = k_lo; o <= k_hi; ++o) {
-                const int c = lists->leaf.cnt[o][region];
-                len += c > 0 ? (unsigned)c : 0u;
+    for (long t0 = 0; t0 < n_tiles; t0 += (long)SORT1_THREADS * SORT1_BATCH) {
+        unsigned v[SORT1_BATCH];
+#pragma unroll
+        for (int i = 0; i < SORT1_BATCH; ++i) {
+            const long t = t0 + (long)i * SORT1_THREADS + threadIdx.x;
+            v[i] = 0u;
+            if (t < n_tiles) {
+                if (lists) {
+                    const int R = lists->leaf.R;
+                    const long region = (long)((int)(t / tiles_x) / R) * lists->leaf.regions_x + ((int)(t % tiles_x) / R);
+                    unsigned len = 4;
+                    for (int o = k_lo; o <= k_hi; ++o) {
+                        const int c = lists->leaf.cnt[o][region];
+                        len += c > 0 ? (unsigned)c : 0u;
+                    }
+                    v[i] = len << 4;
+                } else if (cost) {
+                    v[i] = cost[t];
+                } else {
+                    v[i] = key[t];
+                }
             }
-            k = key_from_cost(len << 4);
-            key[t] = k;
-        } else if (cost) {
-            k = key_from_cost(cost[t]);
-            key[t] = k;
-        } else {
-            k = key[t];
         }
-        atomicAdd(&cnt[wv][k], 1);
+#pragma unroll
+        for (int i = 0; i < SORT1_BATCH; ++i) {
+            const long t = t0 + (long)i * SORT1_THREADS + threadIdx.x;
+            if (t < n_tiles) {
+                unsigned char k;
+                if (lists || cost) {
+                    k = key_from_cost(v[i]);
+                    key[t] = k;
+                } else {
+                    k = (unsigned char)v[i];
+                }
+                atomicAdd(&cnt[wv][k], 1);
+            }
+        }
     }
     __syncthreads();
     // offsets: key descending (dearest first), within a key wave ascending
@@ -3066,7 +3087,19 @@ __global__ void __launch_bounds__(SORT1_THREADS) patch_sort_kernel(unsigned char
     }
     __syncthreads();
     // pass 2: scatter (same thread -> same patches -> same wave as in pass 1)
-    for (long t = threadIdx.x; t < n_tiles; t += SORT1_THREADS) sched[atomicAdd(&cnt[wv][key[t]], 1)] = (int)t;
+    for (long t0 = 0; t0 < n_tiles; t0 += (long)SORT1_THREADS * SORT1_BATCH) {
+        unsigned char k[SORT1_BATCH];
+#pragma unroll
+        for (int i = 0; i < SORT1_BATCH; ++i) {
+            const long t = t0 + (long)i * SORT1_THREADS + threadIdx.x;
+            k[i] = t < n_tiles ? key[t] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int i = 0; i < SORT1_BATCH; ++i) {
+            const long t = t0 + (long)i * SORT1_THREADS + threadIdx.x;
+            if (t < n_tiles) sched[atomicAdd(&cnt[wv][k[i]], 1)] = (int)t;
+        }
+    }
 }
 
 // Bounding boxes of the cells of every region of R x R patches (one 256-thread workgroup per region): {x0, x1, y0, y1},
@@ -3186,8 +3219,12 @@ __device__ __forceinline__ bool shadow_pair_bin(const float4* __restrict__ occl,
         const int sv = fd > 0.0f ? 1 : -1;
         if (sgn == 0) sgn = sv;
         if (sv != sgn) { ok = false; break; }
-        const float ta = fa / fd, tb = fb / fd;
-        const float ea = (errA + 2.0f * errD) / (ad - errD) + 4.0f * eps, eb = (errB + 2.0f * errD) / (ad - errD) + 4.0f * eps;
+        // (reciprocals instead of four correctly rounded divisions per vertex: v_rcp_f32 is good to 1 ulp, a quotient formed
+        // with it to 3 -- |t| <= 1.01 wherever the test can still pass --, and the bounds are rounded up: all inside + 8 eps;
+        // this kernel runs once per launch beside the previous sweep, one dependent chain per wave: 15 -> 8 us)
+        const float rfd = __builtin_amdgcn_rcpf(fd), rin = __builtin_amdgcn_rcpf(ad - errD) * 1.000001f;
+        const float ta = fa * rfd, tb = fb * rfd;
+        const float ea = (errA + 2.0f * errD) * rin + 8.0f * eps, eb = (errB + 2.0f * errD) * rin + 8.0f * eps;
         if (!(ta - ea >= win_lo && ta + ea <= win_hi && tb - eb >= win_lo && tb + eb <= win_hi)) { ok = false; break; }
     }
     return ok;

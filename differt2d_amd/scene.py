@@ -485,10 +485,45 @@ class Scene(Plottable):
             if logic.is_true(valid, approx=approx):
                 yield tx_key, rx_key, path, cand
 
+    def _pairwise_fused(self, fun, fun_args, fun_kwargs, kwargs):
+        """The arguments of a fused pairwise sweep -- the receivers of the scene as a 1 x R grid, one launch per transmitter --
+        or None when ``fun`` is not one of the natively fused closed forms (then: GPU trace + host ``fun``)."""
+        kwargs = dict(kwargs)
+        path_cls = kwargs.pop("path_cls", ImagePath)
+        path_cls_kwargs = kwargs.pop("path_cls_kwargs", None)
+        min_order, max_order, order = kwargs.pop("min_order", 0), kwargs.pop("max_order", 1), kwargs.pop("order", None)
+        filter_objects, key = kwargs.pop("filter_objects", None), kwargs.pop("key", None)
+        native, common = self._sweep_params(fun, fun_args, fun_kwargs, path_cls, path_cls_kwargs, min_order, max_order, order, kwargs)
+        if native is None or not self.receivers or not self.transmitters:
+            return None
+        name, extra = native
+        cands = None
+        if self._solver_of(path_cls) != "image":
+            cands = self.all_path_candidates(min_order, max_order, order=order, filter_objects=filter_objects)
+        sextra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, cands or [], key)
+        rx = np.stack([r.xy for r in self.receivers.values()]).astype(F)
+        return dict(params={"fun": name, **extra, **sextra, **common}, theta0=theta0, filter_objects=filter_objects,
+                    X=np.ascontiguousarray(rx[None, :, 0]), Y=np.ascontiguousarray(rx[None, :, 1]))
+
     def accumulate_over_paths(self, fun: PathFun, fun_args: tuple = (), fun_kwargs: Optional[Mapping] = None, *,
                               reduce_all: bool = False, **kwargs):
-        """Sum of ``valid * fun(...)`` over all candidates, per (tx, rx) pair (reference scene.py:1272-1334)."""
+        """Sum of ``valid * fun(...)`` over all candidates, per (tx, rx) pair (reference scene.py:1272-1334).  A natively
+        fused ``fun`` runs as one fused launch per transmitter over the receivers (a 1 x R grid): the reference's sequential
+        fp32 sum in candidate order, as everywhere; any other callable is evaluated on the host from the traced paths."""
         fun_kwargs = dict(fun_kwargs or {})
+        fused = self._pairwise_fused(fun, fun_args, fun_kwargs, kwargs)
+
+        def fused_results():
+            ctx = self._ctx()
+            for tx_key, tx in self.transmitters.items():
+                self._upload(ctx, fused["filter_objects"])
+                ctx.set_grid(fused["X"], fused["Y"])
+                if fused["theta0"] is not None:
+                    ctx.set_theta0(fused["theta0"])
+                ctx.launch(make_params(**fused["params"]), tx.xy)
+                row = ctx.get_map()[0]
+                for j, rx_key in enumerate(self.receivers):
+                    yield tx_key, rx_key, F(row[j])
 
         def results():
             for (tx_key, rx_key), group in groupby(self.all_paths(**kwargs), operator.itemgetter(slice(2))):
@@ -499,12 +534,66 @@ class Scene(Plottable):
                     acc = F(acc + F(valid) * F(fun(tx, rx, path, inter, *fun_args, **fun_kwargs)))
                 yield tx_key, rx_key, acc
 
+        gen = fused_results if fused is not None else results
         if reduce_all:
             Z = F(0.0)
-            for _, _, p in results():
+            for _, _, p in gen():
                 Z = F(Z + p)
             return Z
-        return results()
+        return gen()
+
+    def accumulate_over_paths_value_and_vjp(self, fun: PathFun, fun_args: tuple = (), fun_kwargs: Optional[Mapping] = None, *,
+                                            cotangent=None, **kwargs):
+        """``accumulate_over_paths`` with its reverse-mode derivatives -- what users of the reference obtain by wrapping the call
+        in ``jax.value_and_grad`` (examples/plot_power_optimize.py:78-93: ``loss(tx_coords, scene)`` over
+        ``scene.accumulate_over_paths(...)``).  ``fun`` must be natively fused.
+
+        ``cotangent``: the derivative of the caller's scalar objective w.r.t. each accumulated value -- a mapping
+        ``{(tx name, rx name): weight}`` (missing pairs: 0), or a callable that receives the values' mapping and returns such a
+        mapping (so that ``objective(values)``'s own derivative can be formed in between: one forward launch, one reverse
+        launch); default: ones, i.e. the gradient of the ``reduce_all`` sum.
+
+        Returns ``(values, vjp)``: ``values[(tx name, rx name)]`` as ``accumulate_over_paths`` yields them, and ``vjp`` with
+        ``"transmitters"[tx name]`` = d objective / d tx.xy, ``"receivers"[rx name]`` = d objective / d rx.xy, ``"objects"`` =
+        d objective / d xys ``[N, 2, 2]`` and ``"phi"`` ``[N]`` (RIS angles; MinPath / FermatPath sweeps)."""
+        fun_kwargs = dict(fun_kwargs or {})
+        fused = self._pairwise_fused(fun, fun_args, fun_kwargs, kwargs)
+        if fused is None:
+            raise L.D2DUnsupported(-4, "the VJP needs transmitters, receivers and a natively fused fun (differt2d_amd.utils): an "
+                                       "arbitrary Python callable cannot be differentiated by the hand-derived kernels")
+        ctx = self._ctx()
+        rx_keys = list(self.receivers)
+        params = make_params(**fused["params"])
+        values = {}
+        if callable(cotangent) or cotangent is None:
+            for tx_key, tx in self.transmitters.items():
+                self._upload(ctx, fused["filter_objects"])
+                ctx.set_grid(fused["X"], fused["Y"])
+                if fused["theta0"] is not None:
+                    ctx.set_theta0(fused["theta0"])
+                ctx.launch(params, tx.xy)
+                row = ctx.get_map()[0]
+                values.update({(tx_key, k): F(row[j]) for j, k in enumerate(rx_keys)})
+        cot = cotangent(dict(values)) if callable(cotangent) else cotangent
+        n = len(self.objects)
+        vjp = {"transmitters": {}, "receivers": {k: np.zeros(2, F) for k in rx_keys}, "objects": np.zeros((n, 2, 2), F), "phi": np.zeros(n, F)}
+        for tx_key, tx in self.transmitters.items():
+            w = np.ones((1, len(rx_keys)), F) if cot is None else np.array([[cot.get((tx_key, k), 0.0) for k in rx_keys]], F)
+            self._upload(ctx, fused["filter_objects"])
+            ctx.set_grid(fused["X"], fused["Y"])
+            ctx.set_cotangent(w)
+            if fused["theta0"] is not None:
+                ctx.set_theta0(fused["theta0"])
+            ctx.launch_vg(params, tx.xy, scene_vjp=True)
+            row, g = ctx.get_map()[0], ctx.get_grad_rx()[0]
+            tx_bar, objects_bar, phi_bar = ctx.get_scene_vjp(with_phi=True)
+            values.update({(tx_key, k): F(row[j]) for j, k in enumerate(rx_keys)})
+            vjp["transmitters"][tx_key] = tx_bar
+            for j, k in enumerate(rx_keys):
+                vjp["receivers"][k] = (vjp["receivers"][k] + w[0, j] * g[j]).astype(F)
+            vjp["objects"] = (vjp["objects"] + objects_bar).astype(F)
+            vjp["phi"] = (vjp["phi"] + phi_bar).astype(F)
+        return values, vjp
 
     # ------------------------------------------------------------------------ grid sweeps
     def _sweep_params(self, fun, fun_args, fun_kwargs, path_cls, path_cls_kwargs, min_order, max_order, order, kwargs):

@@ -141,6 +141,59 @@ def test_accumulate_over_paths():
     np.testing.assert_allclose(total, 6.0, rtol=1e-6)
 
 
+@pytest.mark.parametrize("approx", [False, True])
+def test_accumulate_over_paths_value_and_vjp_like_plot_power_optimize(approx):
+    """examples/plot_power_optimize.py:60-93, 207-226 transcribed: `loss(tx_coords, scene)` = -min over the receivers of
+    (accumulated power / P0), and `jax.value_and_grad(loss)` w.r.t. the transmitter's coordinates -- here one forward launch
+    over the receivers (a 1 x R grid), the objective's own derivative on the host, one reverse launch -- against reverse-mode
+    autodiff of the oracle (torch, fp64) of the same loss; also the fused values against the traced-paths + host-fun route."""
+    import torch
+
+    from differt2d_amd.geometry import Point
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import P0, received_power
+    from oracle import ref as R
+
+    scene = Scene.square_scene_with_obstacle()
+    scene = scene.with_transmitters(tx=Point(xy=np.array([0.5, 0.7], F)))
+    scene = scene.with_receivers(rx_0=Point(xy=np.array([0.3, 0.1], F)), rx_1=Point(xy=np.array([0.5, 0.1], F)),
+                                 rx_2=Point(xy=np.array([0.83, 0.41], F)))
+    kw = dict(max_order=1, approx=approx, alpha=50.0)  # (max_order = 1: the hard mode's zero-gradient zone is avoided, as the example notes)
+
+    def cot_of(values):  # d loss / d value: -1 / P0 for the receiver with the smallest power (jnp.minimum in a left fold)
+        worst = min(values, key=lambda k: float(values[k]))
+        return {worst: -1.0 / P0}
+
+    values, vjp = scene.accumulate_over_paths_value_and_vjp(received_power, cotangent=cot_of, **kw)
+    plain = {(a, b): v for a, b, v in scene.accumulate_over_paths(received_power, **kw)}
+    assert list(values) == list(plain) == [("tx", "rx_0"), ("tx", "rx_1"), ("tx", "rx_2")]
+    assert all(values[k] == plain[k] for k in plain)
+    host_fun = lambda t, r, p, o: received_power(t, r, p, o)  # noqa: E731 -- not fused: GPU trace + host fun
+    host_fun._d2d_native = False
+    slow = {(a, b): v for a, b, v in scene.accumulate_over_paths(host_fun, **kw)}
+    np.testing.assert_allclose([values[k] for k in plain], [slow[k] for k in plain], rtol=2e-6)
+    loss = -min(float(v) for v in values.values()) / P0
+
+    # the oracle's loss under torch autodiff
+    tb = R.TorchBackend("float64")
+    walls = tb.asarray(_scene_walls(scene)).clone().requires_grad_(True)
+    tx = tb.asarray(scene.transmitters["tx"].xy).clone().requires_grad_(True)
+    rx = np.stack([r.xy for r in scene.receivers.values()])
+    Z = R.power_map(walls, tx, rx[None, :, 0], rx[None, :, 1], min_order=0, max_order=1, approx=approx, alpha=50.0, xp=tb)[0]
+    want_loss = -(Z / P0).min()
+    g_tx, g_walls = torch.autograd.grad(want_loss, [tx, walls])
+    assert abs(loss - float(want_loss)) <= 2e-6 * abs(float(want_loss))
+    got_tx = vjp["transmitters"]["tx"]
+    assert np.isfinite(got_tx).all() and np.abs(g_tx.numpy()).max() > 0
+    np.testing.assert_allclose(got_tx, g_tx.numpy(), rtol=2e-5, atol=2e-5 * float(np.abs(g_tx.numpy()).max()))
+    np.testing.assert_allclose(vjp["objects"], g_walls.numpy(), rtol=2e-5, atol=2e-5 * float(np.abs(g_walls.numpy()).max()))
+    # default cotangent: the gradient of the reduce_all sum
+    values1, vjp1 = scene.accumulate_over_paths_value_and_vjp(received_power, **kw)
+    g1, = torch.autograd.grad(Z.sum(), [tx])
+    np.testing.assert_allclose(vjp1["transmitters"]["tx"], g1.numpy(), rtol=2e-5, atol=2e-5 * float(np.abs(g1.numpy()).max()))
+    assert np.isclose(sum(float(v) for v in values1.values()), float(scene.accumulate_over_paths(received_power, reduce_all=True, **kw)), rtol=1e-6)
+
+
 @pytest.mark.parametrize("native", ["tagged", "recognised", "host"])
 def test_accumulate_on_receivers_grid_los(native):
     # tests/test_scene.py:558-627, with the test's own local `fun` ("recognised": the reference's call pattern as written,

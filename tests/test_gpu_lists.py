@@ -126,12 +126,14 @@ def test_value_and_grad_with_lists():
             a, b = on.value_and_grads(tx, X, Y, **kw), off.value_and_grads(tx, X, Y, **kw)
             assert on.debug_region_stats()["leaf_regions"] > 0
         assert _same(a["value"], b["value"])
-        # gradients: where both are finite they are the same sums of the same terms; a NaN artefact of a candidate that
-        # the culling proves invalid may be seen by one launch and not by the other (DESIGN.md "NaN parity")
+        # gradients: the same sums of the same terms, and the same NaN positions -- the reference's autodiff artefacts come from
+        # the NaN scan, whatever the lists did (DESIGN.md "NaN parity"; one NaN cell makes the summed scene VJP NaN, as in the
+        # reference)
         for k in ("grad_rx", "tx_bar", "walls_bar"):
+            assert np.array_equal(np.isnan(a[k]), np.isnan(b[k])), k
             both = np.isfinite(a[k]) & np.isfinite(b[k])
             assert np.array_equal(a[k][both], b[k][both]), k
-            assert both.mean() > 0.9, k
+        assert np.isfinite(a["grad_rx"]).mean() > 0.9
 
 
 @pytest.mark.parametrize("approx", [False, True])
@@ -159,8 +161,10 @@ def test_tx_grid_lists_change_no_bit(approx):
         assert _same(a, b) and _same(a, want), (lo, hi)
         assert _same(ga["value"], a)
         for k in ("grad_rx", "tx_bar", "walls_bar"):
+            assert np.array_equal(np.isnan(ga[k]), np.isnan(gb[k])), k
             both = np.isfinite(ga[k]) & np.isfinite(gb[k])
-            assert np.array_equal(ga[k][both], gb[k][both]) and both.mean() > 0.9, k
+            assert np.array_equal(ga[k][both], gb[k][both]), k
+        assert np.isfinite(ga["grad_rx"]).mean() > 0.9
     # a cell that is not finite: its patch (and its region's) go to the enumerating TX-grid kernel
     X[3, 4] = np.nan
     with _ctx() as on, _ctx(region_lists=0) as off:

@@ -51,12 +51,12 @@ def test_golden_fixtures(path):
     _check(grad, np.asarray(d["grad_rx"], np.float64), os.path.basename(path))
 
 
-@pytest.mark.parametrize("role", ["rx", "tx"])
 @pytest.mark.parametrize("approx,function", [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")])
-@pytest.mark.parametrize("fun", ["received_power", "length_squared", "length", "one"])
+@pytest.mark.parametrize("role,fun", [("rx", "received_power"), ("rx", "length_squared"), ("rx", "length"), ("rx", "one"),
+                                      ("tx", "received_power"), ("tx", "length")])
 def test_live_autodiff(approx, function, fun, role):
-    tx, walls = random_scene(8, seed=31)
-    X, Y = unit_grid(11, 9)
+    tx, walls = random_scene(6, seed=31)
+    X, Y = unit_grid(9, 7)
     kw = dict(min_order=0, max_order=2, approx=approx, function=function, fun=fun)
     want = R.power_map_value_and_grads(walls, tx, X, Y, dtype="float64", grid_role=role, **kw)
     want32 = R.power_map_value_and_grads(walls, tx, X, Y, dtype="float32", grid_role=role, **kw)
