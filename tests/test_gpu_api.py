@@ -181,7 +181,7 @@ def test_accumulate_over_paths_value_and_vjp_like_plot_power_optimize(approx):
     rx = np.stack([r.xy for r in scene.receivers.values()])
     Z = R.power_map(walls, tx, rx[None, :, 0], rx[None, :, 1], min_order=0, max_order=1, approx=approx, alpha=50.0, xp=tb)[0]
     want_loss = -(Z / P0).min()
-    g_tx, g_walls = torch.autograd.grad(want_loss, [tx, walls])
+    g_tx, g_walls = torch.autograd.grad(want_loss, [tx, walls], retain_graph=True)
     assert abs(loss - float(want_loss)) <= 2e-6 * abs(float(want_loss))
     got_tx = vjp["transmitters"]["tx"]
     assert np.isfinite(got_tx).all() and np.abs(g_tx.numpy()).max() > 0

@@ -250,11 +250,17 @@ def test_cfg3_rows_against_the_c_gradient_oracle(role, mode):
     rowscale = np.nanmax(np.abs(grad), axis=(1, 2), keepdims=True)
     bar = 1e-5 * gabs[..., None] + 1e-5 * np.abs(grad) + 1e-6 * rowscale
     worst = float(np.nanmax(np.where(fin, err / bar, 0.0)))
-    # the oracle's exact shortcut (prune) against its plain evaluation on four rows around the transmitter: the same NaN
-    # cells, the same gradients up to those ties
-    v0, g0 = CO.power_map_grad(walls, tx, X[rows[30:34]], Y[rows[30:34]], min_order=0, max_order=2, prune=0, grid_role=role, **kw)
+    # the oracle's shortcut (prune) against its plain evaluation on four rows around the transmitter: the same values, the
+    # same NaN cells, and the same gradients wherever no min / max met a tie between arguments of different derivative (the
+    # shortcut stops at the first occluder saturated to exactly 1; a later one ALSO at exactly 1 with a non-zero derivative
+    # would take half of it under JAX's tie rule -- the kernels stop the same way, DESIGN.md "known deviation")
+    v0, g0, kink = CO.power_map_grad(walls, tx, X[rows[30:34]], Y[rows[30:34]], min_order=0, max_order=2, prune=0,
+                                     grid_role=role, with_kink=True, **kw)
     assert np.array_equal(v0, value[30:34]) and np.array_equal(np.isnan(g0), np.isnan(grad[30:34]))
-    assert (np.nan_to_num(np.abs(g0 - grad[30:34])) <= 1e-6 * rowscale[30:34]).all()
+    smooth = ~kink.astype(bool)[..., None]
+    assert (np.nan_to_num(np.abs(g0 - grad[30:34])) <= bar[30:34])[smooth.repeat(2, -1)].all()
+    assert (np.nan_to_num(np.abs(g0 - g[30:34])) <= bar[30:34])[smooth.repeat(2, -1)].all()
+    print(f"{role} {mode}: plain oracle on 4 rows: {int(kink.sum())} tie cells of {kink.size} left out")
     lit = gabs > 0
     print(f"{role} {mode}: {rows.size} rows, {int(lit.sum())} cells with a path, {int(np.isnan(grad).any(-1).sum())} NaN cells, "
           f"worst error / bar {worst:.3f}; max |grad| {float(np.nanmax(np.abs(grad))):.3e}")

@@ -96,18 +96,29 @@ def test_ris_vertex_sweep_matches_oracle(path_cls_name, steps, approx):
                solver={"MinPath": "min", "FermatPath": "fermat"}[path_cls_name])
     want = R.power_map(None, scene.transmitters["tx"].xy, X, Y, **okw)
     want64 = R.power_map(None, scene.transmitters["tx"].xy, X, Y, xp=R.NUMPY64, **okw)
+    up = lambda a: np.nextafter(np.asarray(a, F), F(np.inf))  # noqa: E731
+    want_n = R.power_map(None, up(scene.transmitters["tx"].xy), up(X), up(Y), **okw)  # the fp32 oracle from inputs nudged by one ulp
     assert got.shape == X.shape
-    scale = np.abs(want).max()
-    # Hundreds of sequential fp32 Adam steps are not reproducible to the last bit across two gradient
-    # implementations, and ill-conditioned cells (RX next to a wall) amplify that: the oracle run in fp64 differs
-    # from the oracle run in fp32 in those very cells.  Bar: on the cells where the oracle is stable (fp32 ~ fp64)
-    # the kernel must agree with it (>= 90 %; typically 95-100 %), and overall it must not be more unstable than the oracle itself.
-    stable = np.isclose(want, want64, rtol=2e-3, atol=2e-3 * scale)
-    close = np.isclose(got, want, rtol=2e-3, atol=2e-3 * scale)
+    scale = np.abs(want64).max()
+    # Hundreds of sequential fp32 Adam steps are not reproducible to the last bit across two gradient implementations, and
+    # ill-conditioned cells (a receiver next to a wall) amplify that: there the oracle run in fp64 differs from the oracle run
+    # in fp32, and from the oracle run in fp32 on inputs one ulp away.  Where the oracle is well conditioned -- its three runs
+    # agree to 2e-3: an oracle-only mask -- the kernel is held to the bar of the image-method gradients (round 4, VERDICT r3
+    # item 7): within 1e-5 of the scale (+ 1e-5 relative) of the fp64 oracle, or within twice the oracle's own fp32 distance
+    # from it.  Elsewhere it must not be more unstable than the oracle itself.
+    ref = np.maximum(np.abs(want - want64), np.abs(want_n - want64))
+    stable = ref <= 2e-3 * scale + 2e-3 * np.abs(want64)
+    err = np.abs(got - want64)
+    tight = np.maximum(1e-5 * scale + 1e-5 * np.abs(want64), 2.0 * ref)
     assert stable.mean() >= 0.7
-    assert close[stable].mean() >= 0.90, f"{(~close[stable]).sum()} of {stable.sum()} stable cells differ"
+    bad = stable & (err > tight)
+    assert not bad.any(), (f"{int(bad.sum())} of {int(stable.sum())} well-conditioned cells beyond the bar: "
+                           f"{[(tuple(int(v) for v in i), float(got[tuple(i)]), float(want64[tuple(i)])) for i in np.argwhere(bad)[:5]]}")
+    close = np.isclose(got, want, rtol=2e-3, atol=2e-3 * scale)
     assert (~close).sum() <= 2 * (~stable).sum() + 0.05 * close.size
-    assert np.median(np.abs(got - want)) <= 1e-4 * scale
+    assert np.median(err) <= 1e-6 * scale
+    print(f"{path_cls_name} steps={steps} approx={approx}: {int(stable.sum())} of {stable.size} cells well conditioned, worst error / bar there "
+          f"{float((err / tight)[stable].max()):.2f}, median error {float(np.median(err)) / scale:.1e} of the scale")
 
 
 def test_all_paths_with_minpath_and_key():
@@ -431,8 +442,8 @@ def test_cfg5_full_size_value_and_gradient_on_sampled_cells():
         supporting lines -- and across the RIS's end points (tests/golden/cfg5_edges.npz, scripts/make_golden_cfg5_edges.py).
 
     `stable` (both fixtures) = the ORACLE's own fp32 run agrees with its fp64 run; it never looks at the GPU.  On those cells:
-    NaN positions identical to the fp32 oracle's, value within 2e-3, per-cell gradient and every entry of the scene VJP within
-    the image-method bar (_tight).  No conditional assertion.  On the other cells the derivative through 1000 Adam steps is
+    NaN positions identical to the fp32 oracle's, value, per-cell gradient and every entry of the scene VJP within
+    the image-method bar (_tight: 1e-5 of the scale, or twice the oracle's own fp32-vs-fp64 distance).  No conditional assertion.  On the other cells the derivative through 1000 Adam steps is
     ill conditioned in the reference itself (next to the corners its fp32 gradients reach 1e30 and overflow to NaN in
     neighbouring cells, and which neighbour overflows depends on the last bit of the hand-derived vs the autodiff objective
     gradient): there the assertion is that the GPU is no less finite than the reference -- the same share of cells."""
@@ -469,7 +480,12 @@ def test_cfg5_full_size_value_and_gradient_on_sampled_cells():
         # NaN positions on the well-conditioned cells: the fp32 reference chain's (none: a stable cell has a finite gradient)
         assert np.array_equal(np.isnan(got_g[stable]), np.isnan(g32[stable])) and np.isfinite(got_g[stable]).all(), (
             f"{name}: non-finite GPU gradient in well-conditioned cells {cells[stable][~np.isfinite(got_g[stable]).all(-1)].tolist()}")
-        np.testing.assert_allclose(got_v[stable], v64[stable], rtol=2e-3, atol=2e-3 * scale, err_msg=name)
+        # values on the well-conditioned cells: the bar of the image-method sweeps (round 4) -- 1e-5 of the scale (+ 1e-5
+        # relative) from the fp64 oracle, or twice the oracle's own fp32 distance from it
+        verr = np.abs(got_v - v64)[stable]
+        vbar = np.maximum(1e-5 * scale + 1e-5 * np.abs(v64), 2.0 * np.abs(v32 - v64))[stable]
+        print(f"   {name}: value max err / bar {float((verr / vbar).max()):.2f}, max err / scale {float(verr.max()) / scale:.2e}")
+        assert (verr <= vbar).all(), f"{name}: {int((verr > vbar).sum())} values beyond the bar on well-conditioned cells {cells[stable][verr > vbar][:5].tolist()}"
         # per-cell gradient: each cell against its own gradient scale (the cells differ by orders of magnitude)
         fin = np.isfinite(g64).all(-1)
         gscale = np.maximum(np.abs(np.nan_to_num(g64)).max(-1), np.median(np.abs(g64[fin]).max(-1)))[:, None]
