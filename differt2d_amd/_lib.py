@@ -21,12 +21,12 @@ LIB_PATH = os.environ.get("D2D_LIB") or os.path.join(CSRC, "libd2d.so")
 D2D_MAX_ORDER = 4
 D2D_NUM_STATS = 16
 D2D_COMM_ID_BYTES = 128
-D2D_ABI_VERSION = 7
+D2D_ABI_VERSION = 8
 
 D2D_WALL, D2D_RIS, D2D_VERTEX = 0, 1, 2
 SOLVER_IMAGE, SOLVER_MINPATH, SOLVER_FERMAT = 0, 1, 2
 ACT_HARD_SIGMOID, ACT_SIGMOID = 0, 1
-FUN_RECEIVED_POWER, FUN_LENGTH_SQUARED, FUN_LENGTH, FUN_ONE = 0, 1, 2, 3
+FUN_RECEIVED_POWER, FUN_LENGTH_SQUARED, FUN_LENGTH, FUN_ONE, FUN_CUSTOM = 0, 1, 2, 3, 4
 OUT_OVERWRITE, OUT_ADD = 0, 1
 GRID_RX, GRID_TX = 0, 1
 
@@ -104,6 +104,7 @@ SYMBOLS = [
     ("d2d_set_optimizer", C.c_int, [_ctx, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]),
     ("d2d_power_map_launch", C.c_int, [_ctx, C.POINTER(Params), _f32p]),
     ("d2d_set_cotangent", C.c_int, [_ctx, C.c_void_p]),
+    ("d2d_set_path_fun_values", C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int64]),
     ("d2d_power_map_vg_launch", C.c_int, [_ctx, C.POINTER(Params), _f32p, C.c_int32]),
     ("d2d_get_grad_rx", C.c_int, [_ctx, _f32p]),
     ("d2d_get_scene_vjp", C.c_int, [_ctx, _f32p, C.c_void_p, C.c_void_p]),

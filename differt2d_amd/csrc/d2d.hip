@@ -206,6 +206,8 @@ struct d2d_ctx {
     float scene_absmax = 0.0f;  // max |coordinate| of the objects
     // value+grad
     DevBuf<float> d_grad, d_cot, d_partial;
+    DevBuf<float> d_cust_f, d_cust_pb;  // d2d_set_path_fun_values: a host-evaluated path function, [C][cells] and [C][cells][NP][2]
+    long long cust_C = -1;              // candidates they hold (-1: none); reset by d2d_set_grid
     DevBuf<double> d_vjp;
     bool have_cot = false;
     bool have_vjp = false;   // d_vjp holds the scene VJP of a sweep of the CURRENT scene (4 N + 2 values)
@@ -637,6 +639,7 @@ void d2d_destroy(d2d_ctx* c) {
     c->d_heavy_list.release(); c->d_heavy_cnt.release(); c->d_heavy_done.release();
     c->d_pair.release();
     c->d_grad.release(); c->d_cot.release(); c->d_partial.release(); c->d_vjp.release();
+    c->d_cust_f.release(); c->d_cust_pb.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
@@ -851,6 +854,7 @@ static int set_grid_impl(d2d_ctx* c, const float* X, const float* Y, int32_t m, 
     c->n = n;
     c->have_grid = true;
     c->have_cot = false;
+    c->cust_C = -1;
     c->have_vjp = false;
     c->have_grad = false;  // d_grad (if any) was sized for the previous grid
     c->gathered[0] = c->gathered[1] = 0;
@@ -1066,6 +1070,24 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     if (!c->have_scene) return fail(D2D_ERR_STATE, "d2d_set_scene must come before a sweep");
     if (!c->have_grid) return fail(D2D_ERR_STATE, "d2d_set_grid must come before a sweep");
     c->have_kernel_time = false;  // whatever this launch turns out to be, the previous launch's kernel time is stale
+    d2d_params p_custom;
+    if (p->fun_id == D2D_FUN_CUSTOM) {
+        // a host-evaluated path function (d2d_set_path_fun_values): the exhaustive value+grad kernel walks every candidate in the
+        // reference's order, which is the order the host's rows come in
+        if (!grad_mode || p->solver != D2D_SOLVER_IMAGE)
+            return fail(D2D_ERR_UNSUPPORTED, "fun_id D2D_FUN_CUSTOM is for d2d_power_map_vg_launch with the image solver only");
+        long long want = 0;
+        for (int k = p->min_order; k <= p->max_order; ++k) {
+            long long ck = 1;
+            for (int i = 0; i < k; ++i) ck *= (i == 0) ? (long long)c->cw.size() : (long long)c->cw.size() - 1;
+            want += ck;
+        }
+        if (c->cust_C != want)
+            return fail(D2D_ERR_STATE, "d2d_set_path_fun_values holds %lld candidates, this sweep walks %lld", c->cust_C, want);
+        p_custom = *p;
+        p_custom.strict_nan = 1;
+        p = &p_custom;
+    }
     if (p->solver == D2D_SOLVER_MINPATH || p->solver == D2D_SOLVER_FERMAT) {
         if (d_stats) return fail(D2D_ERR_UNSUPPORTED, "the optimiser-based solvers have no instrumented build");
         return opt_sweep_launch(c, p, tx, grad_mode);
@@ -1182,6 +1204,10 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         else if (ok) a.sig_l2f = -1e30f;  // fun == 0 throughout
     }
     a.fun_id = p->fun_id;
+    a.cust_f = c->d_cust_f.p;
+    a.cust_pb = c->d_cust_pb.p;
+    a.cust_cells = (long)c->m * c->n;
+    if (p->fun_id == D2D_FUN_CUSTOM) a.sig_mono = 0;  // (values of any sign)
     a.out_mode = p->out_mode;
     a.patch = p->patch;
     a.stats = d_stats;
@@ -1753,6 +1779,27 @@ int d2d_set_cotangent(d2d_ctx* c, const float* cot) {
     HIP_TRY(hipMemcpyAsync(c->d_cot.p, cot, cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_cot = true;
+    return D2D_OK;
+}
+
+int d2d_set_path_fun_values(d2d_ctx* c, const float* f, const float* xys_bar, int64_t n_candidates) {
+    if (!c) return fail(D2D_ERR_INVALID, "ctx is NULL");
+    if (!c->have_grid) return fail(D2D_ERR_STATE, "d2d_set_grid must come first");
+    if (!f || !xys_bar || n_candidates <= 0) {
+        c->cust_C = -1;
+        return (f || xys_bar || n_candidates > 0) ? fail(D2D_ERR_INVALID, "f, xys_bar and n_candidates > 0 go together") : D2D_OK;
+    }
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t rows = (size_t)n_candidates * (size_t)c->m * (size_t)c->n;
+    const size_t np2 = 2 * (size_t)(D2D_MAX_ORDER + 2);
+    c->cust_C = -1;
+    if ((rc = c->d_cust_f.ensure(rows))) return rc;
+    if ((rc = c->d_cust_pb.ensure(rows * np2))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_cust_f.p, f, rows * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_cust_pb.p, xys_bar, rows * np2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->cust_C = n_candidates;
     return D2D_OK;
 }
 

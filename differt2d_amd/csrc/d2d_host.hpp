@@ -152,7 +152,7 @@ inline int check_params(const d2d_params* p, std::string& err) {
     if (p->approx && !(p->alpha > 0.0f)) return err = "alpha must be > 0 in approx mode", D2D_ERR_INVALID;
     if (p->approx && p->act != D2D_ACT_HARD_SIGMOID && p->act != D2D_ACT_SIGMOID)
         return err = "activation " + std::to_string(p->act) + " is not one of the native activations", D2D_ERR_UNSUPPORTED;
-    if (p->fun_id < 0 || p->fun_id > D2D_FUN_ONE) return err = "fun_id " + std::to_string(p->fun_id) + " is not a native path function", D2D_ERR_UNSUPPORTED;
+    if (p->fun_id < 0 || p->fun_id > D2D_FUN_CUSTOM) return err = "fun_id " + std::to_string(p->fun_id) + " is not a native path function", D2D_ERR_UNSUPPORTED;
     if (p->out_mode != D2D_OUT_OVERWRITE && p->out_mode != D2D_OUT_ADD) return err = "bad out_mode " + std::to_string(p->out_mode), D2D_ERR_INVALID;
     if (p->grid_role != D2D_GRID_RX && p->grid_role != D2D_GRID_TX) return err = "bad grid_role " + std::to_string(p->grid_role), D2D_ERR_INVALID;
     if (!(p->seg_tol >= 0.0f)) return err = "seg_tol must be >= 0", D2D_ERR_INVALID;

@@ -155,6 +155,11 @@ struct SweepArgs {
     float* __restrict__ grad;        // [m][n][2] d Z / d rx per cell
     const float* __restrict__ cot;   // [m][n] cotangent for the scene VJP, or null (= ones)
     float* __restrict__ partial;     // [n_waves][4 N + 2] per-wave partial sums of the scene VJP, or null
+    // fun_id == D2D_FUN_CUSTOM (exhaustive value+grad kernel only): a path function the host evaluated on the traced paths --
+    // its values and its derivatives w.r.t. the path's points, per candidate (the sweep's own order) and cell
+    const float* __restrict__ cust_f;   // [C][m * n]
+    const float* __restrict__ cust_pb;  // [C][m * n][D2D_MAX_ORDER + 2][2]
+    long cust_cells;                    // m * n
 
     // patch schedule (patch_cost_kernel / patch_order_kernel): workgroup b takes patch sched[b]; null = identity
     const int* __restrict__ sched;
@@ -323,6 +328,8 @@ struct GradCtx {
     float cot;       // cotangent of this cell's accumulated value
     float* wl;       // LDS [4 N] of this wave: sum over lanes/candidates of cot * (d/d origin.xy, d/d dest.xy)
     bool scene;      // accumulate tbx/tby/wl ?
+    int ci;          // D2D_FUN_CUSTOM: ordinal of the next candidate in the sweep's order (wave-uniform)
+    long cell;       // D2D_FUN_CUSTOM: this lane's cell
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -368,6 +375,8 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     const float zc_acc = (acc_floor >= 0.0f) ? acc_floor : acc;
     int on_i = 0, on_w = 0, hit_i = 0, hit_j = -1;  // GRAD: which activation carries the min / max
     bool znan = false;  // GRAD: the reference's autodiff yields NaN for this (cell, candidate), see below
+    long cust = 0;      // GRAD, D2D_FUN_CUSTOM: this (candidate, cell)'s row of the host-evaluated path function
+    if (GRAD && a.fun_id == D2D_FUN_CUSTOM) cust = (long)(g->ci++) * a.cust_cells + g->cell;
     float px[K + 2], py[K + 2];
     px[0] = txx;
     py[0] = txy;
@@ -474,7 +483,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
 #pragma unroll
         for (int i = 0; i <= K; ++i) znan = znan || (px[i + 1] == px[i] && py[i + 1] == py[i]);
     }
-    if (GRAD && a.fun_id != D2D_FUN_ONE) {
+    if (GRAD && a.fun_id != D2D_FUN_ONE && a.fun_id != D2D_FUN_CUSTOM) {
         // path_length's guard fails where it is needed: a segment vector of exactly (-eps, -eps) becomes (0, 0) once eps is
         // added to both components (geometry.py:199-200), and jnp.linalg.norm's derivative at 0 is 0 / 0 -- NaN whatever
         // cotangent reaches it, a valid candidate's or an invalid one's zero (every path function but the constant one
@@ -816,6 +825,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     if (a.fun_id == D2D_FUN_RECEIVED_POWER) f = a.fnum[K] / (a.h2 + r * r);
     else if (a.fun_id == D2D_FUN_LENGTH_SQUARED) f = r * r;
     else if (a.fun_id == D2D_FUN_LENGTH) f = r;
+    else if (GRAD && a.fun_id == D2D_FUN_CUSTOM) f = a.cust_f[cust];
     else f = 1.0f;
     acc = acc + valid * f;  // scene.py:1909
 
@@ -835,6 +845,15 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         float pbx[K + 2], pby[K + 2];
 #pragma unroll
         for (int i = 0; i < K + 2; ++i) pbx[i] = pby[i] = 0.0f;
+        if (a.fun_id == D2D_FUN_CUSTOM) {
+            // the host's d fun / d xys (a derivative w.r.t. the end points as arguments of `fun` folded into rows 0 and K + 1)
+            const float* pb = a.cust_pb + cust * (2 * (D2D_MAX_ORDER + 2));
+#pragma unroll
+            for (int i = 0; i < K + 2; ++i) {
+                pbx[i] = fbar * pb[2 * i];
+                pby[i] = fbar * pb[2 * i + 1];
+            }
+        }
         // path_length
 #pragma unroll
         for (int i = 0; i <= K; ++i) {
@@ -1909,6 +1928,8 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
     g.cot = in_range ? (a.cot ? a.cot[idx] : 1.0f) : 0.0f;
     g.wl = wl;
     g.scene = scene;
+    g.ci = 0;
+    g.cell = 0;
     // bounding box of the wave's cells (NaN / inf coordinates make every comparison fail: nothing is culled)
     float x0 = rxx, x1 = rxx, y0 = rxy, y1 = rxy;
 #pragma unroll
@@ -2809,6 +2830,8 @@ __device__ __forceinline__ void txg_patch(const SweepArgs& a, const float4* tab,
     g.cot = in_range ? (a.cot ? a.cot[idx] : 1.0f) : 0.0f;  // clamped duplicate lanes contribute nothing
     g.wl = wl;
     g.scene = scene;
+    g.ci = 0;
+    g.cell = 0;
     float x0 = cx, x1 = cx, y0 = cy, y1 = cy;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -3424,6 +3447,8 @@ __global__ void __launch_bounds__(64) power_vg_kernel(SweepArgs a) {
     g.cot = in_range ? (a.cot ? a.cot[idx] : 1.0f) : 0.0f;  // clamped duplicate lanes contribute nothing
     g.wl = wl;
     g.scene = scene;
+    g.ci = 0;
+    g.cell = idx;
     float acc = 0.0f;
     WaveStats st;
     st.shadow = -1;

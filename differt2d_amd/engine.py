@@ -20,6 +20,7 @@ FUN_IDS = {
     "length_squared": L.FUN_LENGTH_SQUARED,
     "length": L.FUN_LENGTH,
     "one": L.FUN_ONE,
+    "custom": L.FUN_CUSTOM,  # values and derivatives from the host: Context.set_path_fun_values (value+grad launches only)
 }
 ACT_IDS = {"hard_sigmoid": L.ACT_HARD_SIGMOID, "sigmoid": L.ACT_SIGMOID}
 SOLVER_IDS = {"image": L.SOLVER_IMAGE, "min": L.SOLVER_MINPATH, "fermat": L.SOLVER_FERMAT}
@@ -213,6 +214,19 @@ class Context:
         if cot.shape != self.shape:
             raise ValueError(f"cotangent must have the grid's shape {self.shape}, got {cot.shape}")
         L.check(self._lib.d2d_set_cotangent(self._ctx, cot.ctypes.data_as(C.c_void_p)))
+
+    def set_path_fun_values(self, f=None, xys_bar=None):
+        """A host-evaluated path function for ``launch_vg(make_params(fun="custom", ...))``: ``f`` [C, m, n] and its derivative
+        w.r.t. the path points ``xys_bar`` [C, m, n, D2D_MAX_ORDER + 2, 2], candidates in the sweep's order (include/d2d.h)."""
+        if f is None:
+            L.check(self._lib.d2d_set_path_fun_values(self._ctx, None, None, 0))
+            return
+        f = np.ascontiguousarray(f, dtype=np.float32)
+        xys_bar = np.ascontiguousarray(xys_bar, dtype=np.float32)
+        if f.ndim != 3 or f.shape[1:] != self.shape or xys_bar.shape != f.shape + (L.D2D_MAX_ORDER + 2, 2):
+            raise ValueError(f"f must be [C, {self.shape[0]}, {self.shape[1]}] and xys_bar f.shape + ({L.D2D_MAX_ORDER + 2}, 2); "
+                             f"got {f.shape} and {xys_bar.shape}")
+        L.check(self._lib.d2d_set_path_fun_values(self._ctx, f.ctypes.data_as(C.c_void_p), xys_bar.ctypes.data_as(C.c_void_p), f.shape[0]))
 
     def launch_vg(self, params: L.Params, tx, scene_vjp: bool = False):
         """Fused value+grad sweep (per-cell d/d rx; optionally the VJP w.r.t. tx and object end points)."""

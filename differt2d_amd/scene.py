@@ -634,6 +634,52 @@ class Scene(Plottable):
             acc = (acc + out["valid"][:, c].reshape(X.shape) * val).astype(F)
         return acc
 
+    def _emit_grid_grad(self, X, Y, fixed: Point, grid_is_rx: bool, point_cls, fun, fun_args, fun_kwargs, common,
+                        filter_objects, path_cls):
+        """Value and per-cell gradient of a sweep with an arbitrary Python ``fun`` (reference scene.py:1892-1923 with any JAX
+        callable): the paths of all (cell, candidate) are traced on the GPU, ``fun`` and its derivative w.r.t. the path points
+        are evaluated on the host once per candidate (fun_grad.py: ``fun.value_and_grad`` or a tape of ``fun``'s operations),
+        and the exhaustive value+grad kernel chains them through the hand-derived adjoint of the validity and of the image
+        method (include/d2d.h: d2d_set_path_fun_values, D2D_FUN_CUSTOM).  ImagePath only."""
+        from .fun_grad import value_and_xys_bar
+
+        if self._solver_of(path_cls) != "image":
+            raise L.D2DUnsupported(-4, "grad / value_and_grad of a path function that is not fused natively: ImagePath only")
+        candidates = self.all_path_candidates(common["min_order"], common["max_order"], order=common.get("order"),
+                                              filter_objects=filter_objects)
+        cells = X.size
+        if cells * max(len(candidates), 1) > EMIT_LIMIT:
+            raise L.D2DUnsupported(-4, f"fun={fun!r} is not fused natively and {cells} cells x {len(candidates)} candidates "
+                                       f"exceed the emit limit; use a function from differt2d_amd.utils")
+        if not candidates or not cells:
+            return np.zeros(X.shape, F), np.zeros(X.shape + (2,), F)
+        grid = np.stack([X.reshape(-1), Y.reshape(-1)], axis=-1).astype(F)
+        other = np.broadcast_to(fixed.xy, grid.shape)
+        txs, rxs = (other, grid) if grid_is_rx else (grid, other)
+        ctx = self._ctx()
+        self._upload(ctx)
+        p = dict(common)
+        p.pop("order", None)
+        p["min_order"], p["max_order"] = 0, L.D2D_MAX_ORDER
+        out = ctx.trace_paths(make_params(solver="image", **p), txs, rxs, candidates)
+        f = np.zeros((len(candidates),) + X.shape, F)
+        bar = np.zeros((len(candidates),) + X.shape + (L.D2D_MAX_ORDER + 2, 2), F)
+        for c, cand in enumerate(candidates):
+            k = len(cand)
+            val, xb = value_and_xys_bar(fun, fixed.xy, grid.reshape(*X.shape, 2), grid_is_rx,
+                                        out["xys"][:, c, : k + 2].reshape(*X.shape, k + 2, 2), out["loss"][:, c].reshape(X.shape),
+                                        self.get_interacting_objects(cand), fun_args, fun_kwargs, point_cls, path_cls)
+            f[c] = val
+            bar[c, ..., : k + 2, :] = xb
+        self._upload(ctx, filter_objects)
+        ctx.set_grid(X, Y)
+        ctx.set_path_fun_values(f, bar)
+        params = make_params(fun="custom", grid_role=L.GRID_RX if grid_is_rx else L.GRID_TX, **common)
+        ctx.launch_vg(params, fixed.xy, scene_vjp=False)
+        value, grad = ctx.get_map(), ctx.get_grad_rx()
+        ctx.set_path_fun_values(None)
+        return value, grad
+
     def _grid_sweep(self, X, Y, fixed_items, grid_is_rx, point_cls, fun, fun_args, fun_kwargs, reduce_all, grad,
                     value_and_grad, path_cls, path_cls_kwargs, min_order, max_order, order, filter_objects, key, kwargs):
         """Shared driver of the two grid sweeps: ``fixed_items`` are the named end points that stay put (transmitters
@@ -646,8 +692,16 @@ class Scene(Plottable):
 
         if native is None:
             if want_grad:
-                raise L.D2DUnsupported(-4, "grad / value_and_grad need a natively fused fun (differt2d_amd.utils): an "
-                                           "arbitrary Python callable cannot be differentiated by the hand-derived kernels")
+                # (value_and_grad takes precedence over grad, reference scene.py:1920-1923)
+                pick = (lambda vg: vg) if value_and_grad else (lambda vg: vg[1])
+                gen = ((name, self._emit_grid_grad(X, Y, pt, grid_is_rx, point_cls, fun, fun_args, fun_kwargs, common,
+                                                   filter_objects, path_cls)) for name, pt in fixed_items)
+                if reduce_all:
+                    Z, G = np.zeros(X.shape, F), np.zeros(X.shape + (2,), F)
+                    for _, (v, g) in gen:
+                        Z, G = (Z + v).astype(F), (G + g).astype(F)
+                    return pick((Z, G))
+                return ((name, pick(vg)) for name, vg in gen)
             gen = ((name, self._emit_grid(X, Y, pt, grid_is_rx, point_cls, fun, fun_args, fun_kwargs, common,
                                           filter_objects, path_cls, path_cls_kwargs, key)) for name, pt in fixed_items)
             if reduce_all:

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define D2D_MAX_ORDER 4 /* highest interaction order a sweep accepts */
-#define D2D_ABI_VERSION 7
+#define D2D_ABI_VERSION 8
 
 typedef enum d2d_status {
     D2D_OK = 0,
@@ -53,7 +53,13 @@ enum { D2D_ACT_HARD_SIGMOID = 0, D2D_ACT_SIGMOID = 1 };
  *   LENGTH_SQUARED  tests/test_scene.py:444-445     path.length() ** 2
  *   LENGTH          differt2d/geometry.py:811-819   path.length()
  *   ONE             1.0 (the map then counts valid paths -- "intersection counts") */
-enum { D2D_FUN_RECEIVED_POWER = 0, D2D_FUN_LENGTH_SQUARED = 1, D2D_FUN_LENGTH = 2, D2D_FUN_ONE = 3 };
+enum {
+    D2D_FUN_RECEIVED_POWER = 0,
+    D2D_FUN_LENGTH_SQUARED = 1,
+    D2D_FUN_LENGTH = 2,
+    D2D_FUN_ONE = 3,
+    D2D_FUN_CUSTOM = 4 /* values and derivatives supplied per (candidate, cell): d2d_set_path_fun_values; value+grad launches only */
+};
 
 /* Which end of the paths the grid cells are. */
 enum { D2D_GRID_RX = 0, D2D_GRID_TX = 1 };
@@ -193,6 +199,22 @@ int d2d_power_map_launch(d2d_ctx* ctx, const d2d_params* params, const float* tx
 /* Cotangent of the value map for the scene-parameter VJP: cot[m*n], or NULL for all ones (the gradient of
  * sum(Z)). Reset by d2d_set_grid. */
 int d2d_set_cotangent(d2d_ctx* ctx, const float* cot);
+
+/* Gradient of a sweep whose path function `fun` is an arbitrary host callable (the reference differentiates any JAX
+ * callable, differt2d/scene.py:1892-1923: d/d cell of sum_c valid_c * fun_c).  The host traces the paths
+ * (d2d_trace_paths), evaluates fun and its derivative on them and hands both over:
+ *   f[n_candidates][m*n]                          fun of (candidate, cell),
+ *   xys_bar[n_candidates][m*n][D2D_MAX_ORDER+2][2] d fun / d path points (rows 0 .. order+1 of a candidate are read; a
+ *                                                 derivative w.r.t. tx.xy / rx.xy as arguments of fun is added to rows 0 / order+1),
+ * candidates in the sweep's order (orders min_order..max_order, lexicographic over the allowed objects -- the order of
+ * d2d_trace_paths' candidate list built by the reference's all_path_candidates).  A following d2d_power_map_vg_launch with
+ * params->fun_id == D2D_FUN_CUSTOM (image solver; every candidate of every cell is evaluated, as under strict_nan) then
+ * chains them through the hand-derived adjoint of the validity and of the image method: d2d_get_map returns
+ * sum_c valid_c * f_c and d2d_get_grad_rx its derivative w.r.t. the cell, d2d_get_scene_vjp the pull-back to the fixed
+ * end point and the wall end points THROUGH THE PATHS (fun's own dependence on the objects is the caller's).
+ * Host arrays, copied before the call returns; NULL / 0 drops them; reset by d2d_set_grid.  D2D_ERR_STATE from the launch
+ * when n_candidates is not the number of candidates the sweep walks. */
+int d2d_set_path_fun_values(d2d_ctx* ctx, const float* f, const float* xys_bar, int64_t n_candidates);
 
 /* Value+grad sweep.  ImagePath: fused, hand-derived reverse mode.  MinPath / FermatPath (differt2d/geometry.py:1117-1288):
  * hand-derived reverse mode through the reference's lax.scan of Adam steps (differt2d/optimize.py:83-97): the solver writes its

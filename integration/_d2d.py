@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-D2D_ABI_VERSION = 7
+D2D_ABI_VERSION = 8
 D2D_GRID_RX, D2D_GRID_TX = 0, 1
 D2D_OUT_OVERWRITE, D2D_OUT_ADD = 0, 1
 D2D_FUN_RECEIVED_POWER = 0

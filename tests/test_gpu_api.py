@@ -564,7 +564,7 @@ def test_scene_vjp_accumulation_refuses_mixed_sweep_kinds():
 
 def test_user_functions_are_recognised_by_what_they_compute():
     """VERDICT r2 item 9: a local `fun` that is one of the fused closed forms runs fused -- with gradients -- without a rename;
-    anything else goes to the host (values) or raises (gradients), as before."""
+    anything else goes to the host."""
     from differt2d_amd import _lib as L
     from differt2d_amd.scene import Scene, _native_fun
     from differt2d_amd.utils import received_power
@@ -585,5 +585,166 @@ def test_user_functions_are_recognised_by_what_they_compute():
     Zr, dZr = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, fun_kwargs=dict(r_coef=0.25, height=0.2),
                                                             value_and_grad=True, **kw)
     assert np.array_equal(Z, Zr) and np.array_equal(dZ, dZr, equal_nan=True) and np.isfinite(dZ).mean() > 0.9
+    # anything else: the host evaluates it, and its gradient goes through fun.value_and_grad or a tape of its operations
+    # (fun_grad.py; the tests below) -- a function the tape cannot follow (numpy calls on recording tensors) is refused
+    g = scene.accumulate_on_receivers_grid_over_paths(X[:8, :8], Y[:8, :8], fun=_length_sq_host, grad=True, **kw)
+    g0 = scene.accumulate_on_receivers_grid_over_paths(X[:8, :8], Y[:8, :8], fun=_length_sq, grad=True, **kw)
+    # (row 0 and column 0 of this grid lie ON the square's walls: NaN cells, by the reference's rules, in both)
+    assert g.shape == (8, 8, 2) and np.array_equal(np.isnan(g), np.isnan(g0)) and np.isfinite(g).mean() > 0.7
+    assert np.nanmax(np.abs(g - g0)) <= 3e-3 * np.nanmax(np.abs(g0))  # (the extra factor is 1 + 1e-3 k, k <= 2)
     with pytest.raises(L.D2DUnsupported):
-        scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=_length_sq_host, grad=True, **kw)
+        scene.accumulate_on_receivers_grid_over_paths(X[:8, :8], Y[:8, :8], fun=lambda t, r, p, o: np.sqrt(p.length()) * len(o),
+                                                      grad=True, **kw)
+
+
+# ---- gradients of sweeps whose path function is NOT fused natively (reference scene.py:1892-1923 with any callable) ----
+def _power_like(transmitter, receiver, path, interacting_objects, r_coef=0.5, height=0.1):
+    """received_power written with operators only: works on arrays and on recording tensors alike."""
+    r = path.length()
+    n = path.xys.shape[-2] - 2
+    return (r_coef ** n) / (height * height + r * r)
+
+
+_power_like._d2d_native = False  # (kept away from the recogniser: this test is about the host-evaluated route)
+
+
+def _odd_fun(transmitter, receiver, path, interacting_objects, w=0.3):
+    """Depends on the length, on both end points as arguments and on an interior point of the path."""
+    r = path.length()
+    dx = receiver.xy[..., 0] - transmitter.xy[..., 0]
+    return w * r * r.sqrt() + dx * dx + path.xys[..., -2, 0] * receiver.xy[..., 1]
+
+
+_odd_fun._d2d_native = False
+
+
+def _odd_fun_oracle(pts, xp=None, w=0.3):
+    from oracle import ref as R
+
+    r = R.path_length(pts, xp)
+    dx = pts[-1][..., 0] - pts[0][..., 0]
+    return w * r * r.sqrt() + dx * dx + pts[-2][..., 0] * pts[-1][..., 1]
+
+
+@pytest.mark.parametrize("role", ["rx", "tx"])
+@pytest.mark.parametrize("approx", [False, True])
+def test_gradient_of_a_host_evaluated_fun_equals_the_fused_one(approx, role):
+    """A callable that computes what received_power computes, but on the host-evaluated route (paths traced on the GPU, fun
+    and d fun / d xys from a tape of its operations, chained through the kernels' adjoint): the per-cell gradient, the NaN
+    cells and the values of the natively fused sweep."""
+    from conftest import random_scene, unit_grid
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import received_power
+
+    tx, walls = random_scene(7, seed=77)
+    scene = Scene.from_walls_array(walls)
+    X, Y = unit_grid(21, 13)
+    kw = dict(min_order=0, max_order=2, approx=approx, reduce_all=True, value_and_grad=True)
+    from differt2d_amd.geometry import Point
+
+    if role == "rx":
+        scene = scene.with_transmitters(tx=Point(xy=tx))
+        sweep = scene.accumulate_on_receivers_grid_over_paths
+    else:
+        scene = scene.with_receivers(rx=Point(xy=tx))
+        sweep = scene.accumulate_on_transmitters_grid_over_paths
+    Z0, G0 = sweep(X, Y, fun=received_power, fun_kwargs=dict(r_coef=0.5, height=0.1), **kw)
+    Z1, G1 = sweep(X, Y, fun=_power_like, **kw)
+    np.testing.assert_allclose(Z1, Z0, rtol=2e-6, atol=1e-6)  # (r_coef ** n / (h h + r r): the tape rounds like the kernel up to the power)
+    assert np.array_equal(np.isnan(G1), np.isnan(G0))
+    scale = float(np.nanmax(np.abs(G0)))
+    assert scale > 0
+    assert np.nanmax(np.abs(G1 - G0)) <= 1e-5 * scale
+    # grad alone, per fixed point
+    (name, G2), = list(sweep(X, Y, fun=_power_like, min_order=0, max_order=2, approx=approx, grad=True))
+    assert np.array_equal(G2, G1, equal_nan=True)
+
+
+@pytest.mark.parametrize("approx,function", [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")])
+def test_gradient_of_an_arbitrary_fun_against_autodiff_of_the_oracle(approx, function):
+    """A function nothing in the library knows (length^1.5, both end points as arguments, an interior path point) through
+    Scene.accumulate_on_receivers_grid_over_paths(value_and_grad=True), against reverse-mode autodiff of the oracle with the
+    same function; then the same through a user-supplied derivative (fun.value_and_grad)."""
+    from conftest import random_scene, unit_grid
+    from differt2d_amd import logic
+    from differt2d_amd.geometry import Point
+    from differt2d_amd.scene import Scene
+    from oracle import ref as R
+
+    tx, walls = random_scene(6, seed=5)
+    scene = Scene.from_walls_array(walls).with_transmitters(tx=Point(xy=tx))
+    X, Y = unit_grid(17, 11)
+    Z, G = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=_odd_fun, fun_kwargs=dict(w=0.25), reduce_all=True,
+                                                         value_and_grad=True, min_order=0, max_order=2, approx=approx,
+                                                         function=getattr(logic, function))
+    want = R.power_map_value_and_grads(walls, tx, X, Y, dtype="float64", min_order=0, max_order=2, approx=approx,
+                                       function=function, fun=_odd_fun_oracle, fun_kwargs=dict(w=0.25))
+    want32 = R.power_map_value_and_grads(walls, tx, X, Y, dtype="float32", min_order=0, max_order=2, approx=approx,
+                                         function=function, fun=_odd_fun_oracle, fun_kwargs=dict(w=0.25))
+    np.testing.assert_allclose(Z, want["value"], rtol=3e-5, atol=1e-5)
+    assert np.array_equal(np.isnan(G), np.isnan(want32["grad_rx"]))
+    scale = float(np.nanmax(np.abs(want["grad_rx"])))
+    err = np.abs(G - want["grad_rx"])
+    bar = np.maximum(1e-5 * scale, 2.0 * np.abs(want32["grad_rx"] - want["grad_rx"]))  # (sigmoid at alpha = 100: the reference's own fp32 distance)
+    assert np.nanmax(err - bar) <= 0.0, f"max err {np.nanmax(err):.3e} at scale {scale:.3e}"
+
+    # the same function with its derivative supplied by the user (no tape)
+    def supplied(transmitter, receiver, path, interacting_objects, w=0.3):
+        xys = np.asarray(path.xys, np.float64)
+        v = (xys[..., 1:, :] - xys[..., :-1, :]) + float(np.finfo(np.float32).eps)
+        ln = np.sqrt((v * v).sum(-1))
+        r = ln.sum(-1)
+        txy, rxy = np.asarray(transmitter.xy, np.float64), np.asarray(receiver.xy, np.float64)
+        dx = rxy[..., 0] - txy[..., 0]
+        val = w * r * np.sqrt(r) + dx * dx + xys[..., -2, 0] * rxy[..., 1]
+        dr = 1.5 * w * np.sqrt(r)
+        bar = np.zeros_like(xys)
+        u = dr[..., None, None] * v / ln[..., None]
+        bar[..., 1:, :] += u
+        bar[..., :-1, :] -= u
+        bar[..., -2, 0] += rxy[..., 1]
+        d_tx = np.stack([-2 * dx, np.zeros_like(dx)], -1)
+        d_rx = np.stack([2 * dx, xys[..., -2, 0]], -1)
+        return val, bar, d_tx, d_rx
+
+    def fun2(*a, **k):  # never called for its value on this route
+        raise AssertionError("fun.value_and_grad should have been used")
+
+    fun2.value_and_grad = supplied
+    fun2._d2d_native = False
+    Z2, G2 = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=fun2, fun_kwargs=dict(w=0.25), reduce_all=True,
+                                                           value_and_grad=True, min_order=0, max_order=2, approx=approx,
+                                                           function=getattr(logic, function))
+    np.testing.assert_allclose(Z2, Z, rtol=2e-6, atol=1e-6)
+    assert np.array_equal(np.isnan(G2), np.isnan(G))
+    assert np.nanmax(np.abs(G2 - G)) <= 1e-5 * scale
+
+
+def test_custom_fun_values_are_checked_by_the_library():
+    """D2D_FUN_CUSTOM without rows, with the wrong number of candidates, on a forward launch: loud errors (include/d2d.h)."""
+    from conftest import random_scene, unit_grid
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import default_context, make_params
+
+    ctx = default_context(0)
+    tx, walls = random_scene(4, seed=3)
+    X, Y = unit_grid(8, 8)
+    ctx.set_scene(walls)
+    ctx.set_grid(X, Y)
+    p = make_params(fun="custom", min_order=0, max_order=1)
+    with pytest.raises(L.D2DError):
+        ctx.launch_vg(p, tx)  # nothing set
+    ctx.set_path_fun_values(np.zeros((3, 8, 8), F), np.zeros((3, 8, 8, L.D2D_MAX_ORDER + 2, 2), F))
+    with pytest.raises(L.D2DError):
+        ctx.launch_vg(p, tx)  # 1 + 4 candidates expected
+    with pytest.raises(L.D2DError):
+        ctx.launch(p, tx)  # forward launches have no use for it
+    f = np.ones((5, 8, 8), F)
+    ctx.set_path_fun_values(f, np.zeros((5, 8, 8, L.D2D_MAX_ORDER + 2, 2), F))
+    ctx.launch_vg(p, tx)
+    a = ctx.get_map()
+    ctx.launch(make_params(fun="one", min_order=0, max_order=1), tx)
+    assert np.array_equal(a, ctx.get_map())  # f = 1: the count of valid paths
+    ctx.set_grid(X, Y + F(0.01))  # a new grid drops the rows
+    with pytest.raises(L.D2DError):
+        ctx.launch_vg(p, tx)
