@@ -153,6 +153,7 @@ struct d2d_ctx {
     long long hidden_builds = 0;        // diagnostic
     float pair_key[6] = {0, 0, 0, 0, 0, 0};  // patch, seg_tol, approx, act, alpha, dperp
     bool use_pair_masks = true;
+    int sig_narrow_filter = 1;  // option "sig_narrow_filter": 0 = the filter's window at -89, 1 = at -17.5 (same bits)
     // scene (device)
     DevBuf<float4> d_occl, d_refl, d_flt;
     DevBuf<int> d_cw;
@@ -1171,8 +1172,13 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         widen = ((mode == d2d::MODE_HSIG) ? 3.0 : 89.0) / (double)p->alpha;
     }
     const double widen_in = !p->approx ? 0.0 : ((mode == d2d::MODE_HSIG) ? 3.0 : 17.5) / (double)p->alpha * (1.0 + 1e-5);
-    double lo = -((double)p->seg_tol + widen);
-    double hi = 1.0 + (double)p->seg_tol + widen;
+    // (sigmoid, forward sweeps: an occlusion test only enters the map through 1 - max_j sigmoid(z_j), and sigmoid(z) < 2^-25
+    // -- z < -17.33 -- leaves 1 - hit at exactly 1.0f, as no test at all would: the divide-free filter may drop what is
+    // certainly below -17.5 instead of what is certainly below -89.  The value+grad build keeps the wide window: it records
+    // which test carries the max.)
+    const double widen_flt = (mode == d2d::MODE_SIG && !grad_mode && c->sig_narrow_filter) ? 17.5 / (double)p->alpha : widen;
+    double lo = -((double)p->seg_tol + widen_flt);
+    double hi = 1.0 + (double)p->seg_tol + widen_flt;
     a.flt_lo = (float)(lo * (1.0 + 1e-5) - 1e-30);
     a.flt_hi = (float)(hi * (1.0 + 1e-5) + 1e-30);
     // on_objects is exactly 0 / False once s < -widen or s > 1 + widen (same saturation argument)
@@ -1912,6 +1918,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
         c->fwd_waves = value;
     }
     else if (!strcmp(name, "pair_masks")) c->use_pair_masks = value != 0;
+    else if (!strcmp(name, "sig_narrow_filter")) c->sig_narrow_filter = (int)value;
 #ifdef D2D_AB_TIMELINE
     else if (!strcmp(name, "tl_ring")) {
         c->tl_ring_on = value != 0;

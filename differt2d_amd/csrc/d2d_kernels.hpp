@@ -194,12 +194,24 @@ struct SweepArgs {
 //   [4] segment/wall tests evaluated (filter)           [5] tests that took the exact-divide path
 //   [6] sum over [0] of the candidate order k           [7] sum over [1] of k   [8] sum over [3] of (k+1)
 struct WaveStats {
-    unsigned long long c[16];  // [9] tile-culling levels evaluated; [10..15] shader-clock ticks per phase (diagnostic)
+    // (32-bit, and kept in vector registers by stat_add: as 16 wave-uniform 64-bit values they took 32 scalar registers of a
+    // kernel that already parks scalars in VGPR lanes; one wave never counts past 2^32)
+    unsigned c[16];  // [9] tile-culling levels evaluated; [10..15] shader-clock ticks per phase (diagnostic)
     int shadow;                // wave state, not a counter: the wall that occluded the wave's previous candidate
     unsigned work;             // every build: work done for this patch in units of ~25 wave-instructions (feeds the schedule)
 };
 
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p); }
+
+// counter I += x in a vector register (see WaveStats)
+#ifndef D2D_STAT_MASK  // (A/B: the counters an instrumented build keeps)
+#define D2D_STAT_MASK 0xffff
+#endif
+template <int I>
+__device__ __forceinline__ void stat_add(WaveStats& st, unsigned long long x) {
+    const unsigned x32 = (unsigned)x;
+    if ((D2D_STAT_MASK >> I) & 1) asm volatile("v_add_u32 %0, %0, %1" : "+v"(st.c[I]) : "v"(x32));
+}
 
 // ---- correctly rounded fp32 division without the range scaling of the generic expansion --------------
 // hipcc expands x / y (with -fhip-fp32-correctly-rounded-divide-sqrt) into v_div_scale x2, v_rcp, a Newton
@@ -405,14 +417,14 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         float ey = __builtin_fmaf(fabsf(gq), fabsf(uy), fabsf(vy)) + fabsf(r0.y);
         float M = __builtin_fmaf(__builtin_fmaf(fabsf(r1.y), ey, fabsf(r1.x) * ex), fc.y, 1e-30f);
         bool cull = !lane_bad && (un != 0.0f) && (ex < 1e18f) && (ey < 1e18f) && ((sa + M < a.on_lo) || (sa - M > a.on_hi));
-        if (STATS) st.c[9] += 1;
+        if (STATS) stat_add<9>(st, 1);
         if (!wave_any(!cull)) return;
     }
 
     D2D_WORK(6 + 2 * K);  // backward scan + on_objects
     if (STATS) {
-        st.c[0] += 1;
-        st.c[6] += K;
+        stat_add<0>(st, 1);
+        stat_add<6>(st, K);
     }
     float sv[K + 1];  // parametric coordinates of the interaction points on their walls (fp32, as on_objects computes them)
     // What the later stages will want from memory is asked for now (scalar loads, wave-uniform): the masks of the candidate's
@@ -470,7 +482,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     else off = fminf(a.alpha * (sw - 0.0f), a.alpha * (1.0f - sw)) <= fmaxf(-89.0f, sig_zc_of(a.sig_l2f, zc_acc));
                     const bool pt_bad = lane_bad || !(fabsf(ptx) < 1e18f) || !(fabsf(pty) < 1e18f);
                     if (!wave_any(!off || pt_bad)) {
-                        if (STATS && i == K - 1) st.c[15] += 1;  // died at the last wall (the first the scan reaches)
+                        if (STATS && i == K - 1) stat_add<15>(st, 1);  // died at the last wall (the first the scan reaches)
                         return;
                     }
                 }
@@ -639,7 +651,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             if (!wave_any(active)) return;  // every lane occluded (or off its walls): valid == 0 whatever the loss is
         }
     }
-    if (STATS) st.c[2] += 1;  // candidates that enter the wall loop
+    if (STATS) stat_add<2>(st, 1);  // candidates that enter the wall loop
     // The wall that finished off the previous candidate of this wave is tried first ("shadow cache"): or / max
     // do not depend on the order of the tests, and neighbouring candidates tend to share their occluder.
     // (the next wall's data are fetched while this one is tested: a lone wave would otherwise sit out one scalar-load
@@ -672,7 +684,10 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             float pb = __builtin_fmaf(-a.flt_lo, fd, fb) * __builtin_fmaf(-a.flt_hi, fd, fb);
             bool miss = fmaxf(pa, pb) > 0.0f;
             if (MODE == MODE_SIG && !skip) any_test = true;
-            if (STATS && !skip) st.c[4] += 1;
+            // (branch-free on purpose: as `if (STATS && !skip) ++count` -- a branch with a side effect between the filter's compare
+            // and its use -- the instrumented kernel's maps differed from the product kernel's at shadow boundaries, 0.5 % of the
+            // cells at cfg2, from round 1 on; found in round 4, scripts/stats_cmp.py and tests/test_gpu_forward.py hold them equal)
+            if (STATS) stat_add<4>(st, skip ? 0 : 1);
             wbits |= (!skip && active && (!miss || bad)) ? (1u << i) : 0u;
             fa_[i] = fa;
             fb_[i] = fb;
@@ -683,7 +698,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
 #pragma unroll
             for (int i = 0; i <= K; ++i) {
                 if (!wave_any((wbits >> i) & 1u)) continue;
-                if (STATS) st.c[5] += 1;
+                if (STATS) stat_add<5>(st, 1);
                 D2D_WORK(2);
                 const float fa = fa_[i], fb = fb_[i], fd = fd_[i];
                 // exact path, geometry.py:163-171
@@ -736,7 +751,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // every lane occluded (or off its walls): valid == 0 whatever the loss is
     if (!wave_any(active)) return;
 
-    if (STATS) st.c[1] += 1;
+    if (STATS) stat_add<1>(st, 1);
     D2D_WORK(4 * K);
     // ---- path loss, geometry.py:1077-1084 / 641-650 ---------------------------------------
     // The loss of an image-method path is rounding noise (~1e-13) unless the path is degenerate, and it only
@@ -782,7 +797,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             float ey = ry_ - (iy - s2 * r0.w);
             loss = loss + (ex * ex + ey * ey);
         }
-        if (STATS) st.c[7] += K;
+        if (STATS) stat_add<7>(st, K);
     }
     bool ok_b = loss < a.tol;                                    // hard: jnp.less
     float ok_x = a.tol - loss;                                   // approx: activation(tol - loss)
@@ -811,7 +826,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
 
     // valid is exactly 0 in every lane (all occluded): acc + 0 * fun == acc, and every adjoint is 0
     if (!wave_any(valid != 0.0f || bad)) return;
-    if (STATS) st.c[3] += 1, st.c[8] += K + 1;
+    if (STATS) stat_add<3>(st, 1), stat_add<8>(st, K + 1);
     D2D_WORK(6);
     // ---- fun(path), geometry.py:176-203 and utils.py:17-54 ---------------------------------
     float r = 0.0f;
@@ -1432,7 +1447,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
             if (alive2 && cull_candidate<K>(bx, by, w, Ix, Iy, a, sh0, a.on_lo, a.on_hi)) alive2 = false;
         }
         unsigned long long mask = __ballot(alive2);
-        if (STATS) st.c[9] += K;
+        if (STATS) stat_add<9>(st, K);
         D2D_WORK(5 * K);
         if constexpr (EMIT) {
             emit_batch(*emit, code, alive2, mask);
@@ -1461,7 +1476,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 eval_candidate<K, MODE, STATS, GRAD, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, g);
             }
         }
-        if (STATS) st.c[14] += __builtin_amdgcn_s_memtime() - te0;
+        if (STATS) stat_add<14>(st, __builtin_amdgcn_s_memtime() - te0);
         qn = 0;
         __builtin_amdgcn_wave_barrier();
     };
@@ -1544,7 +1559,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 }
                 const unsigned long long m1 = __ballot(alive);
                 const int cnt = __builtin_popcountll(m1);
-                if (STATS) st.c[9] += 1;
+                if (STATS) stat_add<9>(st, 1);
                 D2D_WORK(5);
                 if (qn + cnt > 64) flush();
                 if (alive) {
@@ -1579,7 +1594,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                 }
             }
             unsigned long long mask = __ballot(alive);
-            if (STATS) st.c[9] += K;
+            if (STATS) stat_add<9>(st, K);
             D2D_WORK(5 * K);  // one culling level = 4 vertex evaluations
             const unsigned long long te0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
             // ---- lanes = RX cells: survivors in ascending order (= the reference's order)
@@ -1596,7 +1611,7 @@ __device__ __forceinline__ void sweep_order_culled(const SweepArgs& a, const flo
                     eval_candidate<K, MODE, STATS, GRAD, false, false>(a, cand, imgx, imgy, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, g);
                 }
             }
-            if (STATS) st.c[14] += __builtin_amdgcn_s_memtime() - te0;  // exact evaluation of the survivors
+            if (STATS) stat_add<14>(st, __builtin_amdgcn_s_memtime() - te0);  // exact evaluation of the survivors
         }
         }  // !skip_all
         // next prefix (lexicographic, no equal neighbours); static indexing keeps pos[] in registers
@@ -1771,7 +1786,7 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
             }
         }
         unsigned long long mask = cull_batch<K, GRAD>(a, tab, bx, by, code, have, Ix, Iy, on_lo, on_hi, hidden_row, hidden_dperp);
-        if (STATS) st.c[9] += K;
+        if (STATS) stat_add<9>(st, K);
         D2D_WORK(5 * K);
         int budget = 64;
         if (parts > 1) {
@@ -1806,7 +1821,7 @@ __device__ __forceinline__ void sweep_order_listed(const SweepArgs& a, const flo
                 eval_candidate<K, MODE, STATS, GRAD, false, false>(a, ce, ex, ey, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, g);
             }
         }
-        if (STATS) st.c[14] += __builtin_amdgcn_s_memtime() - te0;
+        if (STATS) stat_add<14>(st, __builtin_amdgcn_s_memtime() - te0);
     }
 }
 
@@ -1944,7 +1959,7 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
     const float bx[4] = {box_ok ? x0 : qn, x1, x1, x0};
     const float by[4] = {y0, y0, y1, y1};
     unsigned long long tq0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (STATS) st.c[10] += tq0 - t_start;  // prologue of the patch
+    if (STATS) stat_add<10>(st, tq0 - t_start);  // prologue of the patch
 #ifdef D2D_AB_TIMELINE
     const unsigned t_lineB = (unsigned)(__builtin_amdgcn_s_memrealtime() & 0xffffull);
     unsigned t_lineC = t_lineB;
@@ -2037,19 +2052,19 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
     } else {
     if (a.min_order <= 0 && a.max_order >= 0) sweep_order<0, MODE, STATS, GRADK>(a, a.txx, a.txy, rxx, rxy, lane_bad, acc, st, &g);
     unsigned long long tq1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (STATS) st.c[11] += tq1 - tq0;      // order 0
+    if (STATS) stat_add<11>(st, tq1 - tq0);      // order 0
     if (a.min_order <= 1 && a.max_order >= 1) {
         const unsigned long long* hid = LISTED ? cmem(a.rl)->leaf.hidden : nullptr;
         sweep_order_culled<1, MODE, STATS, GRADK>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, 0, 0x7fffffff, nullptr, nullptr,
                                                   hid ? hid + (size_t)region * a.N : nullptr, hid ? cmem(a.rl)->leaf.hidden_dperp : 0.0f);
     }
     unsigned long long tq2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (STATS) st.c[12] += tq2 - tq1;      // order 1
+    if (STATS) stat_add<12>(st, tq2 - tq1);      // order 1
 #ifdef D2D_AB_TIMELINE
     t_lineC = (unsigned)(__builtin_amdgcn_s_memrealtime() & 0xffffull);
 #endif
     if (a.min_order <= 2 && a.max_order >= 2) sweep_order_any<2, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
-    if (STATS) st.c[13] += __builtin_amdgcn_s_memtime() - tq2;  // order 2
+    if (STATS) stat_add<13>(st, __builtin_amdgcn_s_memtime() - tq2);  // order 2
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) sweep_order_any<3, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
     if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) sweep_order_any<4, MODE, STATS, GRADK, false, LISTED>(a, tab, bx, by, rxx, rxy, lane_bad, acc, st, &g, region, 0, 1, nullptr);
     }
@@ -2098,9 +2113,14 @@ __device__ __forceinline__ void fwd_patch(const SweepArgs& a, float4* tab, float
             dst[4 * a.N + 1] = tby_sum;
         }
     }
-    if (STATS && lane == 0 && a.stats) {
+    if (STATS && a.stats) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) atomicAdd(&a.stats[i], st.c[i]);
+        for (int i = 0; i < 16; ++i) {
+            unsigned v = st.c[i];  // (wave-uniform counts held per lane: a lane that sat out a divergent stretch counted less)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off, 64));
+            if (lane == 0) atomicAdd(&a.stats[i], (unsigned long long)v);
+        }
     }
 }
 
@@ -2272,9 +2292,14 @@ __device__ __forceinline__ void split_patch(const SweepArgs& a, const float4* ta
             a.cost_out[tile] = sum;
         }
     }
-    if (STATS && lane == 0 && a.stats) {
+    if (STATS && a.stats) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) atomicAdd(&a.stats[i], st.c[i]);
+        for (int i = 0; i < 16; ++i) {
+            unsigned v = st.c[i];  // (wave-uniform counts held per lane: a lane that sat out a divergent stretch counted less)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off, 64));
+            if (lane == 0) atomicAdd(&a.stats[i], (unsigned long long)v);
+        }
     }
 }
 

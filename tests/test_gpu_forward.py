@@ -446,3 +446,26 @@ def CO_tx(walls, rx, X, Y, **kw):
     from oracle import c_oracle as CO
 
     return CO.power_map(walls, rx, X, Y, prune=True, grid_role="tx", **kw)
+
+
+@pytest.mark.parametrize("grid", [96, 1024])
+def test_instrumented_build_writes_the_same_map(grid):
+    """d2d_power_map_stats ("same results, not for timing", include/d2d.h): the instrumented kernels' maps against the product
+    kernels', bit for bit, in every validity mode -- bench.py's roofline counters are only worth something if the kernel that
+    counts does the work the timed kernel does (scripts/stats_cmp.py; they differed at shadow boundaries until round 4)."""
+    from bench import workload
+    from differt2d_amd.engine import Context, make_params
+
+    tx, walls, X, Y = workload(50, grid)
+    with Context(0) as c:
+        c.set_scene(walls)
+        c.set_grid(X, Y)
+        for kw in ({}, dict(approx=True), dict(approx=True, function="sigmoid")):
+            for orders in ((0, 2), (0, 0)) if grid == 96 else ((0, 2),):
+                p = make_params(min_order=orders[0], max_order=orders[1], **kw)
+                for _ in range(3):  # (the third launch runs with the work history and the last-segment masks)
+                    c.launch(p, tx)
+                Z = c.get_map().copy()
+                st = c.launch_stats(p, tx)
+                assert np.array_equal(Z, c.get_map(), equal_nan=True), (kw, orders)
+                assert st[0] > 0 and st[4] > 0
