@@ -277,6 +277,12 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *   "cost_history": non-zero (default) = a launch that sweeps the same grid as the previous one orders its patches by the
  *                   work each took then (counted by the kernels); zero = always by the geometric proxy
  *   "pair_masks": zero = do not build / use the wall-to-wall occlusion masks (A/B and tests; same results)
+ *   "nan_scan": the pass behind a culled value+grad sweep that finds the reference's autodiff NaN cells (d2d_params.strict_nan):
+ *                  1 (default) = one workgroup of 16 waves per region of 4 x 4 patches, 2 = one wave per patch (same flags),
+ *                  0 = off (round 3's behaviour: NaN only inside the candidates the sweep evaluates; A/B);
+ *                  "nan_scan_stats": non-zero = count its work (d2d_debug_nan_scan; slows the scan down)
+ *   "sig_narrow_filter": sigmoid validity, forward sweeps: 1 (default) = the divide-free filter of the occlusion tests drops what is
+ *                  certainly below z = -17.5 (1 - sigmoid(z) is exactly 1.0f there), 0 = what is certainly below -89 (same results)
  *   "opt_parallel": zero = MinPath / FermatPath sweeps walk the candidates one after the other in every lane (same results)
  *   "opt_grad_mode": gradients through the MinPath / FermatPath solvers: 0 (default) reverse mode over the stored trajectory,
  *                   1 forward tangents carried through the loop (same derivative; NaN only where a local partial derivative
