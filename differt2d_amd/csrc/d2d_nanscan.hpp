@@ -101,8 +101,10 @@ __device__ __forceinline__ void nan_quad(const WallC& w, float sa, float sb, flo
 // direction condition keeps the survivors few.
 constexpr float NAN_ABS = 1e-6f;
 template <int K, bool APPROX>
+// near_last: what is known about the LAST wall's near-coincidence test from the cells themselves (nan_near_bits): 0 = no cell
+// of the box can have its interaction point within the bound of itself, 1 = some cell may, -1 = not known (the box's corners decide)
 __device__ __forceinline__ bool nan_possible_rx(const float (&bx)[4], const float (&by)[4], const WallC (&w)[K], const float (&Ix)[K],
-                                                const float (&Iy)[K], float fx, float fy, bool plen) {
+                                                const float (&Iy)[K], float fx, float fy, bool plen, int near_last = -1) {
     const float eps = 1.1920929e-07f;
     const float abs3 = plen ? NAN_ABS : 0.0f;
     const bool near_test = APPROX || plen;
@@ -154,7 +156,8 @@ __device__ __forceinline__ bool nan_possible_rx(const float (&bx)[4], const floa
             E = fmaxf(E, mag);
         }
         if (!((pos || neg) && fin)) return true;
-        if (near_test && !(vpos || vneg) && (APPROX || !(dpos || dneg))) return true;
+        const bool near = (lvl == K - 1 && near_last >= 0) ? (near_last != 0) : !(vpos || vneg);
+        if (near_test && near && (APPROX || !(dpos || dneg))) return true;
         E = E + (fabsf(wl.ox) + fabsf(wl.oy)) + (fabsf(Ix[lvl]) + fabsf(Iy[lvl]));
         const float M = __builtin_fmaf(64.0f * eps * wl.rsq * (fabsf(wl.tx) + fabsf(wl.ty)), 2.0f * E, 1e-30f);
         if (!(E < 1e18f) || !(fabsf(smin) < 1e18f) || !(fabsf(smax) < 1e18f)) return true;
@@ -500,7 +503,7 @@ __device__ __forceinline__ void nan_decode_batch(long long id, int Nc, int n_chu
 
 template <int K, bool APPROX, bool TXG>
 __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float4* tab, unsigned long long* list, int* lcount, unsigned* wallbits,
-                                                 const float (&rbx)[4], const float (&rby)[4], const float (&pbx)[4], const float (&pby)[4],
+                                                 const unsigned* nearbits, const unsigned* region_near, const float (&rbx)[4], const float (&rby)[4], const float (&pbx)[4], const float (&pby)[4],
                                                  float cx, float cy, bool force, bool patch_exists, bool& cell_nan, bool& any_nan,
                                                  unsigned long long& n_probe, int& round) {
     static_assert(K >= 1, "order 0 has no scan");
@@ -557,7 +560,7 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
                         Iy[d] = imgy[d];
                     }
                     image_of(q0, pIx, pIy, Ix[K - 1], Iy[K - 1]);
-                    if (alive) alive = nan_possible_rx<K, APPROX>(rbx, rby, w, Ix, Iy, a.txx, a.txy, plen);
+                    if (alive) alive = nan_possible_rx<K, APPROX>(rbx, rby, w, Ix, Iy, a.txx, a.txy, plen, (int)((region_near[wl >> 5] >> (wl & 31)) & 1u));
                 }
             }
             const unsigned long long mask = __ballot(alive);
@@ -601,7 +604,7 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
                     if constexpr (TXG) {
                         if (alive) alive = nan_possible_txg<K, APPROX>(pbx, pby, w, a.txx, a.txy, plen);
                     } else {
-                        if (alive) alive = nan_possible_rx<K, APPROX>(pbx, pby, w, Ix, Iy, a.txx, a.txy, plen);
+                        if (alive) alive = nan_possible_rx<K, APPROX>(pbx, pby, w, Ix, Iy, a.txx, a.txy, plen, (int)((nearbits[w[K - 1].idx >> 5] >> (w[K - 1].idx & 31)) & 1u));
                     }
                 }
                 unsigned long long mask = __ballot(alive);
@@ -639,7 +642,7 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
 
 template <bool APPROX, bool TXG, int MAXK>
 __global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a, unsigned long long* __restrict__ stats) {
-    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, the region's list [NAN_LCAP], then [NAN_W][ceil(N / 32)] flag bits
+    extern __shared__ float4 tab[];  // [2N] refl, [N] flt, the region's list [NAN_LCAP], then [2 NAN_W + 1][ceil(N / 32)] flag bits
     __shared__ float pbox[NAN_W][4];
     __shared__ int lcount[2];
     __shared__ int sbad;
@@ -649,7 +652,9 @@ __global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a
     unsigned long long* list = reinterpret_cast<unsigned long long*>(tab + 3 * a.N);
     const int nwords = (a.N + 31) >> 5;
     unsigned* wallbits_all = reinterpret_cast<unsigned*>(list + NAN_LCAP);
-    for (int i = threadIdx.x; i < NAN_W * nwords; i += 64 * NAN_W) wallbits_all[i] = 0u;
+    for (int i = threadIdx.x; i < (2 * NAN_W + 1) * nwords; i += 64 * NAN_W) wallbits_all[i] = 0u;
+    // [NAN_W][nwords] per patch, then [nwords] of the region: walls whose line some CELL is within the near-coincidence bound of
+    unsigned* nearbits_all = wallbits_all + NAN_W * nwords;
     if (threadIdx.x == 0) {
         lcount[0] = lcount[1] = 0;
         sbad = 0;
@@ -684,6 +689,25 @@ __global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a
         pbox[wv][0] = x0; pbox[wv][1] = x1; pbox[wv][2] = y0; pbox[wv][3] = y1;
     }
     if (wave_any(lane_bad) && lane == 0) atomicOr(&sbad, 1);
+    unsigned* nearbits = nearbits_all + wv * nwords;
+    unsigned* region_near = nearbits_all + NAN_W * nwords;
+    if (!TXG) {
+        // The last segment of a path (interaction point on the candidate's last wall -> the cell) can only vanish, or be the
+        // (eps, eps) of rule (3), for a cell within a few ulps (+ NAN_ABS) of that wall's line: |vn| <= dv in nan_possible_rx's
+        // terms.  A box is crossed by a line far more often than a cell sits on it: the cells themselves are asked, once per
+        // wall (lanes = cells), and the candidate tests look the answer up.
+        const float eps = 1.1920929e-07f;
+        const float abs3 = (a.fun_id != D2D_FUN_ONE) ? NAN_ABS : 0.0f;
+        for (int w0 = 0; w0 < a.N; ++w0) {
+            const float4 q = ldc4(a.refl, 2 * w0);
+            const float vn = __builtin_fmaf(q.x - cx, q.z, (q.y - cy) * q.w);
+            const float dv = 32.0f * eps * ((fabsf(cx) + fabsf(cy)) + (fabsf(q.x) + fabsf(q.y))) + abs3;
+            if (wave_any(!(fabsf(vn) > dv)) && lane == 0) {
+                nearbits[w0 >> 5] |= 1u << (w0 & 31);
+                atomicOr(&region_near[w0 >> 5], 1u << (w0 & 31));
+            }
+        }
+    }
     __syncthreads();
     float r0 = pbox[lane & (NAN_W - 1)][0], r1 = pbox[lane & (NAN_W - 1)][1], r2 = pbox[lane & (NAN_W - 1)][2], r3 = pbox[lane & (NAN_W - 1)][3];
 #pragma unroll
@@ -706,13 +730,13 @@ __global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a
         any_nan = wave_any(cell_nan);
     }
     if (a.min_order <= 1 && a.max_order >= 1)
-        nan_region_order<1, APPROX, TXG>(a, tab, list, lcount, wallbits, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<1, APPROX, TXG>(a, tab, list, lcount, wallbits, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
     if (a.min_order <= 2 && a.max_order >= 2)
-        nan_region_order<2, APPROX, TXG>(a, tab, list, lcount, wallbits, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<2, APPROX, TXG>(a, tab, list, lcount, wallbits, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3)
-        nan_region_order<3, APPROX, TXG>(a, tab, list, lcount, wallbits, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<3, APPROX, TXG>(a, tab, list, lcount, wallbits, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
     if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4)
-        nan_region_order<4, APPROX, TXG>(a, tab, list, lcount, wallbits, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<4, APPROX, TXG>(a, tab, list, lcount, wallbits, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
     const float qnan = __builtin_nanf("");
     if (cell_nan && in_range && patch_exists) {
         a.grad[2 * idx] = qnan;
