@@ -95,6 +95,11 @@ def main():
             else:
                 ok = np.array_equal(got, want, equal_nan=True)
             ok = ok and np.array_equal(got, again, equal_nan=True)
+            if case % 10 == 9 and not role_tx and len(walls):
+                # the instrumented build (d2d_power_map_stats) writes the product kernels' map, bit for bit
+                from differt2d_amd.engine import make_params
+                ctx.launch_stats(make_params(**kw), tx)
+                ok = ok and np.array_equal(got, ctx.get_map(), equal_nan=True)
             if not ok:
                 bad += 1
                 d = np.abs(got - want)
