@@ -719,6 +719,7 @@ int d2d_set_scene(d2d_ctx* c, const float* xys, const uint8_t* kind, const float
     }
     // from here on the old scene is gone: a failed upload leaves the context without a scene, never with half of one
     c->have_scene = false;
+    c->cust_C = -1;               // (a host-evaluated path function's rows belong to the paths of the previous scene)
     c->have_vjp = false;          // d_vjp was sized for (and computed from) the previous scene
     c->have_kernel_time = false;
     c->cost_tiles = 0;  // the patch-cost history describes another sweep
@@ -752,6 +753,7 @@ int d2d_set_candidate_mask(d2d_ctx* c, const uint8_t* allowed) {
         for (int j = 0; j < c->N && same; ++j) same = (c->allowed[(size_t)j] != 0) == (allowed ? allowed[j] != 0 : true);
         if (same) return D2D_OK;  // the mask in place already
     }
+    c->cust_C = -1;     // (... and to the candidates of the previous mask)
     c->cost_tiles = 0;  // the patch-cost history describes another sweep
     for (int i = 0; i < d2d_ctx::N_SPARE; ++i) c->spare_sets[i].cost_tiles = 0;
     int rc = set_device(c);

@@ -212,7 +212,8 @@ int d2d_set_cotangent(d2d_ctx* ctx, const float* cot);
  * chains them through the hand-derived adjoint of the validity and of the image method: d2d_get_map returns
  * sum_c valid_c * f_c and d2d_get_grad_rx its derivative w.r.t. the cell, d2d_get_scene_vjp the pull-back to the fixed
  * end point and the wall end points THROUGH THE PATHS (fun's own dependence on the objects is the caller's).
- * Host arrays, copied before the call returns; NULL / 0 drops them; reset by d2d_set_grid.  D2D_ERR_STATE from the launch
+ * Host arrays, copied before the call returns; NULL / 0 drops them; dropped by d2d_set_grid, by a different scene and by
+ * a different candidate mask.  D2D_ERR_STATE from the launch
  * when n_candidates is not the number of candidates the sweep walks. */
 int d2d_set_path_fun_values(d2d_ctx* ctx, const float* f, const float* xys_bar, int64_t n_candidates);
 
