@@ -204,6 +204,9 @@ struct WaveStats {
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p); }
 
 // counter I += x in a vector register (see WaveStats)
+#ifndef D2D_WALL_PAIRS
+#define D2D_WALL_PAIRS 1  // A/B: 0 = the wall loop of eval_candidate takes one wall per trip (rounds 1 - 3)
+#endif
 #ifndef D2D_STAT_MASK  // (A/B: the counters an instrumented build keeps)
 #define D2D_STAT_MASK 0xffff
 #endif
@@ -656,6 +659,139 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // do not depend on the order of the tests, and neighbouring candidates tend to share their occluder.
     // (the next wall's data are fetched while this one is tested: a lone wave would otherwise sit out one scalar-load
     // latency per wall)
+    // (hard validity only: hard_sigmoid loses 3 % with two walls per trip -- 0.138 against 0.134 ms at cfg2 --, sigmoid's kernel
+    // spills: 9.6 ms against 5.0)
+    constexpr bool PAIRS = D2D_WALL_PAIRS && MODE == MODE_HARD;
+    if constexpr (PAIRS) {
+    // Two walls per trip: their filters are independent instruction streams (a lone wave issues a dependent chain at a
+    // fraction of its rate), and the wave-level question "does any lane need an exact test" is asked once for both.  The
+    // exact tests recompute the three bilinear forms (the same expressions on the same operands: the same bits) instead of
+    // keeping them in registers for the one wall in ten that needs them.
+    auto filt = [&](const float4& ww, int jj) -> unsigned {
+        unsigned wbits = 0u;  // bit i: this lane needs the exact test of segment i
+#pragma unroll
+        for (int i = 0; i <= K; ++i) {
+            const int ig0 = (i == 0) ? -1 : cand[i - 1];
+            const int ig1 = (i == K) ? -1 : cand[i];
+            const bool skip = (jj == ig0 || jj == ig1);  // wave-uniform: a segment ignores the walls it joins
+            float Cx = ww.x - px[i], Cy = ww.y - py[i];
+            float fa = by[i] * Cx - bx[i] * Cy;   // geometry.py:157
+            float fb = ww.z * Cy - ww.w * Cx;     // geometry.py:158
+            float fd = ww.w * bx[i] - ww.z * by[i]; // geometry.py:159
+            // divide-free filter: t = fl(num/fd) certainly outside [flt_lo, flt_hi]?  num/fd lies outside iff
+            // (num - lo fd)(num - hi fd) > 0, whatever the sign of fd; each factor is one fma, so its sign is the exact
+            // difference's, and a product that underflows to 0 (tiny fd, or a numerator on a window edge) counts as "not
+            // certainly outside": the exact test decides.  One compare per segment instead of six and their mask algebra.
+            float pa = __builtin_fmaf(-a.flt_lo, fd, fa) * __builtin_fmaf(-a.flt_hi, fd, fa);
+            float pb = __builtin_fmaf(-a.flt_lo, fd, fb) * __builtin_fmaf(-a.flt_hi, fd, fb);
+            bool miss = fmaxf(pa, pb) > 0.0f;
+            if (MODE == MODE_SIG && !skip) any_test = true;
+            if (STATS) stat_add<4>(st, skip ? 0 : 1);  // (branch-free on purpose: see the single-wall loop below)
+            wbits |= (!skip && active && (!miss || bad)) ? (1u << i) : 0u;
+        }
+        return wbits;
+    };
+    auto exact = [&](const float4& ww, int jj, unsigned wbits) {
+#pragma unroll
+        for (int i = 0; i <= K; ++i) {
+            if (!wave_any((wbits >> i) & 1u)) continue;
+            if (STATS) stat_add<5>(st, 1);
+            D2D_WORK(2);
+            const float Cx = ww.x - px[i], Cy = ww.y - py[i];
+            const float fa = by[i] * Cx - bx[i] * Cy;
+            const float fb = ww.z * Cy - ww.w * Cx;
+            const float fd = ww.w * bx[i] - ww.z * by[i];
+            // exact path, geometry.py:163-171
+            bool dz = (fd == 0.0f);
+            float dd = dz ? 1.0f : fd;
+            float ta, tb;
+            div2_exact(fa, fb, dd, ta, tb);
+            ta = dz ? __builtin_inff() : ta;
+            tb = dz ? __builtin_inff() : tb;
+            if (MODE == MODE_HARD) {
+                bool h = (ta >= a.seg_lo) && (ta <= a.seg_hi) && (tb >= a.seg_lo) && (tb <= a.seg_hi);
+                hit_b = hit_b || h;
+            } else if (MODE == MODE_HSIG) {
+                nanflag = nanflag || (ta != ta) || (tb != tb);
+                float c = fminf(fminf(clampact(ta - a.seg_lo, a.alpha), clampact(a.seg_hi - ta, a.alpha)),
+                                fminf(clampact(tb - a.seg_lo, a.alpha), clampact(a.seg_hi - tb, a.alpha)));
+                // arg-max as the reference's ascending (j, i) scan finds it: the first of equal maxima
+                if (GRAD && (c > hit_c || (c == hit_c && hit_j >= 0 && (jj < hit_j || (jj == hit_j && i < hit_i))))) {
+                    hit_i = i;
+                    hit_j = jj;
+                }
+                hit_c = fmaxf(hit_c, c);
+            } else {
+                nanflag = nanflag || (ta != ta) || (tb != tb);
+                float z = fminf(fminf(a.alpha * (ta - a.seg_lo), a.alpha * (a.seg_hi - ta)),
+                                fminf(a.alpha * (tb - a.seg_lo), a.alpha * (a.seg_hi - tb)));
+                if (GRAD && (z > hit_z || (z == hit_z && hit_j >= 0 && (jj < hit_j || (jj == hit_j && i < hit_i))))) {
+                    hit_i = i;
+                    hit_j = jj;
+                }
+                hit_z = fmaxf(hit_z, z);
+            }
+        }
+        // decided lanes: occlusion already makes valid exactly 0
+        if (MODE == MODE_HARD) active = active && (!hit_b || bad);
+        else if (MODE == MODE_HSIG) active = active && (hit_c != 6.0f || bad);
+        else active = active && (hit_z < 17.5f || bad);
+    };
+    {
+        bool done = a.N <= 0;
+        if (!done && sh >= 0) {  // the cached occluder, on its own: it usually ends the loop
+            const unsigned b0 = filt(w, sh);
+            D2D_WORK(K + 1);
+            if (wave_any(b0 != 0u)) {
+                exact(w, sh, b0);
+                if (!wave_any(active)) {
+                    st.shadow = sh;
+                    done = true;
+                }
+            }
+        }
+        auto next_idx = [&](int x) -> int {
+            ++x;
+            return x == sh ? x + 1 : x;
+        };
+        int jA = (sh == 0) ? 1 : 0;
+        if (!done && jA < a.N) {
+            int jB = next_idx(jA);
+            float4 wA = (sh >= 0) ? ldc4(a.occl, jA) : w;  // (w holds wall 0 when there is no cached occluder)
+            float4 wB = ldc4(a.occl, jB < a.N ? jB : jA);
+            while (true) {
+                const bool hasB = jB < a.N;
+                const int nA = next_idx(jB), nB = next_idx(nA);
+                // (the next trip's walls: their loads fly while this trip computes)
+                const float4 wnA = ldc4(a.occl, nA < a.N ? nA : jA), wnB = ldc4(a.occl, nB < a.N ? nB : jA);
+                const unsigned ba = filt(wA, jA);
+                const unsigned bb = hasB ? filt(wB, jB) : 0u;
+                D2D_WORK(hasB ? 2 * (K + 1) : (K + 1));
+                if (wave_any((ba | bb) != 0u)) {
+                    if (wave_any(ba != 0u)) {
+                        exact(wA, jA, ba);
+                        if (!wave_any(active)) {
+                            st.shadow = jA;
+                            break;
+                        }
+                    }
+                    if (wave_any(bb != 0u)) {
+                        exact(wB, jB, bb);
+                        if (!wave_any(active)) {
+                            st.shadow = jB;
+                            break;
+                        }
+                    }
+                }
+                if (!(nA < a.N)) break;
+                jA = nA;
+                jB = nB;
+                wA = wnA;
+                wB = wnB;
+            }
+        }
+    }
+    } else {
     int nxt = sh >= 0 ? 0 : 1;
     if (nxt == sh) ++nxt;
     for (bool more = a.N > 0; more;) {
@@ -747,6 +883,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         w = wn;
         ++nxt;
         if (nxt == sh) ++nxt;
+    }
     }
     // every lane occluded (or off its walls): valid == 0 whatever the loss is
     if (!wave_any(active)) return;
