@@ -204,6 +204,9 @@ struct WaveStats {
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p); }
 
 // counter I += x in a vector register (see WaveStats)
+#ifndef D2D_WALL_PAIRS_MODES
+#define D2D_WALL_PAIRS_MODES 1  // bit m: validity mode m takes two walls per trip (A/B)
+#endif
 #ifndef D2D_WALL_PAIRS
 #define D2D_WALL_PAIRS 1  // A/B: 0 = the wall loop of eval_candidate takes one wall per trip (rounds 1 - 3)
 #endif
@@ -659,9 +662,10 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // do not depend on the order of the tests, and neighbouring candidates tend to share their occluder.
     // (the next wall's data are fetched while this one is tested: a lone wave would otherwise sit out one scalar-load
     // latency per wall)
-    // (hard validity only: hard_sigmoid loses 3 % with two walls per trip -- 0.138 against 0.134 ms at cfg2 --, sigmoid's kernel
-    // spills: 9.6 ms against 5.0)
-    constexpr bool PAIRS = D2D_WALL_PAIRS && MODE == MODE_HARD;
+    // (hard validity only, D2D_WALL_PAIRS_MODES: hard_sigmoid loses 3 % with two walls per trip -- 0.138 against 0.134 ms at
+    // cfg2: 147 scalars parked in VGPR lanes instead of 62 --, sigmoid's kernel spills: 9.6 ms against 5.0; how far ahead the
+    // pair loop loads its walls -- both next walls before the filters, one, none -- makes no difference: 0.077 - 0.078)
+    constexpr bool PAIRS = D2D_WALL_PAIRS && ((D2D_WALL_PAIRS_MODES >> MODE) & 1);
     if constexpr (PAIRS) {
     // Two walls per trip: their filters are independent instruction streams (a lone wave issues a dependent chain at a
     // fraction of its rate), and the wave-level question "does any lane need an exact test" is asked once for both.  The
