@@ -203,9 +203,22 @@ struct WaveStats {
 
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p); }
 
+// The same wave-uniform index, unknown to the optimiser: a table row loaded through it is loaded HERE, not kept in scalar
+// registers from an earlier load of the same row (the candidate's walls are read before the wall loop and again behind it,
+// where few candidates arrive: held across the loop they are 4 scalars per wall that the loop's own state then has to do without)
+#ifndef D2D_LATE_INDEX
+#define D2D_LATE_INDEX 1
+#endif
+__device__ __forceinline__ int late_index(int i) {
+#if D2D_LATE_INDEX
+    asm volatile("" : "+s"(i));
+#endif
+    return i;
+}
+
 // counter I += x in a vector register (see WaveStats)
 #ifndef D2D_WALL_PAIRS_MODES
-#define D2D_WALL_PAIRS_MODES 1  // bit m: validity mode m takes two walls per trip (A/B)
+#define D2D_WALL_PAIRS_MODES 3  // bit m: validity mode m takes two walls per trip (A/B)
 #endif
 #ifndef D2D_WALL_PAIRS
 #define D2D_WALL_PAIRS 1  // A/B: 0 = the wall loop of eval_candidate takes one wall per trip (rounds 1 - 3)
@@ -662,9 +675,10 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // do not depend on the order of the tests, and neighbouring candidates tend to share their occluder.
     // (the next wall's data are fetched while this one is tested: a lone wave would otherwise sit out one scalar-load
     // latency per wall)
-    // (hard validity only, D2D_WALL_PAIRS_MODES: hard_sigmoid loses 3 % with two walls per trip -- 0.138 against 0.134 ms at
-    // cfg2: 147 scalars parked in VGPR lanes instead of 62 --, sigmoid's kernel spills: 9.6 ms against 5.0; how far ahead the
-    // pair loop loads its walls -- both next walls before the filters, one, none -- makes no difference: 0.077 - 0.078)
+    // (D2D_WALL_PAIRS_MODES: hard and hard_sigmoid.  hard_sigmoid LOST 3 % with two walls per trip -- 147 scalars parked in VGPR
+    // lanes instead of 62 -- until the loss stage reloaded its walls' rows (late_index): 0.132 -> 0.125 ms at cfg2 with both;
+    // sigmoid gains nothing, 5.0 ms either way.  How far ahead the pair loop loads its walls -- both next walls before the
+    // filters, one, none -- makes no difference: 0.077 - 0.078)
     constexpr bool PAIRS = D2D_WALL_PAIRS && ((D2D_WALL_PAIRS_MODES >> MODE) & 1);
     if constexpr (PAIRS) {
     // Two walls per trip: their filters are independent instruction streams (a lone wave issues a dependent chain at a
@@ -916,7 +930,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         float bound = 0.0f;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            const float4 r0 = ldc4(a.refl, 2 * cand[i]);
+            const float4 r0 = ldc4(a.refl, 2 * late_index(cand[i]));
             float s2 = 2.0f * __builtin_fmaf(nvx[i], r0.z, nvy[i] * r0.w);
             float ex = __builtin_fmaf(s2, r0.z, nvx[i + 1] - nvx[i]);
             float ey = __builtin_fmaf(s2, r0.w, nvy[i + 1] - nvy[i]);
@@ -928,7 +942,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     if (!loss_known) {
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-            const float4 r0 = ldc4(a.refl, 2 * cand[i]);
+            const float4 r0 = ldc4(a.refl, 2 * late_index(cand[i]));
             float ix, iy, rx_, ry_;
             normalize2(px[i + 1] - px[i], py[i + 1] - py[i], ix, iy);
             normalize2(px[i + 2] - px[i + 1], py[i + 2] - py[i + 1], rx_, ry_);
