@@ -1237,7 +1237,17 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     bool prep_zeroed = false;
     bool m_masks_ok = false;  // the masks' certified window and bins (set with the shadow masks below)
     double m_in_lo = 0.0, m_in_hi = 0.0, m_dom_lo = 0.0, m_dom_w = 0.0;
-    const bool txg_culled = txg && !c->txg_exhaustive && !(grad_mode && p->strict_nan);  // TX grid: culled kernels
+    // A step of the backward scan with un == 0 (the line to the image parallel to the wall, geometry.py:1105) leaves a
+    // zero-length segment, loss >= 1 (0.999 with roundings): is such a path exactly invalid under this tol / activation?
+    const double x_deg = (double)p->tol - 0.999;  // tol - loss at best
+    const bool degenerate_invalid = !p->approx ? (p->tol <= 0.5f)
+                                    : (mode == d2d::MODE_HSIG ? ((double)p->alpha * x_deg + 3.0 <= -1e-3) : ((double)p->alpha * x_deg <= -89.5));
+    // TX grid: culled kernels -- unless a degenerate path can count.  Their culling walks the chain from the FIXED end (images of
+    // the receiver, first the wall next to the cell), which is the exact chain's LAST step: where an earlier exact step hits
+    // un == 0 the exact points are not the geometric ones the culling reasons about (RX grids cull along the exact chain's own
+    // order and stop at its poles).  Found by scripts/fuzz_parity.py (seed 4003, case 1295: sigmoid, alpha = 10, tol = 0.5 --
+    // a zero-length segment still leaves sigmoid(-5) -- walls on a lattice); tests/test_gpu_forward.py keeps the case.
+    const bool txg_culled = txg && !c->txg_exhaustive && !(grad_mode && p->strict_nan) && degenerate_invalid;
     if ((!txg || txg_culled) && c->N >= 2 && p->max_order >= 1) {
         // [N] masks, then the {histogram, cursors} of the patch schedule's counting sort, then what the region lists need
         // zeroed per launch ({queue length, pool head}, one flag per leaf region): one memset for all of it
@@ -1306,10 +1316,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
                 pair_ext_ok = ext <= 8.0f * c->scene_absmax;  // interaction points of a valid path stay within pdperp of their walls
             }
             // a candidate with un == 0 in some step has a zero-length segment, loss >= 1: is it exactly invalid?
-            const double x = (double)p->tol - 0.999;  // tol - loss at best
-            if (!p->approx) a.shadow_prefix_ok = (p->tol <= 0.5f) ? 1 : 0;
-            else if (mode == d2d::MODE_HSIG) a.shadow_prefix_ok = ((double)p->alpha * x + 3.0 <= -1e-3) ? 1 : 0;
-            else a.shadow_prefix_ok = ((double)p->alpha * x <= -89.5) ? 1 : 0;
+            a.shadow_prefix_ok = degenerate_invalid ? 1 : 0;
             a.pair_prefix_ok = (a.pair && pair_ext_ok && a.shadow_prefix_ok) ? 1 : 0;
         }
     }

@@ -469,3 +469,33 @@ def test_instrumented_build_writes_the_same_map(grid):
                 st = c.launch_stats(p, tx)
                 assert np.array_equal(Z, c.get_map(), equal_nan=True), (kw, orders)
                 assert st[0] > 0 and st[4] > 0
+
+
+def test_tx_grid_with_a_degenerate_step_that_still_counts():
+    """scripts/fuzz_parity.py, seed 4003, case 1295 (the one mismatch in 26 000 fuzz cases over four rounds): a TX grid, sigmoid
+    validity with alpha = 10 and tol = 0.5, walls and cells on a lattice at offset -300.  For one candidate the exact backward
+    scan hits un == 0 (geometry.py:1105) in its first step -- the point stays on the receiver, loss = 1 -- and the path still
+    counts sigmoid(-8) = 3.4e-4, while the TX-grid culling, which walks the chain from the other end, reasoned about the
+    geometric path and dropped it.  TX grids now take the exhaustive kernel whenever a degenerate path is not exactly invalid."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from fuzz_parity import random_case
+
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import Context
+    from oracle import c_oracle as CO
+
+    rng = np.random.default_rng(4003)
+    for case in range(1296):
+        walls, tx, X, Y, kw, allowed = random_case(rng, big=case % 2 == 1)
+    assert kw["function"] == "sigmoid" and kw["alpha"] == 10.0 and len(walls) == 126
+    with Context(0) as c:
+        c.set_option("hidden_min_tiles", 0)
+        c.set_scene(walls)
+        for mask in (allowed, np.isin(np.arange(len(walls)), [1, 7]).astype(np.uint8)):
+            c.set_candidate_mask(mask)
+            got = c.power_map(tx, X, Y, grid_role=L.GRID_TX, **kw)
+            want = CO.power_map(walls, tx, X, Y, allowed=mask, prune=True, grid_role="tx", **kw)
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-5 * max(1.0, float(np.abs(want).max())))
+            assert (got != want).mean() < 0.01  # (sigmoid: bit-equal but for a host libm with an FMA build)
