@@ -13,12 +13,11 @@ template <int VG>
 __global__ void __launch_bounds__(64) worker(unsigned long long* stamps, int n_long, int long_it, int short_it, int interleave, const float4* table,
                                              int table_n) {
     extern __shared__ float lds[];
-    // (table_n > 0: the sweep's head -- a 2.4 KB table staged into LDS behind a barrier -- IN FRONT of the start stamp, as in
-    // power_fwd_kernel: what the stamps then miss of a workgroup's residency shows as slots that look free while workgroups wait)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // (first thing: the stamps bracket the whole residency)
+    // (table_n > 0: the sweep's head as well -- a 2.4 KB table staged into LDS behind a barrier)
     float4* tab = reinterpret_cast<float4*>(lds);
     for (int i = threadIdx.x; i < table_n; i += 64) tab[i] = table[i];
     __syncthreads();
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const bool is_long = interleave ? ((int)blockIdx.x % interleave == 0 && (int)blockIdx.x / interleave < n_long) : ((int)blockIdx.x < n_long);
     const int spin = is_long ? long_it : short_it;
     float x[VG];
