@@ -3,7 +3,9 @@
 or within rtol 2e-5 (sigmoid).  Scenes mix random walls with axis-aligned walls at "nice" coordinates and grids that hit
 them exactly, shared end points (corners), tiny / huge scales, offsets, patch, alpha, tol, filters, orders 0..3.
 
-usage: python scripts/fuzz_parity.py [n_cases] [seed]
+usage: python scripts/fuzz_parity.py [n_cases] [seed] [big]
+       python scripts/fuzz_parity.py --grad [n_cases] [seed]     value + gradient: the DEFAULT (culled) sweep and, every fourth
+                                                                 case, the exhaustive one against oracle/d2d_oracle_grad.c
 """
 
 import os
@@ -59,7 +61,84 @@ def random_case(rng, big=False):
     return walls, tx, X, Y, kw, allowed
 
 
+def grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=False):
+    """One value+grad case against the C gradient oracle (forward-mode duals, nothing shared with the kernels' adjoint).
+    Returns (list of complaints, cells whose gradient was compared, NaN cells).  Values: bit for bit (sigmoid: rtol 1e-6);
+    NaN positions: identical; finite gradients: within 1e-5 of the cell's gradient scale (+ 1e-5 relative; sigmoid 3e-4: at
+    alpha = 100 it amplifies every rounding of its argument) on the cells the ORACLE ALONE calls well conditioned -- its own
+    result survives a one-ulp nudge of the fixed end point and of the cell (scenes snapped to a lattice put end points on
+    walls' lines, where the interaction points are rounding noise for ANY two fp32 evaluation orders)."""
+    role_s = "tx" if role == L.GRID_TX else "rx"
+    okw = dict(kw, grid_role=role_s, allowed=allowed)
+    value, grad, gabs, kink = CO.power_map_grad(walls, tx, X, Y, with_gabs=True, with_kink=True, **okw)
+    up = lambda a: np.nextafter(np.asarray(a, F), F(np.inf))
+    stable = np.ones(X.shape, bool)
+    for tx2, X2, Y2 in ((up(tx), X, Y), (tx, up(X), up(Y))):
+        v2, g2 = CO.power_map_grad(walls, tx2, X2, Y2, **okw)
+        with np.errstate(invalid="ignore"):
+            stable &= np.abs(v2 - value) <= 1e-3 * np.abs(value) + 1e-30
+            stable &= (np.abs(g2 - grad) <= 1e-2 * gabs[..., None] + 1e-30).all(-1)
+    got = ctx.value_and_grads(tx, X, Y, strict_nan=strict, grid_role=role, **kw)
+    out = []
+    sig = kw["approx"] and kw["function"] == "sigmoid"
+    if sig:
+        if not np.allclose(got["value"], value, rtol=2e-5, atol=1e-5 * max(1e-30, float(np.nanmax(np.abs(value), initial=0.0))), equal_nan=True):
+            out.append("value")
+    elif not np.array_equal(got["value"], value, equal_nan=True):
+        out.append(f"value ({int((got['value'] != value).sum())} cells)")
+    g = got["grad_rx"].astype(np.float64)
+    if not np.array_equal(np.isnan(g), np.isnan(grad)):
+        out.append(f"NaN positions (GPU {int(np.isnan(g).sum())}, oracle {int(np.isnan(grad).sum())})")
+    fin = np.isfinite(grad).all(-1) & np.isfinite(g).all(-1) & stable & ~(kink if KINK_MASK else np.zeros_like(kink))
+    rel = 3e-4 if sig else 1e-5
+    floor = 1e-6 * float(np.nanmax(np.abs(grad), initial=0.0)) + 1e-30
+    bar = rel * gabs[..., None] + rel * np.abs(grad) + floor
+    bad = (np.abs(g - grad) > bar).any(-1) & fin
+    if bad.any():
+        w = np.argwhere(bad)[0]
+        out.append(f"gradient ({int(bad.sum())} cells, first {w.tolist()}: GPU {g[tuple(w)]}, oracle {grad[tuple(w)]}, gabs {gabs[tuple(w)]:.3e})")
+    return out, int(fin.sum()), int(np.isnan(grad).any(-1).sum())
+
+
+KINK_MASK = True  # (cells where the oracle met a min / max tie between arguments of different tangent are left out)
+
+
+def main_grad(argv):
+    n_cases = int(argv[0]) if len(argv) > 0 else 200
+    seed = int(argv[1]) if len(argv) > 1 else 0
+    rng = np.random.default_rng(seed)
+    bad = cells = nans = 0
+    t0 = time.time()
+    with Context(0) as ctx:
+        for case in range(n_cases):
+            while True:
+                walls, tx, X, Y, kw, allowed = random_case(rng)
+                if len(walls):
+                    break
+            if kw["max_order"] == 3 and X.size > 1600:  # (the oracle's order-3 duals: keep a case under a second)
+                X, Y = X[:40, :40], Y[:40, :40]
+            kw["fun"] = str(rng.choice(["received_power", "one", "length", "length_squared"]))
+            role = L.GRID_TX if case % 3 == 2 else L.GRID_RX
+            ctx.set_scene(walls)
+            ctx.set_candidate_mask(allowed)
+            ctx.set_option("nan_scan", 2 if case % 5 == 4 else 1)
+            ctx.set_option("sched_min_tiles", 1 if case % 4 < 2 else 1 << 40)
+            msgs, c, n = grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=case % 4 == 3)
+            cells += c
+            nans += n
+            if msgs:
+                bad += 1
+                print(f"MISMATCH case {case} seed {seed} {'TX' if role == L.GRID_TX else 'RX'}-grid strict={case % 4 == 3}: N={len(walls)} "
+                      f"grid={X.shape} kw={kw} allowed={allowed is not None}: " + "; ".join(msgs), flush=True)
+            if case % 200 == 199:
+                print(f"  .. {case + 1} cases, {bad} mismatches, {cells} cells compared, {nans} NaN cells, {time.time() - t0:.0f} s", flush=True)
+    print(f"grad fuzz: {n_cases} cases, {bad} mismatches, {cells} gradient cells compared, {nans} NaN cells, {time.time() - t0:.1f} s (seed {seed})")
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--grad":
+        return main_grad(sys.argv[2:])
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     big = len(sys.argv) > 3 and sys.argv[3] == "big"  # every other case has 65..139 walls
