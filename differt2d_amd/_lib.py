@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("D2D_LIB") or os.path.join(CSRC, "libd2d.so")
 D2D_MAX_ORDER = 4
 D2D_NUM_STATS = 16
 D2D_COMM_ID_BYTES = 128
-D2D_ABI_VERSION = 8
+D2D_ABI_VERSION = 9
 
 D2D_WALL, D2D_RIS, D2D_VERTEX = 0, 1, 2
 SOLVER_IMAGE, SOLVER_MINPATH, SOLVER_FERMAT = 0, 1, 2
@@ -100,6 +100,7 @@ SYMBOLS = [
     ("d2d_set_grid_versioned", C.c_int, [_ctx, _f32p, _f32p, C.c_int32, C.c_int32, C.c_uint64]),
     ("d2d_debug_grid_reuses", C.c_int, [_ctx, C.POINTER(C.c_int64)]),
     ("d2d_debug_sweep_shape", C.c_int, [_ctx, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("d2d_debug_txg_fallbacks", C.c_int, [_ctx, C.POINTER(C.c_int64)]),
     ("d2d_debug_hidden_masks", C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     ("d2d_set_optimizer", C.c_int, [_ctx, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]),
     ("d2d_power_map_launch", C.c_int, [_ctx, C.POINTER(Params), _f32p]),

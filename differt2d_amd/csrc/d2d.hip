@@ -201,6 +201,7 @@ struct d2d_ctx {
     uint64_t grid_fp = 0;                    // strided sample of the resident grid's arrays (checked beside the token)
     bool grid_hash_valid = false;
     int last_shape_waves = 0, last_shape_coop = 0;  // diagnostic: d2d_debug_sweep_shape
+    long long txg_fallbacks = 0;  // diagnostic: d2d_debug_txg_fallbacks
     long long grid_reuses = 0;  // d2d_set_grid calls that found their grid resident already (diagnostic: d2d_debug_grid_reuses)
     float grid_absmax = 0.0f;   // max |coordinate| of the grid (host scan at d2d_set_grid)
     bool grid_all_finite = false;  // every cell coordinate is below 1e18 in magnitude (what the kernels call comfortably finite)
@@ -877,6 +878,12 @@ int d2d_debug_sweep_shape(d2d_ctx* c, int32_t* waves_per_patch, int32_t* candida
     return D2D_OK;
 }
 
+int d2d_debug_txg_fallbacks(d2d_ctx* c, int64_t* count) {
+    if (!c || !count) return fail(D2D_ERR_INVALID, "NULL argument");
+    *count = c->txg_fallbacks;
+    return D2D_OK;
+}
+
 int d2d_debug_hidden_masks(d2d_ctx* c, int64_t* builds, int32_t* valid) {
     if (!c || !builds || !valid) return fail(D2D_ERR_INVALID, "NULL argument");
     *builds = c->hidden_builds;
@@ -1248,6 +1255,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     // order and stop at its poles).  Found by scripts/fuzz_parity.py (seed 4003, case 1295: sigmoid, alpha = 10, tol = 0.5 --
     // a zero-length segment still leaves sigmoid(-5) -- walls on a lattice); tests/test_gpu_forward.py keeps the case.
     const bool txg_culled = txg && !c->txg_exhaustive && !(grad_mode && p->strict_nan) && degenerate_invalid;
+    if (txg && !c->txg_exhaustive && !(grad_mode && p->strict_nan) && !degenerate_invalid) ++c->txg_fallbacks;
     if ((!txg || txg_culled) && c->N >= 2 && p->max_order >= 1) {
         // [N] masks, then the {histogram, cursors} of the patch schedule's counting sort, then what the region lists need
         // zeroed per launch ({queue length, pool head}, one flag per leaf region): one memset for all of it

@@ -545,6 +545,14 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     bool bad = lane_bad;
 #pragma unroll
     for (int i = 1; i <= K; ++i) bad = bad || !(fabsf(px[i]) < 1e18f) || !(fabsf(py[i]) < 1e18f);
+    if (GRAD && a.fun_id == D2D_FUN_CUSTOM) {
+        // a host-evaluated path function that is inf / NaN for this (candidate, cell) -- or whose derivative is -- must meet the
+        // candidate's valid = 0 for real (0 * NaN = NaN in the reference's sum, scene.py:1909, and in its gradient)
+        const float* pb = a.cust_pb + cust * (2 * (D2D_MAX_ORDER + 2));
+        bad = bad || !(fabsf(a.cust_f[cust]) < 3.0e38f);
+#pragma unroll
+        for (int i = 0; i < 2 * (K + 2); ++i) bad = bad || !(fabsf(pb[i]) < 3.0e38f);
+    }
 
     // ---- on_objects, geometry.py:821-854 / 589-621 ----------------------------------------
     bool on_b = true;     // MODE_HARD

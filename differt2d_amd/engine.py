@@ -195,6 +195,13 @@ class Context:
         L.check(self._lib.d2d_debug_sweep_shape(self._ctx, C.byref(w), C.byref(k)))
         return int(w.value), bool(k.value)
 
+    def txg_fallbacks(self) -> int:
+        """Diagnostic: TX-grid sweeps that ran exhaustively because a degenerate path is not exactly invalid under their
+        tol / alpha / activation (include/d2d.h, d2d_params.grid_role)."""
+        n = C.c_int64(0)
+        L.check(self._lib.d2d_debug_txg_fallbacks(self._ctx, C.byref(n)))
+        return int(n.value)
+
     def hidden_masks(self) -> tuple:
         """Diagnostic: (times the last-segment masks were built, valid now?) (include/d2d.h)."""
         n, v = C.c_int64(0), C.c_int32(0)

@@ -125,13 +125,15 @@ def _recognise_fun(fun, fun_args, fun_kwargs):
     and verified on the others).  Returns (native name, make_params kwargs) or None; a callable that raises on the
     probes, depends on anything but the path's length and order -- the end points it is handed, the kinds, lengths or
     orientations of the interacting objects: every path is probed with two different sets of them -- or matches nothing is
-    left to the host.  The verdict is kept per callable (and arguments), so the probes run once; ``fun._d2d_native = False``
-    opts a callable out."""
+    left to the host.  The verdict is kept per callable (and arguments), so the full probe set runs once; a cached POSITIVE
+    verdict is re-checked on every call against three of the probes (orders 0, 1, 2 -- enough to pin both fitted constants): a
+    callable that reads a global, a closure cell or a mutable attribute (a parameter sweep over ``height``) and changed since
+    is probed afresh instead of being run with the stale fit.  ``fun._d2d_native = False`` opts a callable out."""
     try:
         ckey = (tuple(fun_args), tuple(sorted((fun_kwargs or {}).items())))
         hash(ckey)
         cached = _FUN_VERDICTS.get(fun, {}).get(ckey, "?")
-        if cached != "?":
+        if cached is None or (cached != "?" and _verdict_still_holds(fun, fun_args, fun_kwargs, cached)):
             return cached
     except TypeError:  # unhashable arguments, or a callable that cannot be weakly referenced: probe every time
         ckey = None
@@ -142,6 +144,41 @@ def _recognise_fun(fun, fun_args, fun_kwargs):
         except TypeError:
             pass
     return verdict
+
+
+_PROBES = None
+
+
+def _closed_form(name, extra, r, k):
+    if name == "one":
+        return 1.0
+    if name == "length":
+        return r
+    if name == "length_squared":
+        return r * r
+    return extra.get("r_coef", 0.5) ** k / (extra.get("height", 0.1) ** 2 + r * r)
+
+
+def _verdict_still_holds(fun, fun_args, fun_kwargs, verdict) -> bool:
+    global _PROBES
+    if _PROBES is None:
+        _PROBES = _probe_paths()
+    name, extra = verdict
+    seen = set()
+    try:
+        for pair in _PROBES:
+            a, b, path, inter = pair[0]
+            k = path.xys.shape[0] - 2
+            if k in seen or k > 2:
+                continue
+            seen.add(k)
+            v = float(np.asarray(fun(a, b, path, inter, *fun_args, **(fun_kwargs or {})), dtype=np.float64))
+            want = _closed_form(name, extra, float(path.length()), k)
+            if not np.isfinite(v) or abs(v - want) > 2e-6 * abs(want):
+                return False
+    except Exception:  # noqa: BLE001
+        return False
+    return True
 
 
 def _recognise_fun_uncached(fun, fun_args, fun_kwargs):
@@ -487,7 +524,16 @@ class Scene(Plottable):
 
     def _pairwise_fused(self, fun, fun_args, fun_kwargs, kwargs):
         """The arguments of a fused pairwise sweep -- the receivers of the scene as a 1 x R grid, one launch per transmitter --
-        or None when ``fun`` is not one of the natively fused closed forms (then: GPU trace + host ``fun``)."""
+        or None when ``fun`` is not one of the natively fused closed forms (then: GPU trace + host ``fun``).
+
+        ``"launches"``: (tx name, tx, receiver names, X, Y, theta0 rows or None) per launch.  Optimiser-based path classes with
+        a Threefry key and no explicit ``theta0``: the reference hands every (pair, candidate) its own key from a chain of
+        splits in pair-major order (scene.py:1204-1219, what ``_trace`` reproduces), so every pair is its own 1 x 1 launch with
+        its own initial guesses -- the same numbers whether or not ``fun`` is recognised.  No candidates at all (order = 2 in
+        a scene of one object): no launches, the iterator is empty as the reference's groupby over no paths is."""
+        from . import random as jr
+        from .geometry import _theta0_rows
+
         kwargs = dict(kwargs)
         path_cls = kwargs.pop("path_cls", ImagePath)
         path_cls_kwargs = kwargs.pop("path_cls_kwargs", None)
@@ -497,13 +543,34 @@ class Scene(Plottable):
         if native is None or not self.receivers or not self.transmitters:
             return None
         name, extra = native
-        cands = None
-        if self._solver_of(path_cls) != "image":
-            cands = self.all_path_candidates(min_order, max_order, order=order, filter_objects=filter_objects)
-        sextra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, cands or [], key)
+        solver = self._solver_of(path_cls)
+        cands = self.all_path_candidates(min_order, max_order, order=order, filter_objects=filter_objects)
+        rx_keys = list(self.receivers)
         rx = np.stack([r.xy for r in self.receivers.values()]).astype(F)
-        return dict(params={"fun": name, **extra, **sextra, **common}, theta0=theta0, filter_objects=filter_objects,
-                    X=np.ascontiguousarray(rx[None, :, 0]), Y=np.ascontiguousarray(rx[None, :, 1]))
+        pkw = dict(path_cls_kwargs or {})
+        chain = solver != "image" and key is not None and not isinstance(key, np.random.Generator) and pkw.get("theta0") is None
+        launches = []
+        if not cands:
+            sextra = dict(solver=solver)
+        elif chain:
+            steps, many, _, optimizer = _opt_kwargs(pkw)
+            self._ctx().set_optimizer(optimizer)
+            sextra = dict(solver=solver, steps=steps, many=many)
+            counts = [sum(o.parameters_count() for o in self.get_interacting_objects(c)) for c in cands]
+            key = jr.as_key(key)
+            for tx_key, tx in self.transmitters.items():  # (all_transmitter_receiver_pairs: transmitter-major)
+                for j, rx_key in enumerate(rx_keys):
+                    rows = []
+                    for c in counts:
+                        key, key_path = jr.split(key, 2)
+                        rows.extend(_theta0_rows(key_path, c, many))
+                    launches.append((tx_key, tx, [rx_key], np.ascontiguousarray(rx[None, j : j + 1, 0]),
+                                     np.ascontiguousarray(rx[None, j : j + 1, 1]), rows))
+        else:
+            sextra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, cands if solver != "image" else [], key)
+            X, Y = np.ascontiguousarray(rx[None, :, 0]), np.ascontiguousarray(rx[None, :, 1])
+            launches = [(tx_key, tx, rx_keys, X, Y, theta0) for tx_key, tx in self.transmitters.items()]
+        return dict(params={"fun": name, **extra, **sextra, **common}, filter_objects=filter_objects, launches=launches)
 
     def accumulate_over_paths(self, fun: PathFun, fun_args: tuple = (), fun_kwargs: Optional[Mapping] = None, *,
                               reduce_all: bool = False, **kwargs):
@@ -515,14 +582,15 @@ class Scene(Plottable):
 
         def fused_results():
             ctx = self._ctx()
-            for tx_key, tx in self.transmitters.items():
+            params = make_params(**fused["params"])
+            for tx_key, tx, rx_keys, X, Y, theta0 in fused["launches"]:
                 self._upload(ctx, fused["filter_objects"])
-                ctx.set_grid(fused["X"], fused["Y"])
-                if fused["theta0"] is not None:
-                    ctx.set_theta0(fused["theta0"])
-                ctx.launch(make_params(**fused["params"]), tx.xy)
+                ctx.set_grid(X, Y)
+                if theta0 is not None:
+                    ctx.set_theta0(theta0)
+                ctx.launch(params, tx.xy)
                 row = ctx.get_map()[0]
-                for j, rx_key in enumerate(self.receivers):
+                for j, rx_key in enumerate(rx_keys):
                     yield tx_key, rx_key, F(row[j])
 
         def results():
@@ -566,30 +634,31 @@ class Scene(Plottable):
         params = make_params(**fused["params"])
         values = {}
         if callable(cotangent) or cotangent is None:
-            for tx_key, tx in self.transmitters.items():
+            for tx_key, tx, keys, X, Y, theta0 in fused["launches"]:
                 self._upload(ctx, fused["filter_objects"])
-                ctx.set_grid(fused["X"], fused["Y"])
-                if fused["theta0"] is not None:
-                    ctx.set_theta0(fused["theta0"])
+                ctx.set_grid(X, Y)
+                if theta0 is not None:
+                    ctx.set_theta0(theta0)
                 ctx.launch(params, tx.xy)
                 row = ctx.get_map()[0]
-                values.update({(tx_key, k): F(row[j]) for j, k in enumerate(rx_keys)})
+                values.update({(tx_key, k): F(row[j]) for j, k in enumerate(keys)})
         cot = cotangent(dict(values)) if callable(cotangent) else cotangent
         n = len(self.objects)
-        vjp = {"transmitters": {}, "receivers": {k: np.zeros(2, F) for k in rx_keys}, "objects": np.zeros((n, 2, 2), F), "phi": np.zeros(n, F)}
-        for tx_key, tx in self.transmitters.items():
-            w = np.ones((1, len(rx_keys)), F) if cot is None else np.array([[cot.get((tx_key, k), 0.0) for k in rx_keys]], F)
+        vjp = {"transmitters": {k: np.zeros(2, F) for k in self.transmitters}, "receivers": {k: np.zeros(2, F) for k in rx_keys},
+               "objects": np.zeros((n, 2, 2), F), "phi": np.zeros(n, F)}
+        for tx_key, tx, keys, X, Y, theta0 in fused["launches"]:
+            w = np.ones((1, len(keys)), F) if cot is None else np.array([[cot.get((tx_key, k), 0.0) for k in keys]], F)
             self._upload(ctx, fused["filter_objects"])
-            ctx.set_grid(fused["X"], fused["Y"])
+            ctx.set_grid(X, Y)
             ctx.set_cotangent(w)
-            if fused["theta0"] is not None:
-                ctx.set_theta0(fused["theta0"])
+            if theta0 is not None:
+                ctx.set_theta0(theta0)
             ctx.launch_vg(params, tx.xy, scene_vjp=True)
             row, g = ctx.get_map()[0], ctx.get_grad_rx()[0]
             tx_bar, objects_bar, phi_bar = ctx.get_scene_vjp(with_phi=True)
-            values.update({(tx_key, k): F(row[j]) for j, k in enumerate(rx_keys)})
-            vjp["transmitters"][tx_key] = tx_bar
-            for j, k in enumerate(rx_keys):
+            values.update({(tx_key, k): F(row[j]) for j, k in enumerate(keys)})
+            vjp["transmitters"][tx_key] = (vjp["transmitters"][tx_key] + tx_bar).astype(F)
+            for j, k in enumerate(keys):
                 vjp["receivers"][k] = (vjp["receivers"][k] + w[0, j] * g[j]).astype(F)
             vjp["objects"] = (vjp["objects"] + objects_bar).astype(F)
             vjp["phi"] = (vjp["phi"] + phi_bar).astype(F)

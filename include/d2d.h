@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define D2D_MAX_ORDER 4 /* highest interaction order a sweep accepts */
-#define D2D_ABI_VERSION 8
+#define D2D_ABI_VERSION 9
 
 typedef enum d2d_status {
     D2D_OK = 0,
@@ -91,7 +91,12 @@ typedef struct d2d_params {
                            (accumulate_on_receivers_grid_over_paths, differt2d/scene.py:1803-1953);
                            D2D_GRID_TX: the grid cells are transmitters and the `tx` argument of the launch is the
                            fixed RECEIVER (accumulate_on_transmitters_grid_over_paths, differt2d/scene.py:1489-1648);
-                           the per-cell gradient is then taken w.r.t. the transmitter (scene.py:1617-1620) */
+                           the per-cell gradient is then taken w.r.t. the transmitter (scene.py:1617-1620).
+                           TX grids run the culled kernels only while a path with a zero-length segment (a step of the backward
+                           scan with un == 0, loss >= 0.999) is EXACTLY invalid under `tol` / `alpha` / the activation: hard
+                           tol <= 0.5; hard_sigmoid alpha (tol - 0.999) + 3 <= 0; sigmoid alpha (tol - 0.999) <= -89.5 (e.g.
+                           NOT sigmoid with alpha = 10).  Otherwise every (cell, candidate) is evaluated -- correct, tens of
+                           times slower, and counted by d2d_debug_txg_fallbacks */
     int32_t strict_nan; /* value+grad sweeps only.  The reference's reverse-mode autodiff returns NaN for a cell whenever the
                            backward scan of ANY candidate -- valid or not -- hits un == 0 (differt2d/geometry.py:1105) or, in
                            the approx modes, a zero-length segment (normalize, :227-228).  0 (default): candidates that tile
@@ -170,6 +175,10 @@ int d2d_debug_grid_reuses(d2d_ctx* ctx, int64_t* count);
  * patches cut in parts), 4 (patches shared by 4 waves prefix by prefix) or, with candidates = 1, the 4 / 8 / 16 waves of
  * the kernel that shares a patch candidate by candidate (options coop_waves, coop_max_tiles); 0 before any sweep. */
 int d2d_debug_sweep_shape(d2d_ctx* ctx, int32_t* waves_per_patch, int32_t* candidates);
+/* Diagnostic: how many TX-grid sweeps of this context ran the EXHAUSTIVE kernel although culling was asked for (no
+ * strict_nan, no "txg_exhaustive" option), because a degenerate path is not exactly invalid under their parameters (see
+ * d2d_params.grid_role) -- so that a bench or a profile does not misattribute that time. */
+int d2d_debug_txg_fallbacks(d2d_ctx* ctx, int64_t* count);
 /* Diagnostic: how often the last-segment masks of the leaf regions ("hidden_masks" option) were built, and whether the
  * context holds valid ones now. */
 int d2d_debug_hidden_masks(d2d_ctx* ctx, int64_t* builds, int32_t* valid);

@@ -65,7 +65,8 @@ def grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=False):
     """One value+grad case against the C gradient oracle (forward-mode duals, nothing shared with the kernels' adjoint).
     Returns (list of complaints, cells whose gradient was compared, NaN cells).  Values: bit for bit (sigmoid: rtol 1e-6);
     NaN positions: identical; finite gradients: within 1e-5 of the cell's gradient scale (+ 1e-5 relative; sigmoid 3e-4: at
-    alpha = 100 it amplifies every rounding of its argument) on the cells the ORACLE ALONE calls well conditioned -- its own
+    alpha = 100 it amplifies every rounding of its argument; + what one ulp of the cell or of the fixed end point moves the
+    oracle's own gradient by) on the cells the ORACLE ALONE calls well conditioned -- its own
     result survives a one-ulp nudge of the fixed end point and of the cell (scenes snapped to a lattice put end points on
     walls' lines, where the interaction points are rounding noise for ANY two fp32 evaluation orders)."""
     role_s = "tx" if role == L.GRID_TX else "rx"
@@ -73,11 +74,13 @@ def grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=False):
     value, grad, gabs, kink = CO.power_map_grad(walls, tx, X, Y, with_gabs=True, with_kink=True, **okw)
     up = lambda a: np.nextafter(np.asarray(a, F), F(np.inf))
     stable = np.ones(X.shape, bool)
+    sens = np.zeros(X.shape + (2,))  # how far ONE ulp of an input moves the oracle's own gradient
     for tx2, X2, Y2 in ((up(tx), X, Y), (tx, up(X), up(Y))):
         v2, g2 = CO.power_map_grad(walls, tx2, X2, Y2, **okw)
         with np.errstate(invalid="ignore"):
             stable &= np.abs(v2 - value) <= 1e-3 * np.abs(value) + 1e-30
             stable &= (np.abs(g2 - grad) <= 1e-2 * gabs[..., None] + 1e-30).all(-1)
+            sens = np.maximum(sens, np.nan_to_num(np.abs(g2 - grad)))
     got = ctx.value_and_grads(tx, X, Y, strict_nan=strict, grid_role=role, **kw)
     out = []
     sig = kw["approx"] and kw["function"] == "sigmoid"
@@ -92,7 +95,7 @@ def grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=False):
     fin = np.isfinite(grad).all(-1) & np.isfinite(g).all(-1) & stable & ~(kink if KINK_MASK else np.zeros_like(kink))
     rel = 3e-4 if sig else 1e-5
     floor = 1e-6 * float(np.nanmax(np.abs(grad), initial=0.0)) + 1e-30
-    bar = rel * gabs[..., None] + rel * np.abs(grad) + floor
+    bar = rel * gabs[..., None] + rel * np.abs(grad) + floor + sens  # (no fp32 evaluation is pinned tighter than one input ulp)
     bad = (np.abs(g - grad) > bar).any(-1) & fin
     if bad.any():
         w = np.argwhere(bad)[0]

@@ -141,6 +141,43 @@ def test_accumulate_over_paths():
     np.testing.assert_allclose(total, 6.0, rtol=1e-6)
 
 
+@pytest.mark.parametrize("path_cls_name", ["MinPath", "FermatPath"])
+def test_accumulate_over_paths_keyed_optimiser_classes_fused_equals_traced(path_cls_name):
+    """with a Threefry key the reference hands every (pair, candidate) its own key from a chain of splits
+    (scene.py:1204-1219).  The fused route (a recognised `fun`) and the traced route (`_d2d_native = False`) must draw the
+    same initial guesses -- the same numbers whichever way `fun` runs -- and an explicit theta0 is shared by all pairs in both;
+    no candidates at all: an empty iterator in both (the reference's groupby over no paths)."""
+    import differt2d_amd.geometry as G
+    from differt2d_amd.geometry import Point
+    from differt2d_amd.random import PRNGKey
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import received_power
+
+    path_cls = getattr(G, path_cls_name)
+    scene = Scene.square_scene_with_obstacle()
+    scene = scene.with_transmitters(tx_a=Point(xy=np.array([0.5, 0.7], F)), tx_b=Point(xy=np.array([0.15, 0.35], F)))
+    scene = scene.with_receivers(rx_0=Point(xy=np.array([0.3, 0.1], F)), rx_1=Point(xy=np.array([0.5, 0.1], F)),
+                                 rx_2=Point(xy=np.array([0.83, 0.41], F)))
+    host_fun = lambda t, r, p, o: received_power(t, r, p, o)  # noqa: E731
+    host_fun._d2d_native = False
+    # few steps: the solver has NOT converged, so the result depends on the initial guess (what the key decides)
+    kw = dict(max_order=2, approx=True, path_cls=path_cls, path_cls_kwargs=dict(steps=7), key=PRNGKey(1234))
+    fused = list(scene.accumulate_over_paths(received_power, **kw))
+    traced = list(scene.accumulate_over_paths(host_fun, **kw))
+    assert [(a, b) for a, b, _ in fused] == [(a, b) for a, b, _ in traced] and len(fused) == 6
+    np.testing.assert_allclose([v for *_, v in fused], [v for *_, v in traced], rtol=2e-6, atol=1e-9)
+    other = list(scene.accumulate_over_paths(received_power, **dict(kw, key=PRNGKey(1235))))
+    assert not np.allclose([v for *_, v in fused], [v for *_, v in other], rtol=1e-4), "the key must matter after 7 steps"
+    # pairs of one transmitter must not share their guesses: the chain gives each its own
+    values, vjp = scene.accumulate_over_paths_value_and_vjp(received_power, **kw)
+    assert [values[(a, b)] for a, b, _ in fused] == [v for *_, v in fused]
+    assert all(np.isfinite(vjp["transmitters"][k]).all() for k in ("tx_a", "tx_b"))
+    one = Scene(transmitters=scene.transmitters, receivers=scene.receivers, objects=scene.objects[:1])
+    assert list(one.accumulate_over_paths(received_power, **dict(kw, order=2))) == []
+    assert list(one.accumulate_over_paths(host_fun, **dict(kw, order=2))) == []
+    assert one.accumulate_over_paths(received_power, reduce_all=True, **dict(kw, order=2)) == 0.0
+
+
 @pytest.mark.parametrize("approx", [False, True])
 def test_accumulate_over_paths_value_and_vjp_like_plot_power_optimize(approx):
     """examples/plot_power_optimize.py:60-93, 207-226 transcribed: `loss(tx_coords, scene)` = -min over the receivers of
@@ -593,7 +630,7 @@ def test_user_functions_are_recognised_by_what_they_compute():
     assert g.shape == (8, 8, 2) and np.array_equal(np.isnan(g), np.isnan(g0)) and np.isfinite(g).mean() > 0.7
     assert np.nanmax(np.abs(g - g0)) <= 3e-3 * np.nanmax(np.abs(g0))  # (the extra factor is 1 + 1e-3 k, k <= 2)
     with pytest.raises(L.D2DUnsupported):
-        scene.accumulate_on_receivers_grid_over_paths(X[:8, :8], Y[:8, :8], fun=lambda t, r, p, o: np.sqrt(p.length()) * len(o),
+        scene.accumulate_on_receivers_grid_over_paths(X[:8, :8], Y[:8, :8], fun=lambda t, r, p, o: np.sort(p.length()) * len(o),
                                                       grad=True, **kw)
 
 

@@ -499,3 +499,7 @@ def test_tx_grid_with_a_degenerate_step_that_still_counts():
             want = CO.power_map(walls, tx, X, Y, allowed=mask, prune=True, grid_role="tx", **kw)
             np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-5 * max(1.0, float(np.abs(want).max())))
             assert (got != want).mean() < 0.01  # (sigmoid: bit-equal but for a host libm with an FMA build)
+        assert c.txg_fallbacks() == 2  # (the diagnostic says so: d2d_debug_txg_fallbacks)
+        c.power_map(tx, X, Y, grid_role=L.GRID_TX, **dict(kw, alpha=100.0, tol=1e-2))
+        c.power_map(tx, X, Y, grid_role=L.GRID_RX, **kw)
+        assert c.txg_fallbacks() == 2  # alpha (tol - 0.999) <= -89.5: culled; RX grids never fall back

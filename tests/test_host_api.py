@@ -234,3 +234,24 @@ def test_from_geojson(how):
         Scene.from_geojson(12345)
     with pytest.raises(json.JSONDecodeError):
         Scene.from_geojson(path)  # a path string is not a JSON document
+
+
+def test_recognised_path_functions_follow_their_free_variables():
+    """a callable that reads a global / closure / mutable attribute must not run with a stale fit after that value
+    changed (a parameter sweep over `height`); the cached verdict is re-checked on three probes per call."""
+    from differt2d_amd.scene import _native_fun
+
+    cfg = {"h": 1.0, "n": 2}
+    fun = lambda tx, rx, path, inter: 0.5 ** len(inter) / (cfg["h"] ** 2 + path.length() ** 2)  # noqa: E731
+    assert _native_fun(fun, (), None) == ("received_power", {"r_coef": 0.5, "height": 1.0})
+    assert _native_fun(fun, (), None) == ("received_power", {"r_coef": 0.5, "height": 1.0})  # (cache hit)
+    cfg["h"] = 3.0
+    assert _native_fun(fun, (), None) == ("received_power", {"r_coef": 0.5, "height": 3.0})
+    power = lambda tx, rx, path, inter: path.length() ** cfg["n"]  # noqa: E731
+    assert _native_fun(power, (), None) == ("length_squared", {})
+    cfg["n"] = 1
+    assert _native_fun(power, (), None) == ("length", {})
+    cfg["n"] = 3
+    assert _native_fun(power, (), None) is None
+    cfg["n"] = 2  # a negative verdict is kept: the host route is always correct
+    assert _native_fun(power, (), None) is None
