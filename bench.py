@@ -28,12 +28,15 @@ roofline  = the kernel is FP32-VALU bound (~1e6 FLOP per H
                                       120 FLOP per lane and level (this repository's own pricing, not a SURVEY figure)
               reference_work_only     the same without the culling: only work the reference's algorithm also does
               unpruned_equivalent     SURVEY.md's unpruned count / time: a statement of pruning, not of utilisation
-            `frac` / `achieved` are executed_with_culling (as in round 1).  `traffic` is null: HBM bytes are not measured
-            inside this run (rocprofv3 PMC passes: profiles/, scripts/profile_gpu.sh).
+            `frac` / `achieved` are executed_with_culling (as in round 1).  `traffic`: HBM bytes per launch from the newest
+            committed PMC summary (profiles/rNN_aM_pmc.json; rocprofv3 PMC passes, scripts/profile_gpu.sh), with its source in
+            `traffic_source` -- not measured inside this run.
 extras    = (N = 1, outside the timed region, skipped by --no-extras) the same map in hard_sigmoid and sigmoid validity, a
             moving-TX sequence (a different transmitter every step: the schedule's work history is then always one step
             stale), the first launch after set_grid, value+grad (default = culling + NaN scan, the exhaustive cross-check,
-            and without the scan), and `parity`: mismatch counts
+            and without the scan), `more_modes` (value+grad in hard_sigmoid / sigmoid validity, TX grids forward and
+            value+grad), configs[3] in hard_sigmoid validity, `cfg5` (configs[4]: MinPath / FermatPath forward and
+            value+grad+VJP), `api` (the reference's entry point, PCIe included), and `parity`: mismatch counts
             of the timed configuration's map against the oracle (committed full-map row CRCs + the cpu_baseline's rows).
 cpu_baseline = the oracle's C/OpenMP restatement on a bounded row sample of the same grid (rank 0, N = 1).
 Prints ONE JSON line on rank 0.
@@ -111,7 +114,10 @@ def usable_cores():
 
 def cpu_baseline(tx, walls, X, Y, max_order, approx, budget_rows=64):
     """Oracle (C restatement, OpenMP, all usable host cores) timed on a bounded row sample of the same grid.
-    Returns (the cpu_baseline object, the sampled row indices, the oracle's map on those rows)."""
+    Returns (the cpu_baseline object, the sampled row indices, the oracle's map on those rows).  `value` = every candidate of
+    every cell fully evaluated, as the reference does (prune 0); `value_pruned` = the same oracle with its exact per-cell
+    shortcuts (prune 2: leaves a candidate at the first wall whose on_objects is exactly 0, stops the occlusion tests at the
+    first exact hit) -- the like-for-like figure beside a GPU sweep that culls."""
     from oracle import c_oracle as CO
 
     CO.build()
@@ -121,6 +127,9 @@ def cpu_baseline(tx, walls, X, Y, max_order, approx, budget_rows=64):
     t0 = time.perf_counter()
     ref = CO.power_map(walls, tx, Xs, Ys, min_order=0, max_order=max_order, approx=approx, prune=False, nthreads=cores)
     dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref2 = CO.power_map(walls, tx, Xs, Ys, min_order=0, max_order=max_order, approx=approx, prune=2, nthreads=cores)
+    dt2 = time.perf_counter() - t0
     cands = Xs.size * num_candidates(walls.shape[0], 0, max_order)
     return {
         "value": cands / dt,
@@ -130,7 +139,29 @@ def cpu_baseline(tx, walls, X, Y, max_order, approx, budget_rows=64):
         "sample": f"{budget_rows} of {X.shape[0]} grid rows x {X.shape[1]} columns ({Xs.size} RX cells, "
                   f"{cands:.3g} candidates, every candidate fully evaluated), C/OpenMP restatement of DiffeRT2d v0.4.0 "
                   f"(the JAX reference cannot be installed here), {dt:.1f} s",
+        "value_pruned": cands / dt2,
+        "pruned_what": f"the same rows with the oracle's exact per-cell shortcuts (prune=2), {dt2:.2f} s; maps identical: "
+                       f"{bool(np.array_equal(ref, ref2, equal_nan=True))}",
     }, rows, ref
+
+
+def committed_traffic(approx):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the newest committed PMC summary under profiles/
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, scripts/profile_gpu.sh) -- not measured inside this run."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_a{int(approx)}_pmc.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        kib = float(d["FETCH_SIZE"]) + float(d["WRITE_SIZE"])
+    except (OSError, ValueError, KeyError, TypeError):
+        return None, None
+    return kib * 1024.0, (f"profiles/{os.path.basename(files[-1])}: FETCH_SIZE {float(d['FETCH_SIZE']):.0f} KiB + WRITE_SIZE "
+                          f"{float(d['WRITE_SIZE']):.0f} KiB per dispatch as counted (4-byte-per-lane loads; the guide's x2 FETCH "
+                          f"correction, calibrated on 16-B streaming reads, would make it {(2 * float(d['FETCH_SIZE']) + float(d['WRITE_SIZE'])) * 1024 / 1e6:.1f} MB), "
+                          f"kernel {d.get('_meta', {}).get('kernel', '?')}")
 
 
 def row_crcs(a):
@@ -254,7 +285,7 @@ def api_leg(tx, walls, resident_ms, sizes=(300, 1024), n_calls=12):
     return out
 
 
-def strong_leg(ctx, world, rank, distributed, do_gather, timed, which="cfg4", steps=5):
+def strong_leg(ctx, world, rank, distributed, do_gather, timed, which="cfg4", steps=5, approx=False):
     """A BASELINE.json configuration with its rows split over the ranks -- configs[3] (200 walls, 2048 x 2048, orders 0..3) or
     configs[1] (the timed workload's own 1024 x 1024 grid) -- the STRONG-scaling companion of the timed (weak) workload, in the
     same process, for the N = 1, 2, 4, 8 sequence.  Reference semantics: ONE assembled map (scene.py:1927-1953)."""
@@ -266,7 +297,7 @@ def strong_leg(ctx, world, rank, distributed, do_gather, timed, which="cfg4", st
     shards = RowShards(X.shape[0], world)
     ctx.set_scene(walls)
     ctx.set_grid(shards.take(X, rank), shards.take(Y, rank))
-    p = make_params(min_order=0, max_order=max_order)
+    p = make_params(min_order=0, max_order=max_order, approx=approx)
 
     def step():
         ctx.launch(p, tx)
@@ -281,9 +312,41 @@ def strong_leg(ctx, world, rank, distributed, do_gather, timed, which="cfg4", st
         wall0, _ = timed(lambda: ctx.launch(p, tx), steps, 2)
         out["ms_per_step_without_gather"] = wall0 * 1e3 / steps
     C = num_candidates(n_walls, 0, max_order)
-    out.update({"workload": f"{n_walls} walls, {grid}x{grid} RX grid split over {world} rank(s), orders 0..{max_order} (C={C}), hard validity; "
+    out.update({"workload": f"{n_walls} walls, {grid}x{grid} RX grid split over {world} rank(s), orders 0..{max_order} (C={C}), {'hard_sigmoid' if approx else 'hard'} validity; "
                             f"BASELINE.json {cfg}", "scaling": "strong", "steps": steps, "ms_per_step": wall * 1e3 / steps,
                 "candidates_per_s": X.size * C / (wall / steps)})
+    return out
+
+
+def cfg5_leg(ctx, timed, steps=1000, n=5):
+    """BASELINE.json configs[4]: Scene.square_scene() + RIS([[0.5, 0.3], [0.5, 0.7]], phi = pi / 4) + its two end points as
+    diffraction vertices, scene.grid(n=300), order 1, MinPath with 1000 Adam steps, hard_sigmoid validity: the forward sweep
+    and value + per-cell gradient + scene VJP (incl. the RIS's vertices and phi) through the Adam loop.  theta0 explicit (NumPy
+    seed 1234, as tests/golden/cfg5_samples.npz).  Replaces the context's scene and grid."""
+    from differt2d_amd.engine import make_params
+    from differt2d_amd.geometry import RIS, objects_to_tables
+    from differt2d_amd.scene import Scene
+
+    scene = Scene.square_scene()
+    ris = RIS(xys=[[0.5, 0.3], [0.5, 0.7]], phi=np.pi / 4)
+    scene = scene.add_objects(ris, *ris.get_vertices())
+    X, Y = scene.grid(n=300)
+    tx = scene.transmitters["tx"].xy
+    cands = scene.all_path_candidates(order=1)
+    rng = np.random.default_rng(1234)
+    theta0 = [rng.random(sum(o.parameters_count() for o in scene.get_interacting_objects(c)), dtype=np.float32) for c in cands]
+    ctx.set_scene(*objects_to_tables(scene.objects))
+    ctx.set_grid(X, Y)
+    ctx.set_theta0(theta0)
+    out = {"workload": f"square scene + RIS + its 2 vertices (7 objects), 300x300 RX grid, order 1 ({len(cands)} candidates), "
+                       f"{steps} Adam steps per (cell, candidate), hard_sigmoid validity; BASELINE.json configs[4] on 1 GPU"}
+    for solver in ("min", "fermat"):
+        p = make_params(min_order=1, max_order=1, approx=True, solver=solver, steps=steps)
+        w, _ = timed(lambda p=p: ctx.launch(p, tx), n, 1)
+        out[f"{solver}path_forward"] = {"ms_per_step": w * 1e3 / n, "steps": n,
+                                        "solver_iterations_per_s": X.size * len(cands) * steps / (w / n)}
+        w, _ = timed(lambda p=p: ctx.launch_vg(p, tx, scene_vjp=True), n, 1)
+        out[f"{solver}path_value_and_grad_and_vjp"] = {"ms_per_step": w * 1e3 / n, "steps": n}
     return out
 
 
@@ -505,6 +568,26 @@ def main():
                       "candidate of every cell evaluated (the cross-check). `without_nan_scan`: round 3's default (A/B; only the "
                       "evaluated candidates' NaN). kernels_ms: sweep + scan on their stream (HIP events)")
         extras["value_and_grad"] = vg
+        # ---- the other value+grad figures README / DESIGN quote: hard_sigmoid and sigmoid validity, TX grids (forward and
+        # value+grad: accumulate_on_transmitters_grid_over_paths, scene.py:1489-1648)
+        more = {}
+        for name in ("hard_sigmoid", "sigmoid"):
+            p = make_params(min_order=0, max_order=max_order, **mode_kw[name])
+            n = max(3, n_x // 4) if name != "sigmoid" else 3
+            w, _ = timed(lambda p=p: ctx.launch_vg(p, tx, scene_vjp=True), n, 1)
+            more[f"value_and_grad_{name}"] = {"ms_per_step": w * 1e3 / n, "steps": n}
+        for name in ("hard", "hard_sigmoid"):
+            p = make_params(min_order=0, max_order=max_order, grid_role=L.GRID_TX, **mode_kw[name])
+            n = max(3, n_x // 4)
+            w, _ = timed(lambda p=p: ctx.launch(p, tx), n, 2)
+            more[f"tx_grid_forward_{name}"] = {"ms_per_step": w * 1e3 / n, "steps": n}
+            w, _ = timed(lambda p=p: ctx.launch_vg(p, tx, scene_vjp=True), n, 2)
+            more[f"tx_grid_value_and_grad_{name}"] = {"ms_per_step": w * 1e3 / n, "steps": n}
+        more["tx_grid_exhaustive_fallbacks"] = ctx.txg_fallbacks()
+        more["what"] = ("the timed workload's scene and grid; value_and_grad_* = value + per-cell gradient + scene VJP (default sweep: "
+                        "culling + NaN scan); tx_grid_* = the grid cells are transmitters and the workload's transmitter the fixed "
+                        "receiver; wall time per step, back to back, resident inputs")
+        extras["more_modes"] = more
     elif not args.no_extras:
         def step_vg():
             ctx.launch_vg(params, tx, scene_vjp=True)
@@ -532,6 +615,8 @@ def main():
             extras["strong_cfg2"] = strong_leg(ctx, world, rank, distributed, do_gather, timed, "cfg2", steps=min(steps, 50))
         extras["strong_cfg4"] = strong_leg(ctx, world, rank, distributed, do_gather, timed, "cfg4")
     if not args.no_extras and world == 1 and args.workload == "cfg2" and default_shape:
+        extras["strong_cfg4_hard_sigmoid"] = strong_leg(ctx, world, rank, distributed, do_gather, timed, "cfg4", steps=3, approx=True)
+        extras["cfg5"] = cfg5_leg(ctx, timed)
         extras["api"] = api_leg(tx, walls, ms_per_step)
 
     if rank == 0:
@@ -540,6 +625,7 @@ def main():
         flop_unpruned = unpruned_flop_per_rx(n_walls, 0, max_order, approx) * cells_local
         per_s = 1.0 / (kernel_ms * 1e-3) / 1e12
         achieved = (flop_ref + flop_cull) * per_s
+        traffic_bytes, traffic_src = committed_traffic(approx) if (args.workload == "cfg2" and default_shape and world == 1) else (None, None)
         parity = None
         line = {
             "metric": "ray-path candidates/s",
@@ -584,7 +670,8 @@ def main():
                     "note": "all over kernel_ms; frac = executed_with_culling; pmc_lane_ops (64 x SQ_INSTS_VALU / time / peak) needs "
                             "rocprofv3 PMC passes and is not measured inside this run: see profiles/*_summary.md",
                 },
-                "traffic": None,
+                "traffic": traffic_bytes,
+                "traffic_source": traffic_src,
                 "kernel": "d2d::power_fwd_split_kernel" if small else "d2d::power_fwd_kernel",
                 "kernel_ms": kernel_ms,
                 # + shadow masks, region candidate lists (region_list_kernel, region_refine_kernel), patch schedule, the

@@ -301,6 +301,15 @@ __device__ __forceinline__ void normalize2(float vx, float vy, float& ox, float&
     oy = vy / len;
 }
 
+// f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>): a loop whose index is a compile-time constant inside the body
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
 // Pre-division hard_sigmoid: clamp(alpha*x + 3, 0, 6); hard_sigmoid(x) = clampact(x) / 6.
 __device__ __forceinline__ float clampact(float x, float alpha) {
     float z = alpha * x;
@@ -405,6 +414,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
     // that receives the contribution alone -- but knows that sum to be at least acc_floor when the addition happens
     const float zc_acc = (acc_floor >= 0.0f) ? acc_floor : acc;
     int on_i = 0, on_w = 0, hit_i = 0, hit_j = -1;  // GRAD: which activation carries the min / max
+    float hit2 = -3.0e38f;  // GRAD, approx modes: the largest occlusion test OTHER than the one that carries the max (ties: JAX splits)
     bool znan = false;  // GRAD: the reference's autodiff yields NaN for this (cell, candidate), see below
     long cust = 0;      // GRAD, D2D_FUN_CUSTOM: this (candidate, cell)'s row of the host-evaluated path function
     if (GRAD && a.fun_id == D2D_FUN_CUSTOM) cust = (long)(g->ci++) * a.cust_cells + g->cell;
@@ -746,6 +756,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     hit_i = i;
                     hit_j = jj;
                 }
+                if (GRAD) hit2 = (c > hit_c) ? hit_c : fmaxf(hit2, c);
                 hit_c = fmaxf(hit_c, c);
             } else {
                 nanflag = nanflag || (ta != ta) || (tb != tb);
@@ -755,6 +766,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     hit_i = i;
                     hit_j = jj;
                 }
+                if (GRAD) hit2 = (z > hit_z) ? hit_z : fmaxf(hit2, z);
                 hit_z = fmaxf(hit_z, z);
             }
         }
@@ -882,6 +894,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                         hit_i = i;
                         hit_j = j;
                     }
+                    if (GRAD) hit2 = (c > hit_c) ? hit_c : fmaxf(hit2, c);
                     hit_c = fmaxf(hit_c, c);
                 } else {
                     nanflag = nanflag || (ta != ta) || (tb != tb);
@@ -891,6 +904,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                         hit_i = i;
                         hit_j = j;
                     }
+                    if (GRAD) hit2 = (z > hit_z) ? hit_z : fmaxf(hit2, z);
                     hit_z = fmaxf(hit_z, z);
                 }
             }
@@ -1051,9 +1065,20 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
         bool occ = false;
 
         if (MODE != MODE_HARD) {
-            const int sel = (on_v <= nh_v && on_v <= ok_v) ? 0 : ((nh_v <= ok_v) ? 1 : 2);
+            // valid = minimum(minimum(on, not hit), ok) (logic.py:490-512, a left fold): jnp.minimum hands its cotangent to the
+            // smaller argument and splits it evenly at a tie (logic.py:358)
+            float w_on = (on_v < nh_v) ? 1.0f : (nh_v < on_v) ? 0.0f : 0.5f;
+            float w_nh = 1.0f - w_on, w_ok = 0.0f;
+            {
+                const float m01 = fminf(on_v, nh_v);
+                const float keep = (m01 < ok_v) ? 1.0f : (ok_v < m01) ? 0.0f : 0.5f;
+                w_on *= keep;
+                w_nh *= keep;
+                w_ok = 1.0f - keep;
+            }
+            const float vb_on = vbar * w_on, vb_nh = vbar * w_nh, vb_ok = vbar * w_ok;
             // ---- ok = activation(tol - loss)
-            float lossbar = (sel == 2) ? -(vbar * dact<MODE>(ok_x, a.alpha)) : 0.0f;
+            float lossbar = (w_ok != 0.0f) ? -(vb_ok * dact<MODE>(ok_x, a.alpha)) : 0.0f;
             if (K > 0 && wave_any(lossbar != 0.0f)) {
 #pragma unroll
                 for (int i = 0; i < K; ++i) {
@@ -1091,7 +1116,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     float dx = px[i + 1] - r0.x, dy = py[i + 1] - r0.y;
                     float s = (r1.x * dx + r1.y * dy) / r1.z;
                     float x = on_w ? (1.0f - s) : (s - 0.0f);
-                    float sb = (sel == 0 && i == on_i) ? vbar * dact<MODE>(x, a.alpha) * (on_w ? -1.0f : 1.0f) : 0.0f;
+                    float sb = (w_on != 0.0f && i == on_i) ? vb_on * dact<MODE>(x, a.alpha) * (on_w ? -1.0f : 1.0f) : 0.0f;
                     float q = sb / r1.z;
                     pbx[i + 1] += q * r1.x; pby[i + 1] += q * r1.y;
                     obx[i] -= q * r1.x; oby[i] -= q * r1.y;
@@ -1103,16 +1128,14 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                 }
             }
             // ---- not(intersects): the test carrying the max, and inside it the activation carrying the min
-            occ = (sel == 1) && (hit_j >= 0) && (vbar != 0.0f);
-            if (wave_any(occ)) {
-                const int jj = occ ? hit_j : 0;
-                const float4 w = ldc4(a.occl, jj);
-                float qx = 0.0f, qy = 0.0f, q1x = 0.0f, q1y = 0.0f;  // P3 = p[hit_i], P4 = p[hit_i + 1]
-#pragma unroll
-                for (int i = 0; i <= K; ++i)
-                    if (i == hit_i) {
-                        qx = px[i]; qy = py[i]; q1x = px[i + 1]; q1y = py[i + 1];
-                    }
+            occ = (w_nh != 0.0f) && (hit_j >= 0) && (vb_nh != 0.0f);
+            // The adjoint of ONE occlusion test (segment i, object jj) that carries `wgt` of the cotangent of `hit`: inside the test,
+            // minimum(minimum(ge(ta), le(ta)), minimum(ge(tb), le(tb))) (geometry.py:163-173), ties split evenly again.  tree =
+            // false: the one activation that carries the minimum in pre-activation order (the path without ties: as before).
+            auto occluder_adjoint = [&](auto ic, const float4& w, float wgt, bool tree, float& o_p1bx, float& o_p1by, float& o_abx,
+                                        float& o_aby) {
+                constexpr int i = decltype(ic)::value;
+                const float qx = px[i], qy = py[i], q1x = px[i + 1], q1y = py[i + 1];  // P3, P4
                 float Bx = qx - q1x, By = qy - q1y;
                 float Cx = w.x - qx, Cy = w.y - qy;
                 float fa = By * Cx - Bx * Cy, fb = w.z * Cy - w.w * Cx, fd = w.w * Bx - w.z * By;
@@ -1123,32 +1146,113 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                 float m0, m1, m2, m3;
                 if (MODE == MODE_HSIG) { m0 = clampact(x0, a.alpha); m1 = clampact(x1, a.alpha); m2 = clampact(x2, a.alpha); m3 = clampact(x3, a.alpha); }
                 else { m0 = a.alpha * x0; m1 = a.alpha * x1; m2 = a.alpha * x2; m3 = a.alpha * x3; }
-                int which = 0; float mm = m0;
-                if (m1 < mm) { mm = m1; which = 1; }
-                if (m2 < mm) { mm = m2; which = 2; }
-                if (m3 < mm) { mm = m3; which = 3; }
-                float xsel = (which == 0) ? x0 : (which == 1) ? x1 : (which == 2) ? x2 : x3;
+                float k0, k1, k2, k3;  // share of the test's cotangent per activation
+                if (!tree) {
+                    int which = 0; float mm = m0;
+                    if (m1 < mm) { mm = m1; which = 1; }
+                    if (m2 < mm) { mm = m2; which = 2; }
+                    if (m3 < mm) { mm = m3; which = 3; }
+                    k0 = (which == 0) ? 1.0f : 0.0f; k1 = (which == 1) ? 1.0f : 0.0f; k2 = (which == 2) ? 1.0f : 0.0f; k3 = (which == 3) ? 1.0f : 0.0f;
+                } else {
+                    // (the reference compares the ACTIVATIONS: in sigmoid mode two pre-activations may round to one float)
+                    if (MODE == MODE_SIG) { m0 = sigmoidf_(m0); m1 = sigmoidf_(m1); m2 = sigmoidf_(m2); m3 = sigmoidf_(m3); }
+                    const float a0 = (m0 < m1) ? 1.0f : (m1 < m0) ? 0.0f : 0.5f, b0 = (m2 < m3) ? 1.0f : (m3 < m2) ? 0.0f : 0.5f;
+                    const float mA = fminf(m0, m1), mB = fminf(m2, m3);
+                    const float ab = (mA < mB) ? 1.0f : (mB < mA) ? 0.0f : 0.5f;
+                    k0 = ab * a0; k1 = ab * (1.0f - a0); k2 = (1.0f - ab) * b0; k3 = (1.0f - ab) * (1.0f - b0);
+                }
                 // valid = ... 1 - hit ... : d valid / d hit = -1
-                float hb = (occ && !dz) ? -(vbar * dact<MODE>(xsel, a.alpha)) : 0.0f;
-                float tab = (which == 0) ? hb : (which == 1) ? -hb : 0.0f;
-                float tbb = (which == 2) ? hb : (which == 3) ? -hb : 0.0f;
+                const float hw = (wgt != 0.0f && !dz) ? -(vb_nh * wgt) : 0.0f;
+                const float h0 = (k0 != 0.0f) ? hw * k0 * dact<MODE>(x0, a.alpha) : 0.0f, h1 = (k1 != 0.0f) ? hw * k1 * dact<MODE>(x1, a.alpha) : 0.0f;
+                const float h2 = (k2 != 0.0f) ? hw * k2 * dact<MODE>(x2, a.alpha) : 0.0f, h3 = (k3 != 0.0f) ? hw * k3 * dact<MODE>(x3, a.alpha) : 0.0f;
+                float tab = h0 - h1, tbb = h2 - h3;
                 float fab = tab / dd, fbb = tbb / dd;
                 float fdb = -(tab * ta + tbb * tb) / dd;
-                fdb = (hb != 0.0f) ? fdb : 0.0f;
+                fdb = (tab != 0.0f || tbb != 0.0f) ? fdb : 0.0f;
                 // fa = By Cx - Bx Cy ; fb = Ax Cy - Ay Cx ; fd = Ay Bx - Ax By
                 float Bbx = -fab * Cy + fdb * w.w, Bby = fab * Cx - fdb * w.z;
                 float Cbx = fab * By - fbb * w.w, Cby = -fab * Bx + fbb * w.z;
-                abx = fbb * Cy - fdb * By;
-                aby = -fbb * Cx + fdb * Bx;
-                p1bx = Cbx; p1by = Cby;
-                float g3x = Bbx - Cbx, g3y = Bby - Cby;  // d/d P3
-                float g4x = -Bbx, g4y = -Bby;            // d/d P4
-#pragma unroll
-                for (int i = 0; i <= K; ++i)
-                    if (i == hit_i) {
-                        pbx[i] += g3x; pby[i] += g3y;
-                        pbx[i + 1] += g4x; pby[i + 1] += g4y;
+                o_abx = fbb * Cy - fdb * By;
+                o_aby = -fbb * Cx + fdb * Bx;
+                o_p1bx = Cbx; o_p1by = Cby;
+                pbx[i] += Bbx - Cbx; pby[i] += Bby - Cby;  // d/d P3
+                pbx[i + 1] -= Bbx; pby[i + 1] -= Bby;      // d/d P4
+            };
+            // Do two or more tests tie for the maximum?  (hard_sigmoid: equal clamped pre-activations; sigmoid: pre-activations that
+            // round to the same float under the activation -- common next to saturation, where the fp32 sigmoid has 2^-24 steps)
+            bool tie = false;
+            float vmax = 0.0f;
+            if (wave_any(occ)) {
+                if (MODE == MODE_HSIG) {
+                    vmax = hit_c;
+                    tie = occ && hit2 == hit_c;
+                } else {
+                    vmax = sigmoidf_(hit_z);
+                    tie = occ && sigmoidf_(hit2) == vmax;
+                }
+            }
+            if (wave_any(tie)) {
+                // jnp.maximum in a left fold over (segment, object) (geometry.py:881-904): of r tying tests the q-th in the fold's
+                // order carries 2^-(r - q + 1) of the cotangent, the first as much as the second.  One pass counts, one applies;
+                // lanes without a tie take their single test with weight 1 -- the same arithmetic as the path below.
+                int r = 0, q = 0;
+                for (int pass = 0; pass < 2; ++pass) {
+                    static_for<0, K + 1>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        const int ig0 = (i == 0) ? -1 : cand[i - 1];
+                        const int ig1 = (i == K) ? -1 : cand[i];
+                        for (int jj = 0; jj < a.N; ++jj) {
+                            if (jj == ig0 || jj == ig1) continue;
+                            const float4 w = ldc4(a.occl, jj);
+                            const float Cx = w.x - px[i], Cy = w.y - py[i];
+                            const float fa = by[i] * Cx - bx[i] * Cy, fb = w.z * Cy - w.w * Cx, fd = w.w * bx[i] - w.z * by[i];
+                            const bool dz = (fd == 0.0f);
+                            float ta, tb;
+                            div2_exact(fa, fb, dz ? 1.0f : fd, ta, tb);
+                            ta = dz ? __builtin_inff() : ta;
+                            tb = dz ? __builtin_inff() : tb;
+                            float v;
+                            if (MODE == MODE_HSIG)
+                                v = fminf(fminf(clampact(ta - a.seg_lo, a.alpha), clampact(a.seg_hi - ta, a.alpha)),
+                                          fminf(clampact(tb - a.seg_lo, a.alpha), clampact(a.seg_hi - tb, a.alpha)));
+                            else
+                                v = sigmoidf_(fminf(fminf(a.alpha * (ta - a.seg_lo), a.alpha * (a.seg_hi - ta)),
+                                                    fminf(a.alpha * (tb - a.seg_lo), a.alpha * (a.seg_hi - tb))));
+                            const bool t = occ && (v == vmax);
+                            if (pass == 0) {
+                                r += t ? 1 : 0;
+                            } else if (wave_any(t)) {
+                                q += t ? 1 : 0;
+                                const int sh_ = (q == 1) ? r - 1 : r - q + 1;
+                                const float wgt = t ? __builtin_ldexpf(1.0f, -sh_) : 0.0f;
+                                float tp1x, tp1y, tax, tay;
+                                occluder_adjoint(ic, w, wgt, true, tp1x, tp1y, tax, tay);
+                                if (g->scene) {
+                                    // P1 = (1 + patch) o - patch d ; P2 = (1 + patch) d - patch o ; A = P2 - P1
+                                    const float P1bx = tp1x - tax, P1by = tp1y - tay, pa = a.patch;
+                                    const float s0 = wave_sum(g->cot * ((1.0f + pa) * P1bx - pa * tax)), s1 = wave_sum(g->cot * ((1.0f + pa) * P1by - pa * tay));
+                                    const float s2_ = wave_sum(g->cot * ((1.0f + pa) * tax - pa * P1bx)), s3 = wave_sum(g->cot * ((1.0f + pa) * tay - pa * P1by));
+                                    if ((threadIdx.x & 63) == 0) {
+                                        float* w4 = g->wl + 4 * jj;
+                                        atomicAdd(&w4[0], s0); atomicAdd(&w4[1], s1); atomicAdd(&w4[2], s2_); atomicAdd(&w4[3], s3);
+                                    }
+                                }
+                            }
+                        }
+                    });
+                }
+                occ = false;  // (applied, the objects' adjoints included)
+            } else if (wave_any(occ)) {
+                const int jj = occ ? hit_j : 0;
+                const float4 w = ldc4(a.occl, jj);
+                static_for<0, K + 1>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if (wave_any(occ && hit_i == i)) {
+                        float tp1x, tp1y, tax, tay;
+                        occluder_adjoint(ic, w, (occ && hit_i == i) ? 1.0f : 0.0f, false, tp1x, tp1y, tax, tay);
+                        if (occ && hit_i == i) { p1bx = tp1x; p1by = tp1y; abx = tax; aby = tay; }
                     }
+                });
             }
         }
 

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the MinPath / FermatPath sweeps (GPU box): the solver kernels (K4) against
+oracle/d2d_oracle_opt.c on random scenes of Wall / RIS / Vertex objects -- value maps and, every other case, per-cell gradients
+through the Adam loop -- orders 1..2 (order 3 in small scenes), both solvers, all validity modes, both grid roles.
+
+Sequential fp32 Adam steps are not reproducible to the last bit between two gradient implementations and chaotic where a
+solve has not settled, so cells are compared where the ORACLE ALONE calls the sweep well conditioned (CO.opt_conditioning:
+every candidate's trajectory agrees between its fp64 run, its fp32 run and fp32 runs from inputs one ulp away); there the GPU
+sits within 1e-5 of the map's scale (+ 1e-5 relative) of the fp64 oracle, or within twice the oracle's own fp32 distance.
+
+usage: python scripts/fuzz_opt.py [n_cases] [seed]"""
+
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from differt2d_amd import _lib as L  # noqa: E402
+from differt2d_amd.engine import Context  # noqa: E402
+from oracle import c_oracle as CO  # noqa: E402
+
+F = np.float32
+
+
+def random_case(rng):
+    n = int(rng.integers(1, 7))
+    kinds = rng.choice([0, 0, 0, 1, 2], n).astype(np.uint8)
+    xys = rng.random((n, 2, 2)).astype(F)
+    if rng.random() < 0.4:  # axis-aligned / lattice walls: receivers on supporting lines, collinear objects
+        m = rng.random(xys.shape) < 0.5
+        xys = np.where(m, np.round(xys * 4) / 4, xys).astype(F)
+    xys[(xys[:, 0] == xys[:, 1]).all(-1)] += F(0.125)
+    for j in range(n):
+        if kinds[j] == 2:
+            xys[j, 1] = xys[j, 0]
+    phis = (rng.random(n) * 3.0 - 1.5).astype(F)
+    fixed = rng.random(2).astype(F)
+    gx, gy = int(rng.integers(1, 25)), int(rng.integers(1, 25))
+    lo, hi = (-0.2, 1.2) if rng.random() < 0.3 else (0.0, 1.0)
+    X, Y = np.meshgrid(np.linspace(lo, hi, gx).astype(F), np.linspace(lo, hi, gy).astype(F))
+    mode = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")][int(rng.integers(0, 3))]
+    max_order = int(rng.integers(1, 4)) if n <= 3 else int(rng.integers(1, 3))
+    min_order = int(rng.integers(0, max_order + 1))
+    kw = dict(approx=mode[0], function=mode[1], alpha=float(rng.choice([100.0, 50.0, 10.0])), tol=float(rng.choice([1e-2, 1e-3, 0.5])),
+              patch=float(rng.choice([0.0, 0.0, 0.02, -0.05])), fun=str(rng.choice(["received_power", "one", "length", "length_squared"])),
+              solver=str(rng.choice(["min", "fermat"])), steps=int(rng.choice([1, 2, 5, 30, 100, 250])))
+    cands = L.enumerate_candidates(n, min_order, max_order, None)
+    theta0 = [rng.random(L.D2D_MAX_ORDER, dtype=F) for _ in cands]
+    return kinds, xys, phis, fixed, X, Y, kw, min_order, max_order, cands, theta0
+
+
+def check_case(ctx, case, kinds, xys, phis, fixed, X, Y, kw, min_order, max_order, cands, theta0, with_grad, role):
+    th = [t[: sum(kinds[int(i)] != 2 for i in c)] for c, t in zip(cands, theta0)]
+    cond = CO.opt_conditioning(kinds, xys, phis, fixed, X, Y, cands, th, kw["steps"], with_grad=with_grad,
+                               grid_role="tx" if role == L.GRID_TX else "rx", **{k: v for k, v in kw.items() if k != "steps"})
+    ctx.set_scene(xys, kinds, phis)
+    ctx.set_theta0(theta0)
+    gkw = dict(kw, min_order=min_order, max_order=max_order, grid_role=role)
+    msgs = []
+    if with_grad:
+        out = ctx.value_and_grads(fixed, X, Y, **gkw)
+        got, g = out["value"], out["grad_rx"].astype(np.float64)
+        if not np.array_equal(got, ctx.power_map(fixed, X, Y, **gkw), equal_nan=True):
+            msgs.append("value map of the gradient sweep differs from the forward sweep's")
+    else:
+        got = ctx.power_map(fixed, X, Y, **gkw)
+    stable, v64, scale = cond["stable"], cond["value64"], cond["scale"]
+    bar = np.maximum(1e-5 * scale + 1e-5 * np.abs(v64), 2.0 * cond["dist"]) + 1e-30
+    bad = stable & ~(np.abs(got - v64) <= bar)
+    if bad.any():
+        w = tuple(np.argwhere(bad)[0])
+        msgs.append(f"value ({int(bad.sum())} of {int(stable.sum())} stable cells, first {w}: GPU {got[w]!r} oracle64 {v64[w]!r} oracle32 {cond['value32'][w]!r})")
+    n_grad = 0
+    if with_grad:
+        g64, g32 = cond["grad64"], cond["grad32"]
+        fin = np.isfinite(g64).all(-1) & np.isfinite(g32).all(-1) & stable
+        with np.errstate(invalid="ignore"):
+            gs = np.maximum(np.abs(np.nan_to_num(g64)).max(-1), 1e-3 * float(np.nanmax(np.abs(np.where(np.isfinite(g64), g64, 0.0)), initial=0.0)) + 1e-30)[..., None]
+            # the gradient through the loop must itself be well conditioned: the oracle's fp32 and fp64 runs within 1e-2 of the cell's scale
+            fin &= (np.abs(g32 - g64) <= 1e-2 * gs).all(-1)
+            gbar = np.maximum(1e-5 * gs + 1e-5 * np.abs(g64), 2.0 * np.abs(g32 - g64))
+            gbad = fin & ~(np.abs(g - g64) <= gbar).all(-1)
+        n_grad = int(fin.sum())
+        if gbad.any():
+            w = tuple(np.argwhere(gbad)[0])
+            msgs.append(f"gradient ({int(gbad.sum())} of {n_grad} cells, first {w}: GPU {g[w]} oracle64 {g64[w]} oracle32 {g32[w]})")
+    return msgs, int(stable.sum()), int(stable.size), n_grad
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    bad = n_stable = n_cells = n_grad = 0
+    t0 = time.time()
+    with Context(0) as ctx:
+        for case in range(n_cases):
+            kinds, xys, phis, fixed, X, Y, kw, lo, hi, cands, theta0 = random_case(rng)
+            role = L.GRID_TX if case % 3 == 2 else L.GRID_RX
+            msgs, s, c, g = check_case(ctx, case, kinds, xys, phis, fixed, X, Y, kw, lo, hi, cands, theta0, case % 2 == 1, role)
+            n_stable, n_cells, n_grad = n_stable + s, n_cells + c, n_grad + g
+            if msgs:
+                bad += 1
+                print(f"MISMATCH case {case} seed {seed} {'TX' if role == L.GRID_TX else 'RX'}-grid: kinds={kinds.tolist()} grid={X.shape} orders {lo}..{hi} "
+                      f"kw={kw}: " + "; ".join(msgs), flush=True)
+            if case % 100 == 99:
+                print(f"  .. {case + 1} cases, {bad} mismatches, {n_stable} of {n_cells} cells well conditioned, {n_grad} gradients compared, {time.time() - t0:.0f} s", flush=True)
+    print(f"opt fuzz: {n_cases} cases, {bad} mismatches, {n_stable} of {n_cells} cells well conditioned (values compared there), "
+          f"{n_grad} per-cell gradients compared, {time.time() - t0:.1f} s (seed {seed})")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

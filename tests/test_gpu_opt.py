@@ -615,3 +615,62 @@ def test_optimizer_through_the_scene_api():
     assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, d, equal_nan=True) and not np.array_equal(a, c, equal_nan=True)
     with pytest.raises(L.D2DUnsupported):
         scene.accumulate_on_receivers_grid_over_paths(X, Y, path_cls_kwargs=dict(steps=40, theta0=theta0, optimizer=object()), **kw)
+
+
+def test_cfg5_full_map_against_the_c_oracle():
+    """BASELINE.json configs[4] on ALL 90 000 cells: the MinPath sweep (300 x 300 receivers, 7 order-1
+    candidates over square scene + RIS + its two vertices, 1000 Adam steps, hard_sigmoid validity) against
+    oracle/d2d_oracle_opt.c -- the C restatement with forward-mode duals for the objective's gradient, pinned to oracle/ref.py by
+    tests/test_oracle_opt_c.py -- computed live on the host cores: fp64 run, fp32 run, fp32 runs from inputs one ulp away,
+    interaction points compared after 30 / 100 / 300 / 1000 steps (CO.opt_conditioning: the oracle-only conditioning mask of
+    scripts/make_golden_cfg5.py, now for every cell instead of 1 045).  On the well-conditioned cells: value within 1e-5 of the
+    map's scale (+ 1e-5 relative) of the fp64 oracle or within twice the oracle's own fp32 distance.  Per-cell gradients through
+    the loop (second-order forward jets in the oracle, reverse mode over the stored trajectory on the GPU): every tenth row,
+    9 000 cells, same rule per cell."""
+    import os
+    import time
+
+    from differt2d_amd.engine import default_context
+    from oracle import c_oracle as CO
+    from oracle import ref as R
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg5_samples.npz"))
+    xys, kind, phi, tx, steps = z["xys"], z["kind"], z["phi"], z["tx"], int(z["steps"])
+    theta0 = [np.array([t, 0, 0, 0], F) if np.isfinite(t) else np.zeros(4, F) for t in z["theta0"]]
+    th = [np.array([t], F) if np.isfinite(t) else np.zeros(0, F) for t in z["theta0"]]
+    cands = R.all_path_candidates(7, order=1)
+    x = np.linspace(0.0, 1.0, 300).astype(F)
+    X, Y = np.meshgrid(x, x)
+    ctx = default_context()
+    ctx.set_scene(xys, kind, phi)
+    ctx.set_theta0(theta0)
+    kw = dict(min_order=1, max_order=1, approx=True, solver="min", steps=steps)
+    full = ctx.value_and_grads(tx, X, Y, **kw)
+    t0 = time.time()
+    cond = CO.opt_conditioning(kind, xys, phi, tx, X, Y, cands, th, steps, solver="min", approx=True)
+    t1 = time.time()
+    stable, v64, scale = cond["stable"], cond["value64"], cond["scale"]
+    bar = np.maximum(1e-5 * scale + 1e-5 * np.abs(v64), 2.0 * cond["dist"])
+    err = np.abs(full["value"] - v64)
+    print(f"cfg5, all {stable.size} cells: {int(stable.sum())} well conditioned in the oracle; value max err / bar there "
+          f"{float((err / bar)[stable].max()):.2f}, max err / scale {float(err[stable].max()) / scale:.2e} (oracle: 4 runs, {t1 - t0:.0f} s)")
+    assert stable.mean() > 0.8
+    assert (err <= bar)[stable].all(), f"{int((err > bar)[stable].sum())} well-conditioned cells beyond the bar: {np.argwhere(stable & (err > bar))[:5].tolist()}"
+    # everywhere: no less stable than the oracle itself is across its own runs
+    loose = np.abs(full["value"] - cond["value32"]) <= 2e-3 * scale + 2e-3 * np.abs(v64)
+    assert (~loose).sum() <= 2 * (~stable).sum()
+    # per-cell gradients on every tenth row
+    rows = np.arange(5, 300, 10)
+    cg = CO.opt_conditioning(kind, xys, phi, tx, X[rows], Y[rows], cands, th, steps, solver="min", approx=True, with_grad=True)
+    g, g64, g32 = full["grad_rx"][rows].astype(np.float64), cg["grad64"], cg["grad32"]
+    fin = np.isfinite(g64).all(-1) & np.isfinite(g32).all(-1) & cg["stable"]
+    gs = np.maximum(np.abs(np.nan_to_num(g64)).max(-1), np.median(np.abs(g64[fin]).max(-1)))[..., None]
+    with np.errstate(invalid="ignore"):
+        fin &= (np.abs(g32 - g64) <= 1e-2 * gs).all(-1)  # (the derivative through 1000 steps itself well conditioned)
+        gerr, gref = np.abs(g - g64) / gs, np.abs(g32 - g64) / gs
+        bad = fin & ~(gerr <= np.maximum(1e-5, 2.0 * gref)).all(-1)
+    print(f"cfg5, per-cell gradients on {rows.size} rows: {int(fin.sum())} of {fin.size} cells compared; max err / cell scale "
+          f"{float(gerr[fin].max()):.2e} (the oracle's fp32 vs fp64: {float(gref[fin].max()):.2e}); oracle {time.time() - t1:.0f} s")
+    assert fin.mean() > 0.7
+    assert np.isfinite(g[fin]).all()
+    assert not bad.any(), f"{int(bad.sum())} cells beyond max(1e-5, 2 x the oracle's fp32 error): {np.argwhere(bad)[:5].tolist()}"
