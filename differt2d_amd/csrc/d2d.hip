@@ -221,6 +221,15 @@ struct d2d_ctx {
     long long nan_scan_mode = 1;        // ... 1: two levels (regions of 4 x 4 patches, then patches), 2: one wave per patch (A/B and tests; same flags)
     bool nan_scan_stats = false;        // "nan_scan_stats" option: count probes / flagged cells / flagged patches (d2d_debug_nan_scan)
     DevBuf<unsigned long long> d_nan_stats;
+    // the scan BESIDE the sweep ("nan_scan_async", default on): on a stream of its own, its flags applied by nan_apply_kernel once
+    // both are through (sweep 0.14 ms + scan 0.26 ms one behind the other at cfg3)
+    bool nan_scan_async = true;
+    long long nan_scan_prio = 0;        // "nan_scan_prio": 0 the scan stream has the lowest priority, 1 the highest (A/B)
+    hipStream_t scan_stream = nullptr;  // created at the first use
+    long long scan_stream_prio = -1;
+    hipEvent_t ev_scan_fork = nullptr, ev_scan_done = nullptr;
+    DevBuf<unsigned long long> d_nan_cells;  // [patches]
+    DevBuf<unsigned> d_nan_rows;             // [patches][1 + ceil(N / 32)]
     bool want_wave_cycles = false;
     long long split_max_tiles = -1;     // launches up to this many patches share every patch between 4 waves (-1: by the validity mode)
     long long coop_max_tiles = -1;      // ... and up to this many candidate by candidate (power_fwd_coop_kernel); -1: by the validity mode
@@ -665,6 +674,9 @@ void d2d_destroy(d2d_ctx* c) {
     }
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->sort_stream) (void)hipStreamDestroy(c->sort_stream);
+    if (c->scan_stream) { (void)hipStreamSynchronize(c->scan_stream); (void)hipStreamDestroy(c->scan_stream); }
+    if (c->ev_scan_fork) (void)hipEventDestroy(c->ev_scan_fork);
+    if (c->ev_scan_done) (void)hipEventDestroy(c->ev_scan_done);
     if (c->h_meta) (void)hipHostFree(c->h_meta);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -953,10 +965,29 @@ static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, in
     if (grad_mode) {
         // one (cell, candidate) per lane, the candidates side by side; value, per-cell gradient and VJP partial sums go
         // through per-candidate scratch and are reduced in candidate order
-        if (C < 1 || C > 65535 || (long long)C * a.cells > (1ll << 28))
+        if (C > 65535 || (long long)C * a.cells > (1ll << 28))
             return fail(D2D_ERR_UNSUPPORTED, "%lld candidates x %lld cells exceed the gradient sweep's scratch (2^28 contributions)",
                         (long long)C, (long long)a.cells);
         const int n_elem = 5 * c->N + 2;  // [4N] object end points, [2] fixed end point, [N] phi
+        if (C == 0) {
+            // no candidate at all (order 2 in a scene of one object): the map, its gradient and the scene VJP are zero -- the
+            // reference's loop over no candidates (scene.py:1892-1918); found by scripts/fuzz_opt.py
+            if (p->out_mode == D2D_OUT_ADD && !c->have_grad) return fail(D2D_ERR_STATE, "D2D_OUT_ADD needs a previous value+grad sweep on this grid");
+            if ((rc = c->d_grad.ensure(2 * (size_t)a.cells))) return rc;
+            c->have_grad = true;
+            HIP_TRY(d2d::launch_opt_grad_reduce(nullptr, nullptr, 0, a.cells, c->d_out.p, c->d_grad.p, p->out_mode, c->stream));
+            if (grad_mode == 2) {
+                if ((rc = c->d_vjp.ensure((size_t)n_elem))) return rc;
+                if ((rc = join_comm(c, 2))) return rc;
+                if (!(p->out_mode == D2D_OUT_ADD && c->have_vjp)) {
+                    HIP_TRY(hipMemsetAsync(c->d_vjp.p, 0, (size_t)n_elem * sizeof(double), c->stream));
+                    c->vjp_has_phi = true;
+                    c->vjp_reduced = false;
+                }
+                c->have_vjp = true;
+            }
+            return D2D_OK;
+        }
         if (p->out_mode == D2D_OUT_ADD && !c->have_grad) return fail(D2D_ERR_STATE, "D2D_OUT_ADD needs a previous value+grad sweep on this grid");
         if (grad_mode == 2 && p->out_mode == D2D_OUT_ADD && c->have_vjp) {
             if (!c->vjp_has_phi)
@@ -1616,6 +1647,57 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         }
         if (p->out_mode == D2D_OUT_OVERWRITE) c->have_vjp = false;
         const size_t lds = (size_t)(4 * c->N + 4) * sizeof(float);
+        // (hard validity with fun = 1: nothing is differentiated through the path; order 0 alone: only path_length's own trap)
+        const bool scan = !p->strict_nan && (!txg || txg_culled) && c->nan_scan && (p->approx || p->fun_id != D2D_FUN_ONE) &&
+                          ((p->max_order >= 1 && !c->cw.empty()) || (p->min_order <= 0 && p->fun_id != D2D_FUN_ONE));
+        // The culled sweep writes the gradients of the candidates it evaluates; the reference's autodiff NaN positions -- an exact
+        // zero in the backward scan of ANY candidate, valid or not -- come from a pass of their own (d2d_nanscan.hpp), which
+        // poisons the cells and the patches' rows of VJP partial sums the way the exhaustive kernel (strict_nan) would have
+        // written them.  It reads the scene's tables and the grid only: it runs BESIDE the sweep on a stream of its own and
+        // leaves flags that nan_apply_kernel applies once both are through ("nan_scan_async" = 0: behind the sweep, as in round 4).
+        auto launch_scan = [&](hipStream_t st, const d2d::SweepArgs& as) -> int {
+            // two levels (a workgroup of 16 waves per region of 4 x 4 patches) when the region's list fits beside the tables
+            const size_t lds_r = (size_t)(3 * c->N) * sizeof(float4) + (size_t)d2d::NAN_LCAP * sizeof(unsigned long long) +
+                                 (size_t)(2 * d2d::NAN_W + 1) * (size_t)((c->N + 31) / 32) * sizeof(unsigned) + 16;
+            const bool regions = c->nan_scan_mode != 2 && lds_r + 512 <= d2d_host::LDS_LIMIT && c->N <= 4095;
+            const size_t lds_n = regions ? lds_r : (size_t)(3 * c->N) * sizeof(float4) + (size_t)c->N * sizeof(int) + 16;
+            if (lds_n > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the NaN scan's LDS table", c->N);
+            unsigned long long* ns = nullptr;
+            if (c->nan_scan_stats) {
+                int rc2;
+                if ((rc2 = c->d_nan_stats.ensure(4))) return rc2;
+                HIP_TRY(hipMemsetAsync(c->d_nan_stats.p, 0, 4 * sizeof(unsigned long long), st));
+                ns = c->d_nan_stats.p;
+            }
+            const dim3 grid_regions((unsigned)(((tiles_x + d2d::NAN_R - 1) / d2d::NAN_R) * ((tiles_y + d2d::NAN_RY - 1) / d2d::NAN_RY)));
+            HIP_TRY(d2d::launch_nan_scan(p->approx != 0, txg, p->max_order, regions, regions ? grid_regions : grid_patches, lds_n, st, as, ns));
+            return D2D_OK;
+        };
+        bool scan_beside = false;
+        if (scan && c->nan_scan_async) {
+            if (c->scan_stream == nullptr || c->scan_stream_prio != c->nan_scan_prio) {
+                if (c->scan_stream) { HIP_TRY(hipStreamSynchronize(c->scan_stream)); HIP_TRY(hipStreamDestroy(c->scan_stream)); c->scan_stream = nullptr; }
+                int prio_lo = 0, prio_hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+                HIP_TRY(hipStreamCreateWithPriority(&c->scan_stream, hipStreamNonBlocking, c->nan_scan_prio ? prio_hi : prio_lo));
+                c->scan_stream_prio = c->nan_scan_prio;
+            }
+            if (!c->ev_scan_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_scan_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+            if (!c->ev_scan_done) HIP_TRY(hipEventCreateWithFlags(&c->ev_scan_done, hipEventDisableTiming | hipEventDisableSystemFence));
+            const int rw = 1 + (c->N + 31) / 32;
+            if ((rc = c->d_nan_cells.ensure((size_t)tiles))) return rc;
+            if (grad_mode == 2 && (rc = c->d_nan_rows.ensure((size_t)tiles * rw))) return rc;
+            d2d::SweepArgs as = a;
+            as.nan_cell_bits = c->d_nan_cells.p;
+            as.nan_row_bits = grad_mode == 2 ? c->d_nan_rows.p : nullptr;
+            as.nan_row_words = rw;
+            // (the previous launch's nan_apply_kernel has read the flags: stream order through the fork event)
+            HIP_TRY(hipEventRecord(c->ev_scan_fork, c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->scan_stream, c->ev_scan_fork, 0));
+            if ((rc = launch_scan(c->scan_stream, as))) return rc;
+            HIP_TRY(hipEventRecord(c->ev_scan_done, c->scan_stream));
+            scan_beside = true;
+        }
         if (!txg && !p->strict_nan) {
             // culled value+grad sweep (default)
             const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4) + 512;  // tables, adjoint table, culling queue
@@ -1643,27 +1725,15 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         } else {
             HIP_TRY(d2d::launch_vg(mode, txg, true, grid, lds, c->stream, a));
         }
-        // (hard validity with fun = 1: nothing is differentiated through the path; order 0 alone: only path_length's own trap)
-        if (!p->strict_nan && (!txg || txg_culled) && c->nan_scan && (p->approx || p->fun_id != D2D_FUN_ONE) &&
-            ((p->max_order >= 1 && !c->cw.empty()) || (p->min_order <= 0 && p->fun_id != D2D_FUN_ONE))) {
-            // The culled sweep has written the gradients of the candidates it evaluated; the reference's autodiff NaN positions
-            // -- an exact zero in the backward scan of ANY candidate, valid or not -- come from a pass of their own
-            // (d2d_nanscan.hpp), which poisons the cells and the patches' rows of VJP partial sums the way the exhaustive
-            // kernel (strict_nan) would have written them.
-            // two levels (a workgroup of 16 waves per region of 4 x 4 patches) when the region's list fits beside the tables
-            const size_t lds_r = (size_t)(3 * c->N) * sizeof(float4) + (size_t)d2d::NAN_LCAP * sizeof(unsigned long long) +
-                                 (size_t)(2 * d2d::NAN_W + 1) * (size_t)((c->N + 31) / 32) * sizeof(unsigned) + 16;
-            const bool regions = c->nan_scan_mode != 2 && lds_r + 512 <= d2d_host::LDS_LIMIT && c->N <= 4095;
-            const size_t lds_n = regions ? lds_r : (size_t)(3 * c->N) * sizeof(float4) + (size_t)c->N * sizeof(int) + 16;
-            if (lds_n > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the NaN scan's LDS table", c->N);
-            unsigned long long* ns = nullptr;
-            if (c->nan_scan_stats) {
-                if ((rc = c->d_nan_stats.ensure(4))) return rc;
-                HIP_TRY(hipMemsetAsync(c->d_nan_stats.p, 0, 4 * sizeof(unsigned long long), c->stream));
-                ns = c->d_nan_stats.p;
-            }
-            const dim3 grid_regions((unsigned)(((tiles_x + d2d::NAN_R - 1) / d2d::NAN_R) * ((tiles_y + d2d::NAN_RY - 1) / d2d::NAN_RY)));
-            HIP_TRY(d2d::launch_nan_scan(p->approx != 0, txg, p->max_order, regions, regions ? grid_regions : grid_patches, lds_n, c->stream, a, ns));
+        if (scan_beside) {
+            d2d::SweepArgs as = a;
+            as.nan_cell_bits = c->d_nan_cells.p;
+            as.nan_row_bits = grad_mode == 2 ? c->d_nan_rows.p : nullptr;
+            as.nan_row_words = 1 + (c->N + 31) / 32;
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
+            HIP_TRY(d2d::launch_nan_apply(c->stream, as, (long)tiles));
+        } else if (scan) {
+            if ((rc = launch_scan(c->stream, a))) return rc;
         }
         D2D_KERNEL_DONE();
         if (grad_mode == 2) {
@@ -1955,6 +2025,8 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
         if (value) c->nan_scan_mode = value;
     }
     else if (!strcmp(name, "nan_scan_stats")) c->nan_scan_stats = value != 0;
+    else if (!strcmp(name, "nan_scan_async")) c->nan_scan_async = value != 0;
+    else if (!strcmp(name, "nan_scan_prio")) c->nan_scan_prio = value != 0 ? 1 : 0;
     else if (!strcmp(name, "prep_fused")) c->prep_fused = value != 0;
     else if (!strcmp(name, "opt_parallel")) c->opt_parallel = value != 0;
     else if (!strcmp(name, "opt_grad_mode")) {

@@ -173,6 +173,11 @@ struct SweepArgs {
     int* __restrict__ heavy_done;     // [n_heavy] quarters finished (zero between launches)
     unsigned* __restrict__ cost_out;  // [n_patches] work this patch took (feeds the next launch's schedule), or null
 
+    // NaN scan beside the sweep (d2d_nanscan.hpp; null: the scan writes into grad / partial itself, behind the sweep): what the
+    // scan found, per patch -- applied by nan_apply_kernel once both are through
+    unsigned long long* nan_cell_bits;  // [patches] bit l: the cell of lane l gets a NaN gradient
+    unsigned* nan_row_bits;             // [patches][nan_row_words] word 0: the patch has a flag (the fixed end point's entries), then one bit per object
+    int nan_row_words;
 #ifdef D2D_AB_TIMELINE
     unsigned long long* tl_ring;  // diagnostic build: [256][2] first start / end (100 MHz real-time counter) of the last 256 forward launches
     int tl_seq;
@@ -1130,10 +1135,8 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             // ---- not(intersects): the test carrying the max, and inside it the activation carrying the min
             occ = (w_nh != 0.0f) && (hit_j >= 0) && (vb_nh != 0.0f);
             // The adjoint of ONE occlusion test (segment i, object jj) that carries `wgt` of the cotangent of `hit`: inside the test,
-            // minimum(minimum(ge(ta), le(ta)), minimum(ge(tb), le(tb))) (geometry.py:163-173), ties split evenly again.  tree =
-            // false: the one activation that carries the minimum in pre-activation order (the path without ties: as before).
-            auto occluder_adjoint = [&](auto ic, const float4& w, float wgt, bool tree, float& o_p1bx, float& o_p1by, float& o_abx,
-                                        float& o_aby) {
+            // minimum(minimum(ge(ta), le(ta)), minimum(ge(tb), le(tb))) (geometry.py:163-173), ties split evenly again.
+            auto occluder_adjoint = [&](auto ic, const float4& w, float wgt, float& o_p1bx, float& o_p1by, float& o_abx, float& o_aby) {
                 constexpr int i = decltype(ic)::value;
                 const float qx = px[i], qy = py[i], q1x = px[i + 1], q1y = py[i + 1];  // P3, P4
                 float Bx = qx - q1x, By = qy - q1y;
@@ -1146,21 +1149,13 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                 float m0, m1, m2, m3;
                 if (MODE == MODE_HSIG) { m0 = clampact(x0, a.alpha); m1 = clampact(x1, a.alpha); m2 = clampact(x2, a.alpha); m3 = clampact(x3, a.alpha); }
                 else { m0 = a.alpha * x0; m1 = a.alpha * x1; m2 = a.alpha * x2; m3 = a.alpha * x3; }
-                float k0, k1, k2, k3;  // share of the test's cotangent per activation
-                if (!tree) {
-                    int which = 0; float mm = m0;
-                    if (m1 < mm) { mm = m1; which = 1; }
-                    if (m2 < mm) { mm = m2; which = 2; }
-                    if (m3 < mm) { mm = m3; which = 3; }
-                    k0 = (which == 0) ? 1.0f : 0.0f; k1 = (which == 1) ? 1.0f : 0.0f; k2 = (which == 2) ? 1.0f : 0.0f; k3 = (which == 3) ? 1.0f : 0.0f;
-                } else {
-                    // (the reference compares the ACTIVATIONS: in sigmoid mode two pre-activations may round to one float)
-                    if (MODE == MODE_SIG) { m0 = sigmoidf_(m0); m1 = sigmoidf_(m1); m2 = sigmoidf_(m2); m3 = sigmoidf_(m3); }
-                    const float a0 = (m0 < m1) ? 1.0f : (m1 < m0) ? 0.0f : 0.5f, b0 = (m2 < m3) ? 1.0f : (m3 < m2) ? 0.0f : 0.5f;
-                    const float mA = fminf(m0, m1), mB = fminf(m2, m3);
-                    const float ab = (mA < mB) ? 1.0f : (mB < mA) ? 0.0f : 0.5f;
-                    k0 = ab * a0; k1 = ab * (1.0f - a0); k2 = (1.0f - ab) * b0; k3 = (1.0f - ab) * (1.0f - b0);
-                }
+                // share of the test's cotangent per activation: minimum(minimum(ge(ta), le(ta)), minimum(ge(tb), le(tb))), the
+                // reference compares the ACTIVATIONS (in sigmoid mode two pre-activations may round to one float) and splits ties
+                if (MODE == MODE_SIG) { m0 = sigmoidf_(m0); m1 = sigmoidf_(m1); m2 = sigmoidf_(m2); m3 = sigmoidf_(m3); }
+                const float a0 = (m0 < m1) ? 1.0f : (m1 < m0) ? 0.0f : 0.5f, b0 = (m2 < m3) ? 1.0f : (m3 < m2) ? 0.0f : 0.5f;
+                const float mA = fminf(m0, m1), mB = fminf(m2, m3);
+                const float ab = (mA < mB) ? 1.0f : (mB < mA) ? 0.0f : 0.5f;
+                const float k0 = ab * a0, k1 = ab * (1.0f - a0), k2 = (1.0f - ab) * b0, k3 = (1.0f - ab) * (1.0f - b0);
                 // valid = ... 1 - hit ... : d valid / d hit = -1
                 const float hw = (wgt != 0.0f && !dz) ? -(vb_nh * wgt) : 0.0f;
                 const float h0 = (k0 != 0.0f) ? hw * k0 * dact<MODE>(x0, a.alpha) : 0.0f, h1 = (k1 != 0.0f) ? hw * k1 * dact<MODE>(x1, a.alpha) : 0.0f;
@@ -1226,7 +1221,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                                 const int sh_ = (q == 1) ? r - 1 : r - q + 1;
                                 const float wgt = t ? __builtin_ldexpf(1.0f, -sh_) : 0.0f;
                                 float tp1x, tp1y, tax, tay;
-                                occluder_adjoint(ic, w, wgt, true, tp1x, tp1y, tax, tay);
+                                occluder_adjoint(ic, w, wgt, tp1x, tp1y, tax, tay);
                                 if (g->scene) {
                                     // P1 = (1 + patch) o - patch d ; P2 = (1 + patch) d - patch o ; A = P2 - P1
                                     const float P1bx = tp1x - tax, P1by = tp1y - tay, pa = a.patch;
@@ -1249,7 +1244,7 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     constexpr int i = decltype(ic)::value;
                     if (wave_any(occ && hit_i == i)) {
                         float tp1x, tp1y, tax, tay;
-                        occluder_adjoint(ic, w, (occ && hit_i == i) ? 1.0f : 0.0f, false, tp1x, tp1y, tax, tay);
+                        occluder_adjoint(ic, w, (occ && hit_i == i) ? 1.0f : 0.0f, tp1x, tp1y, tax, tay);
                         if (occ && hit_i == i) { p1bx = tp1x; p1by = tp1y; abx = tax; aby = tay; }
                     }
                 });

@@ -441,6 +441,21 @@ __global__ void __launch_bounds__(64) nan_scan_kernel(SweepArgs a, unsigned long
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3) nan_scan_order<3, APPROX, TXG>(a, tab, wallnan, bx, by, cx, cy, force, cell_nan, any_nan, n_probe);
     if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4) nan_scan_order<4, APPROX, TXG>(a, tab, wallnan, bx, by, cx, cy, force, cell_nan, any_nan, n_probe);
     const float qnan = __builtin_nanf("");
+    const unsigned long long flagged = __ballot(cell_nan && in_range);
+    if (a.nan_cell_bits != nullptr) {
+        // beside the sweep: leave the flags for nan_apply_kernel (every patch writes its words: nothing to zero beforehand)
+        if (lane == 0) a.nan_cell_bits[tile] = flagged;
+        if (a.nan_row_bits != nullptr) {
+            __syncthreads();
+            unsigned* dst = a.nan_row_bits + tile * a.nan_row_words;
+            if (lane == 0) dst[0] = any_nan ? 1u : 0u;
+            for (int wd = lane; wd + 1 < a.nan_row_words; wd += 64) {
+                unsigned b = 0u;
+                for (int k = 0; k < 32 && 32 * wd + k < a.N; ++k) b |= (any_nan && wallnan[32 * wd + k]) ? (1u << k) : 0u;
+                dst[1 + wd] = b;
+            }
+        }
+    } else {
     if (cell_nan && in_range) {
         a.grad[2 * idx] = qnan;
         a.grad[2 * idx + 1] = qnan;
@@ -452,7 +467,7 @@ __global__ void __launch_bounds__(64) nan_scan_kernel(SweepArgs a, unsigned long
             if (wallnan[i]) dst[4 * i] = dst[4 * i + 1] = dst[4 * i + 2] = dst[4 * i + 3] = qnan;
         if (lane == 0) dst[4 * a.N] = dst[4 * a.N + 1] = qnan;
     }
-    const unsigned long long flagged = __ballot(cell_nan && in_range);
+    }
     if (stats && lane == 0) {
         atomicAdd(&stats[0], n_probe);
         atomicAdd(&stats[1], (unsigned long long)__builtin_popcountll(flagged));
@@ -738,6 +753,19 @@ __global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a
     if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4)
         nan_region_order<4, APPROX, TXG>(a, tab, list, lcount, wallbits, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
     const float qnan = __builtin_nanf("");
+    const unsigned long long flagged = __ballot(cell_nan && in_range && patch_exists);
+    if (a.nan_cell_bits != nullptr) {
+        // beside the sweep: leave the flags for nan_apply_kernel (every patch writes its words: nothing to zero beforehand)
+        if (patch_exists) {
+            if (lane == 0) a.nan_cell_bits[tile] = flagged;
+            if (a.nan_row_bits != nullptr) {
+                __builtin_amdgcn_wave_barrier();
+                unsigned* dst = a.nan_row_bits + tile * a.nan_row_words;
+                if (lane == 0) dst[0] = any_nan ? 1u : 0u;
+                for (int wd = lane; wd + 1 < a.nan_row_words; wd += 64) dst[1 + wd] = any_nan ? wallbits[wd] : 0u;
+            }
+        }
+    } else {
     if (cell_nan && in_range && patch_exists) {
         a.grad[2 * idx] = qnan;
         a.grad[2 * idx + 1] = qnan;
@@ -749,11 +777,43 @@ __global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a
             if ((wallbits[i >> 5] >> (i & 31)) & 1u) dst[4 * i] = dst[4 * i + 1] = dst[4 * i + 2] = dst[4 * i + 3] = qnan;
         if (lane == 0) dst[4 * a.N] = dst[4 * a.N + 1] = qnan;
     }
-    const unsigned long long flagged = __ballot(cell_nan && in_range && patch_exists);
+    }
     if (stats && lane == 0) {
         atomicAdd(&stats[0], n_probe);
         atomicAdd(&stats[1], (unsigned long long)__builtin_popcountll(flagged));
         if (any_nan && patch_exists) atomicAdd(&stats[2], 1ull);
+    }
+}
+
+// What a scan that ran BESIDE the sweep found, applied once both are through: one wave per patch (four to a workgroup); the flagged
+// cells get their NaN gradient, the patch's row of VJP partial sums a NaN for the fixed end point and the flagged objects --
+// exactly what the scan writes itself when it runs behind the sweep.
+__global__ void __launch_bounds__(256) nan_apply_kernel(float* __restrict__ grad, float* __restrict__ partial,
+                                                        const unsigned long long* __restrict__ cell_bits, const unsigned* __restrict__ row_bits,
+                                                        int row_words, int N, int m, int n, long tiles) {
+    const int lane = threadIdx.x & 63;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= tiles) return;
+    const unsigned long long bits = cell_bits[tile];
+    const float qnan = __builtin_nanf("");
+    if (bits != 0ull) {
+        const int tiles_x = (n + TILE_W - 1) / TILE_W;
+        const int col = (int)(tile % tiles_x) * TILE_W + (lane & (TILE_W - 1));
+        const int row = (int)(tile / tiles_x) * TILE_H + (lane / TILE_W);
+        if (((bits >> lane) & 1ull) && col < n && row < m) {
+            const long idx = (long)row * n + col;
+            grad[2 * idx] = qnan;
+            grad[2 * idx + 1] = qnan;
+        }
+    }
+    if (partial != nullptr && row_bits != nullptr) {
+        const unsigned* src = row_bits + tile * row_words;
+        if (src[0] != 0u) {
+            float* dst = partial + tile * (4 * N + 2);
+            for (int i = lane; i < N; i += 64)
+                if ((src[1 + (i >> 5)] >> (i & 31)) & 1u) dst[4 * i] = dst[4 * i + 1] = dst[4 * i + 2] = dst[4 * i + 3] = qnan;
+            if (lane == 0) dst[4 * N] = dst[4 * N + 1] = qnan;
+        }
     }
 }
 

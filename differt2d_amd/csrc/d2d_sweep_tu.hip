@@ -220,6 +220,11 @@ hipError_t launch_nan_scan(bool approx, bool txg, int max_order, bool regions, d
 #undef D2D_NS
     return hipGetLastError();
 }
+hipError_t launch_nan_apply(hipStream_t s, const SweepArgs& a, long tiles) {
+    hipLaunchKernelGGL(nan_apply_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, a.grad, a.partial, a.nan_cell_bits, a.nan_row_bits,
+                       a.nan_row_words, a.N, a.m, a.n, tiles);
+    return hipGetLastError();
+}
 #else
 #error "unknown D2D_TU_FAMILY"
 #endif

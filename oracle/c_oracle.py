@@ -54,6 +54,7 @@ class OrcOptParams(C.Structure):
         ("b2", C.c_double),
         ("eps", C.c_double),
         ("grid_is_tx", C.c_int32),
+        ("g_ulps", C.c_int32),
     ]
 
 
@@ -190,7 +191,7 @@ def power_map_grad(walls, tx, X, Y, allowed=None, nthreads=0, with_gabs=False, w
     if with_gabs:
         out += (gabs,)
     if with_kink:
-        out += (kink.astype(bool),)
+        out += (kink if with_kink == "sites" else kink.astype(bool),)
     if with_amp:
         out += (amp,)
     return out
@@ -244,9 +245,9 @@ def _opt_cands(cands, theta0s):
 
 
 def make_opt_params(solver="min", steps=100, approx=False, function="hard_sigmoid", alpha=100.0, tol=1e-2, patch=0.0, seg_tol=0.005,
-                    fun="received_power", r_coef=0.5, height=0.1, lr=0.1, b1=0.9, b2=0.999, eps=1e-8, grid_role="rx"):
+                    fun="received_power", r_coef=0.5, height=0.1, lr=0.1, b1=0.9, b2=0.999, eps=1e-8, grid_role="rx", g_ulps=0):
     return OrcOptParams(int(bool(approx)), ACT_IDS[function], FUN_IDS[fun], alpha, tol, patch, seg_tol, r_coef, height,
-                        SOLVER_IDS[solver], int(steps), lr, b1, b2, eps, 1 if grid_role == "tx" else 0)
+                        SOLVER_IDS[solver], int(steps), lr, b1, b2, eps, 1 if grid_role == "tx" else 0, int(g_ulps))
 
 
 def opt_power_map(kinds, xys, phis, fixed, X, Y, cands, theta0s, dtype="float32", grad=False, with_paths=False, nthreads=0,
@@ -308,16 +309,18 @@ def opt_adam_step(t, g, x, mu, nu, dtype="float32", **kw):
 def opt_conditioning(kinds, xys, phis, fixed, X, Y, cands, theta0s, steps, tol_pts=2e-5, tol_val=2e-3, with_grad=False, **kw):
     """Which cells of a MinPath / FermatPath sweep are well conditioned -- decided by the oracle alone (the rule of
     scripts/make_golden_cfg5.py::solver_agreement, here at C speed for whole maps): the solver of EVERY candidate follows the
-    same trajectory in the fp64 run, in the fp32 run, and in the fp32 runs from a cell one ulp away and from a fixed end point
-    and initial guesses one ulp away -- interaction points within ``tol_pts`` after 30, 100, 300 and all ``steps`` iterations
-    -- and the four values agree to ``tol_val`` of the map's scale.  Returns dict(value32, value64, stable, dist) with ``dist``
+    same trajectory in the fp64 run, in the fp32 run, in the fp32 runs from a cell one ulp away and from a fixed end point and
+    initial guesses one ulp away, and in fp32 runs whose every objective gradient is moved by one ulp either way (what another
+    implementation of the same derivative differs by) -- interaction points within ``tol_pts`` after 30, 100, 300 and all
+    ``steps`` iterations -- and all the values agree to ``tol_val`` of the map's scale.  Returns dict(value32, value64, stable, dist) with ``dist``
     the largest distance of an fp32 run's value from the fp64 one (the bar no fp32 evaluation can be held below); with_grad
     also grad32 / grad64 (per-cell gradients of the plain fp32 and fp64 runs)."""
     F = np.float32
     up = lambda a: np.nextafter(np.asarray(a, F), F(np.inf)).astype(F)  # noqa: E731
     X, Y, fixed = np.asarray(X, F), np.asarray(Y, F), np.asarray(fixed, F)
     th_up = [up(t) for t in theta0s]
-    variants = ((fixed, X, Y, theta0s), (fixed, up(X), up(Y), theta0s), (up(fixed), X, Y, th_up))
+    variants = ((fixed, X, Y, theta0s, 0), (fixed, up(X), up(Y), theta0s, 0), (up(fixed), X, Y, th_up, 0), (fixed, X, Y, theta0s, 1),
+                (fixed, X, Y, theta0s, -1))
     snaps = sorted({s for s in (30, 100, 300, steps) if s <= steps})
     out = {}
     r64 = opt_power_map(kinds, xys, phis, fixed, X, Y, cands, theta0s, dtype="float64", with_paths=True, steps=steps, snaps=snaps,
@@ -325,9 +328,9 @@ def opt_conditioning(kinds, xys, phis, fixed, X, Y, cands, theta0s, steps, tol_p
     v64, p64 = r64[0], r64[-2]
     stable = np.ones(X.shape, bool)
     dist = np.zeros(X.shape)
-    for i, (f_, X_, Y_, th_) in enumerate(variants):
+    for i, (f_, X_, Y_, th_, gu) in enumerate(variants):
         r32 = opt_power_map(kinds, xys, phis, f_, X_, Y_, cands, th_, dtype="float32", with_paths=True, steps=steps, snaps=snaps,
-                            grad=with_grad and i == 0, **kw)
+                            grad=with_grad and i == 0, g_ulps=gu, **kw)
         if len(cands):
             with np.errstate(invalid="ignore"):
                 stable &= np.abs(r32[-2] - p64).max(axis=(-1, -2, -3, -4)) <= tol_pts

@@ -77,6 +77,13 @@ static inline dual dsqrt(dual a) {
  * arguments with DIFFERENT tangents was met -- the cell sits on a kink of the map, where the derivative is a convention (JAX's:
  * the mean) and where an evaluation with any other rounding may see no tie at all. */
 static _Thread_local int g_kink;
+/* g_site: where the next minimum / maximum sits -- bit of g_kink it sets when it ties with different tangents: 0 inside an
+ * activation (relu6), 1 on_objects' ge / le pair, 2 on_objects' fold over the walls, 3 a segment test's ge / le pair, 4 the pair of
+ * a wall test's two quotients, 5 the fold of the occlusion tests, 6 valid = all(on, not hit, ok) */
+static _Thread_local int g_site;
+/* Diagnostic (environment ORC_TIE_FIRST = bit mask of sites): at those sites a tie sends the whole cotangent to the FIRST
+ * argument instead of splitting it -- what an adjoint without a tie rule computes; used to attribute a deviation to a site. */
+static int g_tie_first = 0;
 /* g_amp (per thread, per candidate): the largest |u| / |u.n| met in the backward scan -- how much a step amplifies the
  * rounding of the point it starts from (a pole of the image method nearby: every fp32 evaluation order gets its own digits) */
 static _Thread_local double g_amp;
@@ -84,7 +91,8 @@ static inline dual dmin(dual a, dual b) {
     if (a.v != a.v || b.v != b.v) { dual r = {NAN, NAN, NAN}; return r; }
     if (a.v < b.v) return a;
     if (b.v < a.v) return b;
-    if (a.x != b.x || a.y != b.y) g_kink = 1;
+    if (a.x != b.x || a.y != b.y) g_kink |= 1 << g_site;
+    if ((g_tie_first >> g_site) & 1) return a;
     dual r = {a.v, 0.5 * (a.x + b.x), 0.5 * (a.y + b.y)};
     return r;
 }
@@ -92,7 +100,8 @@ static inline dual dmax(dual a, dual b) {
     if (a.v != a.v || b.v != b.v) { dual r = {NAN, NAN, NAN}; return r; }
     if (a.v > b.v) return a;
     if (b.v > a.v) return b;
-    if (a.x != b.x || a.y != b.y) g_kink = 1;
+    if (a.x != b.x || a.y != b.y) g_kink |= 1 << g_site;
+    if ((g_tie_first >> g_site) & 1) return a;
     dual r = {a.v, 0.5 * (a.x + b.x), 0.5 * (a.y + b.y)};
     return r;
 }
@@ -100,8 +109,13 @@ static inline dual dmax(dual a, dual b) {
 /* logic.py:218-267 */
 static inline dual activation(dual x, const orc_params* p) {
     dual z = dmulc(p->alpha, x);
-    if (p->act == 0) /* jax.nn.hard_sigmoid: relu6(z + 3) / 6, relu6 = minimum(maximum(., 0), 6) */
-        return ddiv(dmin(dmax(dadd(z, dc(3.0f)), dc(0.0f)), dc(6.0f)), dc(6.0f));
+    if (p->act == 0) { /* jax.nn.hard_sigmoid: relu6(z + 3) / 6, relu6 = minimum(maximum(., 0), 6) */
+        const int site = g_site;
+        g_site = 0;
+        dual r = ddiv(dmin(dmax(dadd(z, dc(3.0f)), dc(0.0f)), dc(6.0f)), dc(6.0f));
+        g_site = site;
+        return r;
+    }
     /* jax.nn.sigmoid = lax.logistic: value 1 / (1 + exp(-z)), JVP y (1 - y) */
     const float y = 1.0f / (1.0f + expf(-z.v));
     const double g = (double)y * (1.0 - (double)y);
@@ -145,7 +159,9 @@ static inline dual seg_test(dual num, dual den, const orc_params* p) {
     const int den_is_zero = (den.v == 0.0f);
     dual dd = den_is_zero ? dc(1.0f) : den;
     dual t = den_is_zero ? dc(INFINITY) : ddiv(num, dd);
-    return t_and(t_ge(t, dc(-p->seg_tol), p), t_le(t, dc(1.0f + p->seg_tol), p), p->approx);
+    dual ge = t_ge(t, dc(-p->seg_tol), p), le = t_le(t, dc(1.0f + p->seg_tol), p);
+    g_site = 3;
+    return t_and(ge, le, p->approx);
 }
 
 /* geometry.py:82-173 with P1, P2 = the patched wall (constants here), P3, P4 = a path segment */
@@ -156,7 +172,9 @@ static inline dual wall_hits(const wall_t* w, dual p3x, dual p3y, dual p4x, dual
     dual a = dsub(dmul(By, Cx), dmul(Bx, Cy));
     dual b = dsub(dmulc(Ax, Cy), dmulc(Ay, Cx));
     dual d = dsub(dmulc(Ay, Bx), dmulc(Ax, By));
-    return t_and(seg_test(a, d, p), seg_test(b, d, p), p->approx);
+    dual sa = seg_test(a, d, p), sb = seg_test(b, d, p);
+    g_site = 4;
+    return t_and(sa, sb, p->approx);
 }
 
 static inline float ipow(float x, int n) { /* lax.integer_pow */
@@ -226,7 +244,10 @@ static dual eval_candidate(const wall_t* W, int N, const int* cand, int k, dual 
         float sq = w->tx_ * w->tx_ + w->ty_ * w->ty_;
         if (sq == 0.0f) sq = 1.0f;
         dual s = ddiv(dadd(dmulc(w->tx_, ox_), dmulc(w->ty_, oy_)), dc(sq));
-        dual c = t_and(t_ge(s, dc(0.0f), p), t_le(s, dc(1.0f), p), p->approx);
+        dual ge = t_ge(s, dc(0.0f), p), le = t_le(s, dc(1.0f), p);
+        g_site = 1;
+        dual c = t_and(ge, le, p->approx);
+        g_site = 2;
         on = t_and(on, c, p->approx);
     }
     /* path loss, geometry.py:1077-1084 / 641-650 */
@@ -256,12 +277,15 @@ static dual eval_candidate(const wall_t* W, int N, const int* cand, int k, dual 
             const int ig1 = (i == k) ? -1 : cand[i];
             for (int j = 0; j < N; ++j) {
                 if (j == ig0 || j == ig1) continue;
-                hit = t_or(hit, wall_hits(&W[j], px[i], py[i], px[i + 1], py[i + 1], p), p->approx);
+                dual wh = wall_hits(&W[j], px[i], py[i], px[i + 1], py[i + 1], p);
+                g_site = 5;
+                hit = t_or(hit, wh, p->approx);
                 if (p->prune && hit.v == 1.0f && hit.x == 0.0 && hit.y == 0.0) { i = k; break; }
             }
         }
     }
     dual ok = t_lt(loss, dc(p->tol), p);
+    g_site = 6;
     dual valid = skip ? dc(0.0f) : t_and(t_and(on, t_not(hit, p->approx), p->approx), ok, p->approx);
     if (valid.v != valid.v) valid = dc(0.0f); /* jnp.nan_to_num: value 0, nothing flows back */
     /* path function: geometry.py:176-203, utils.py:17-54 */
@@ -321,13 +345,14 @@ static long enum_candidates(int N, const uint8_t* allowed, int k, cand_t* out) {
  * [ncell] sum over the candidates of |d contribution / d cell.x| + |d contribution / d cell.y| -- the magnitude an fp32
  * evaluation's rounding scales with (a gradient that is a small difference of large contributions cannot be held to a
  * relative bar of its own size).  kink (may be NULL): [ncell] 1 where some minimum / maximum tied between arguments with
- * different tangents.  amp (may be NULL): [ncell] the largest |u| / |u.n| of the backward scans of the candidates whose
+ * different tangents (a bit mask of where: see g_site).  amp (may be NULL): [ncell] the largest |u| / |u.n| of the backward scans of the candidates whose
  * contribution has a non-zero tangent (how ill-conditioned the cell's gradient is: a pole of the image method nearby).
  */
 int orc_power_map_grad(const float* walls, int N, const uint8_t* allowed, const orc_params* p, const float* tx, const float* X,
                        const float* Y, long ncell, float* value, double* grad, double* gabs, uint8_t* kink, double* amp,
                        int nthreads) {
     if (N < 0 || p->max_order > ORC_MAX_ORDER || p->min_order < 0) return -1;
+    g_tie_first = getenv("ORC_TIE_FIRST") ? atoi(getenv("ORC_TIE_FIRST")) : 0;
     wall_t* W = (wall_t*)malloc(sizeof(wall_t) * (N > 0 ? N : 1));
     for (int j = 0; j < N; ++j) make_wall(&W[j], walls + 4 * j, p->patch);
     long total = 0;

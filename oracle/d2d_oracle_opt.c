@@ -63,6 +63,8 @@ typedef struct orc_opt_params {
     int32_t steps;    /* >= 1 */
     double lr, b1, b2, eps; /* optax.adam(0.1): 0.1, 0.9, 0.999, 1e-8 */
     int32_t grid_is_tx;
+    int32_t g_ulps; /* conditioning probe: every objective gradient moved by this many units in the last place (0: as computed) --
+                       what another implementation of the same derivative (a reverse pass, a hand-derived formula) differs by */
 } orc_opt_params;
 
 #define ORC_OPT_INSTANCE
@@ -504,7 +506,10 @@ static JET SFX(eval_candidate)(const OBJ* O, int N, const int32_t* cand, int k, 
 #endif
             }
             for (int i = 0; i < n; ++i) {
-                const REAL g = (REAL)f.g[i];
+                REAL g = (REAL)f.g[i];
+                for (int u = 0; u < (p->g_ulps < 0 ? -p->g_ulps : p->g_ulps); ++u)
+                    g = (sizeof(REAL) == 4) ? (REAL)nextafterf((float)g, p->g_ulps > 0 ? INFINITY : -INFINITY)
+                                            : (REAL)nextafter((double)g, p->g_ulps > 0 ? INFINITY : -INFINITY);
                 const double* dg = dgs[i];
                 /* oracle/ref.py:633-637 */
                 const REAL b1 = (REAL)p->b1, b2 = (REAL)p->b2, ob1 = (REAL)(1.0 - p->b1), ob2 = (REAL)(1.0 - p->b2);

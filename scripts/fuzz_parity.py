@@ -97,6 +97,19 @@ def grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=False):
     floor = 1e-6 * float(np.nanmax(np.abs(grad), initial=0.0)) + 1e-30
     bar = rel * gabs[..., None] + rel * np.abs(grad) + floor + sens  # (no fp32 evaluation is pinned tighter than one input ulp)
     bad = (np.abs(g - grad) > bar).any(-1) & fin
+    # Cells beyond that bar are held to the oracle's conditioning in every direction: the cell and the fixed end point moved by
+    # one ulp either way, one coordinate at a time (an activation's argument within rounding of a kink of hard_sigmoid: the
+    # derivative JUMPS there, and which side an fp32 evaluation lands on depends on its order of operations)
+    for w in np.argwhere(bad)[:16]:
+        w = tuple(w)
+        Xc, Yc = X[w[0]:w[0] + 1, w[1]:w[1] + 1], Y[w[0]:w[0] + 1, w[1]:w[1] + 1]
+        s6 = np.zeros(2)
+        nudge = lambda a, d: np.nextafter(np.asarray(a, F), F(np.inf * d)) if d else np.asarray(a, F)  # noqa: E731
+        for dx, dy, dt in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
+            _, g2 = CO.power_map_grad(walls, nudge(tx, dt), nudge(Xc, dx), nudge(Yc, dy), **okw)
+            s6 = np.maximum(s6, np.nan_to_num(np.abs(g2[0, 0] - grad[w]), nan=np.inf))
+        if (np.abs(g[w] - grad[w]) <= bar[w] + 2.0 * s6).all():
+            bad[w] = False
     if bad.any():
         w = np.argwhere(bad)[0]
         out.append(f"gradient ({int(bad.sum())} cells, first {w.tolist()}: GPU {g[tuple(w)]}, oracle {grad[tuple(w)]}, gabs {gabs[tuple(w)]:.3e})")
