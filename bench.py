@@ -361,6 +361,8 @@ def main():
     ap.add_argument("--max-order", type=int, default=None)
     ap.add_argument("--approx", type=int, default=0, help="validity of the TIMED map: 0 hard (reference default), 1 hard_sigmoid")
     ap.add_argument("--gather", choices=["root", "all"], default="root", help="N > 1: gather the map to rank 0, or all-gather it")
+    ap.add_argument("--comm-prio", type=int, default=0, choices=[-1, 0, 1],
+                    help="N > 1: priority of the stream the RCCL gather runs on beside the next sweep (lowest / default / highest): A/B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other modes / moving-TX / value+grad / parity legs")
     args = ap.parse_args()
@@ -396,6 +398,7 @@ def main():
         print(f"[bench rank {rank}] {e}", file=sys.stderr, flush=True)
         sys.exit(4)
     if distributed:
+        ctx.set_option("comm_prio", args.comm_prio)
         # torch.distributed.run is only the launcher: rendezvous through /tmp, everything else through RCCL
         from differt2d_amd.parallel import file_rendezvous, file_rendezvous_cleanup
 
@@ -652,7 +655,7 @@ def main():
                          "every timed step sweeps the same transmitter (see moving_tx for a different one every step) and "
                          "rebuilds everything that depends on it: shadow masks, region candidate lists, patch schedule (on a side "
                          "stream beside the previous step's sweep, as in any back-to-back sequence of launches: DESIGN.md section 4)",
-                "sharding": f"{world} rank(s), 8-row blocks round-robin"
+                "sharding": f"{world} rank(s), 8-row blocks round-robin" + (f", comm stream priority {args.comm_prio}" if world > 1 else "")
                             + (f"; 1 RCCL {'gather to rank 0 (ncclSend/ncclRecv)' if args.gather == 'root' else 'all-gather'} of the "
                                f"value map per step, overlapped with the next step's sweep" if gather else ""),
             },

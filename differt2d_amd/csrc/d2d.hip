@@ -306,6 +306,7 @@ struct d2d_ctx {
     DevBuf<float> d_gather[2], d_send[2];  // [0] value map, [1] gradient map: gathered shards / staging copy of the local shard
     // the all-gather of step k runs on its own stream, overlapped with the sweep of step k+1
     hipStream_t comm_stream = nullptr;
+    long long comm_prio = 0;  // "comm_prio" option: priority of comm_stream when it is created
     // every collective runs on comm_stream behind a "ready" event of the main stream; [0] value-map gather, [1] gradient-map
     // gather, [2] scene-VJP all-reduce; the main stream waits for ev_done[i] only where it reuses what collective i touches
     hipEvent_t ev_ready = nullptr, ev_done[3] = {nullptr, nullptr, nullptr};
@@ -524,7 +525,13 @@ int join_all_comm(d2d_ctx* c) {
 }
 int ensure_comm_stream(d2d_ctx* c) {
     if (c->comm_stream) return D2D_OK;
-    HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    // "comm_prio" (set before the first collective): 0 default priority, 1 the highest, -1 the lowest.  The gather runs beside the
+    // NEXT step's sweep, and round 4 measured that more busy hardware queues make a sweep's own workgroups start more slowly
+    // ("Tried and rejected in round 4"): which priority costs the sweep least is for the first multi-GPU run
+    // to measure (bench.py --comm-prio).
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    HIP_TRY(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, c->comm_prio > 0 ? prio_hi : (c->comm_prio < 0 ? prio_lo : 0)));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     for (int w = 0; w < 3; ++w) HIP_TRY(hipEventCreateWithFlags(&c->ev_done[w], hipEventDisableTiming));
     return D2D_OK;
@@ -2025,6 +2032,10 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
         if (value) c->nan_scan_mode = value;
     }
     else if (!strcmp(name, "nan_scan_stats")) c->nan_scan_stats = value != 0;
+    else if (!strcmp(name, "comm_prio")) {
+        if (c->comm_stream) return fail(D2D_ERR_STATE, "comm_prio must be set before the first collective creates the communication stream");
+        c->comm_prio = value > 0 ? 1 : (value < 0 ? -1 : 0);
+    }
     else if (!strcmp(name, "nan_scan_async")) c->nan_scan_async = value != 0;
     else if (!strcmp(name, "nan_scan_prio")) c->nan_scan_prio = value != 0 ? 1 : 0;
     else if (!strcmp(name, "prep_fused")) c->prep_fused = value != 0;

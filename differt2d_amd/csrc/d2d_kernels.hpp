@@ -1178,12 +1178,14 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
             bool tie = false;
             float vmax = 0.0f;
             if (wave_any(occ)) {
+                // (tests that tie at a SATURATED value -- two occluders that each hide the lane completely -- have zero derivatives:
+                // nothing to split, and they are common at shadow boundaries)
                 if (MODE == MODE_HSIG) {
                     vmax = hit_c;
-                    tie = occ && hit2 == hit_c;
+                    tie = occ && hit2 == hit_c && hit_c < 6.0f;
                 } else {
                     vmax = sigmoidf_(hit_z);
-                    tie = occ && sigmoidf_(hit2) == vmax;
+                    tie = occ && vmax < 1.0f && sigmoidf_(hit2) == vmax;
                 }
             }
             if (wave_any(tie)) {

@@ -251,12 +251,13 @@ def make_opt_params(solver="min", steps=100, approx=False, function="hard_sigmoi
 
 
 def opt_power_map(kinds, xys, phis, fixed, X, Y, cands, theta0s, dtype="float32", grad=False, with_paths=False, nthreads=0,
-                  snaps=None, **kw):
+                  snaps=None, fp32_tangents=False, **kw):
     """MinPath / FermatPath power map over a scene of Wall / RIS / Vertex objects (kinds [N]: 0 / 1 / 2, xys [N, 2, 2] -- a
     Vertex keeps its point in row 0 --, phis [N]) for one fixed end point; ``cands``: list of index arrays, ``theta0s``: one
     array of initial guesses per candidate (shared by all cells, scene.py:1887-1890).  dtype float32: the reference's chain;
     float64: the same chain in double (for the conditioning mask).  Returns value [shape] (dtype), and with ``grad`` the
-    per-cell gradient [shape + (2,)] float64 (NaN where the reference's reverse mode yields NaN), and with ``with_paths`` the
+    per-cell gradient [shape + (2,)] float64 (NaN where the reference's reverse mode yields NaN; ``fp32_tangents``: the
+    derivative arithmetic itself in fp32 too -- the yardstick for what any fp32 autodiff loses), and with ``with_paths`` the
     solver's interaction points after ``snaps`` (default: all ``steps``) updates [shape + (C, len(snaps), ORC_MAX_ORDER, 2)] and
     the recorded losses [shape + (C,)]."""
     f64 = np.dtype(dtype) == np.float64
@@ -271,7 +272,7 @@ def opt_power_map(kinds, xys, phis, fixed, X, Y, cands, theta0s, dtype="float32"
     pts = np.empty(Xc.shape + (len(cands), snaps.size, ORC_MAX_ORDER, 2), np.float64) if with_paths else None
     loss = np.empty(Xc.shape + (len(cands),), np.float64) if with_paths else None
     ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
-    rc = lib().orc_opt_power_map(int(f64), xys.reshape(-1) if xys.size else np.zeros(1), kinds if kinds.size else np.zeros(1, np.uint8),
+    rc = lib().orc_opt_power_map(2 if (fp32_tangents and grad and not f64) else int(f64), xys.reshape(-1) if xys.size else np.zeros(1), kinds if kinds.size else np.zeros(1, np.uint8),
                                  sincos.reshape(-1) if sincos.size else np.zeros(1), int(kinds.size), C.byref(p),
                                  np.ascontiguousarray(np.asarray(fixed, np.float32), dtype=np.float64), Xc.reshape(-1), Yc.reshape(-1), Xc.size,
                                  ci.reshape(-1), ck, len(cands), th.reshape(-1), value.reshape(-1), ptr(g), ptr(pts), ptr(loss), snaps, int(snaps.size), nthreads)
@@ -314,7 +315,8 @@ def opt_conditioning(kinds, xys, phis, fixed, X, Y, cands, theta0s, steps, tol_p
     implementation of the same derivative differs by) -- interaction points within ``tol_pts`` after 30, 100, 300 and all
     ``steps`` iterations -- and all the values agree to ``tol_val`` of the map's scale.  Returns dict(value32, value64, stable, dist) with ``dist``
     the largest distance of an fp32 run's value from the fp64 one (the bar no fp32 evaluation can be held below); with_grad
-    also grad32 / grad64 (per-cell gradients of the plain fp32 and fp64 runs)."""
+    also grad32 / grad64 (per-cell gradients of the plain fp32 and fp64 runs) and grad32t (the fp32 run with its derivative
+    arithmetic in fp32 too)."""
     F = np.float32
     up = lambda a: np.nextafter(np.asarray(a, F), F(np.inf)).astype(F)  # noqa: E731
     X, Y, fixed = np.asarray(X, F), np.asarray(Y, F), np.asarray(fixed, F)
@@ -339,10 +341,20 @@ def opt_conditioning(kinds, xys, phis, fixed, X, Y, cands, theta0s, steps, tol_p
             out["value32"] = r32[0]
             if with_grad:
                 out["grad32"] = r32[1]
+                # the same run with its derivative arithmetic in fp32 as well: what fp32 autodiff (forward or reverse) loses
+                out["grad32t"] = opt_power_map(kinds, xys, phis, f_, X_, Y_, cands, th_, dtype="float32", steps=steps, grad=True,
+                                               fp32_tangents=True, **kw)[1]
     scale = float(np.nanmax(np.abs(v64))) if v64.size else 0.0
     with np.errstate(invalid="ignore"):
         stable &= dist <= tol_val * scale + tol_val * np.abs(v64)
-    out.update(value64=v64, dist=dist, scale=scale, stable=stable)
+    # Adam with a fixed step ends many near-grazing solves in a period-2 limit cycle (lr = 0.1: two points some 5e-3 apart), and
+    # on which of the two a run sits after `steps` updates is decided when its trajectory enters the cycle -- by rounding: the
+    # probes above agree there, a gradient 2 .. 16 ulps away flips it (scripts/diag_cfg5_full.py).  `parity`: cells whose value
+    # changes with one more update; `value32_next` is what the other parity gives.
+    v_next = opt_power_map(kinds, xys, phis, fixed, X, Y, cands, theta0s, dtype="float32", steps=steps + 1, **kw).astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        parity = ~(np.abs(v_next - out["value32"].astype(np.float64)) <= 1e-5 * scale + 1e-5 * np.abs(v64))
+    out.update(value64=v64, dist=dist, scale=scale, stable=stable, parity=parity, value32_next=v_next)
     if with_grad:
         out["grad64"] = r64[1]
     return out

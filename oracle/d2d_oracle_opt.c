@@ -68,9 +68,12 @@ typedef struct orc_opt_params {
 } orc_opt_params;
 
 #define ORC_OPT_INSTANCE
-/* four instances of the body below: {fp32, fp64} x {lean: first-order jets in theta only (value maps), full: second-order
- * jets in (theta, cell) (value + per-cell gradient)} */
+/* five instances of the body below: {fp32, fp64} x {lean: first-order jets in theta only (value maps), full: second-order
+ * jets in (theta, cell) (value + per-cell gradient)}, and the full fp32 one again with its DERIVATIVES in fp32 as well (TREAL =
+ * float: what an fp32 derivative arithmetic -- any fp32 autodiff, forward or reverse -- loses against the exact derivative of
+ * the fp32 chain; the yardstick of the gradient comparisons) */
 #define REAL float
+#define TREAL double
 #define SQRT sqrtf
 #define EXP expf
 #define REAL_EPS 1.1920929e-07f
@@ -83,12 +86,19 @@ typedef struct orc_opt_params {
 #define JSECOND 1
 #include "d2d_oracle_opt.c"
 #undef SFX
+#undef TREAL
+#define TREAL float
+#define SFX(name) name##_f32t
+#include "d2d_oracle_opt.c"
+#undef SFX
 #undef JSECOND
+#undef TREAL
 #undef REAL
 #undef SQRT
 #undef EXP
 #undef REAL_EPS
 #define REAL double
+#define TREAL double
 #define SQRT sqrt
 #define EXP exp
 #define REAL_EPS 2.220446049250313e-16
@@ -104,7 +114,7 @@ typedef struct orc_opt_params {
 /*
  * xys [N][2][2] (a Vertex keeps its point in row 0), kind [N], sincos [N][2] = sin(phi), cos(phi) as the caller's backend
  * evaluates them; cands [C][ORC_MAX_ORDER], cand_k [C]; theta0 [C][ORC_MAX_ORDER] (one guess per unknown of the candidate, in
- * order).  fixed [2]: the transmitter (receiver for a TX grid).  Outputs: value [ncell] (as double: exact for the fp32 run);
+ * order).  f64: 0 fp32, 1 fp64, 2 fp32 with fp32 derivatives (gradient runs).  fixed [2]: the transmitter (receiver for a TX grid).  Outputs: value [ncell] (as double: exact for the fp32 run);
  * grad [ncell][2] or NULL; pts [ncell][C][n_snap][ORC_MAX_ORDER][2] or NULL (the solver's interaction points after snaps[s]
  * updates, 1 <= snaps[s] <= steps) and loss [ncell][C] or NULL (the recorded loss): what the trajectory agreement of the
  * conditioning mask is taken from.
@@ -114,7 +124,7 @@ int orc_opt_power_map(int f64, const double* xys, const uint8_t* kind, const dou
                       const int32_t* cand_k, long C, const double* theta0, double* value, double* grad, double* pts,
                       double* loss, const int32_t* snaps, int n_snap, int nthreads) {
 #define ORC_OPT_ARGS xys, kind, sincos, N, p, fixed, X, Y, ncell, cands, cand_k, C, theta0, value, grad, pts, loss, snaps, n_snap, nthreads
-    if (grad) return f64 ? orc_opt_power_map_f64g(ORC_OPT_ARGS) : orc_opt_power_map_f32g(ORC_OPT_ARGS);
+    if (grad) return f64 == 1 ? orc_opt_power_map_f64g(ORC_OPT_ARGS) : (f64 == 2 ? orc_opt_power_map_f32t(ORC_OPT_ARGS) : orc_opt_power_map_f32g(ORC_OPT_ARGS));
     return f64 ? orc_opt_power_map_f64(ORC_OPT_ARGS) : orc_opt_power_map_f32(ORC_OPT_ARGS);
 }
 
@@ -143,9 +153,9 @@ int orc_opt_adam_step(int f64, const orc_opt_params* p, int t, double g, double*
 #endif
 typedef struct {
     REAL v;
-    double g[NV];
+    TREAL g[NV];
 #if JSECOND
-    double h[NV][NV];
+    TREAL h[NV][NV];
 #endif
 } SFX(jet);
 #define JET SFX(jet)
@@ -197,7 +207,7 @@ static inline JET SFX(jsub)(JET a, JET b) {
 static inline JET SFX(jmul)(JET a, JET b) {
     JET r;
     r.v = a.v * b.v;
-    const double av = (double)a.v, bv = (double)b.v;
+    const TREAL av = (TREAL)a.v, bv = (TREAL)b.v;
     for (int i = 0; i < J_nv; ++i) {
         r.g[i] = a.g[i] * bv + av * b.g[i];
         IF2(for (int j = 0; j < J_nv; ++j) r.h[i][j] = a.h[i][j] * bv + a.g[i] * b.g[j] + a.g[j] * b.g[i] + av * b.h[i][j];)
@@ -208,15 +218,15 @@ static inline JET SFX(jmulc)(REAL c, JET a) {
     JET r;
     r.v = c * a.v;
     for (int i = 0; i < J_nv; ++i) {
-        r.g[i] = (double)c * a.g[i];
-        IF2(for (int j = 0; j < J_nv; ++j) r.h[i][j] = (double)c * a.h[i][j];)
+        r.g[i] = (TREAL)c * a.g[i];
+        IF2(for (int j = 0; j < J_nv; ++j) r.h[i][j] = (TREAL)c * a.h[i][j];)
     }
     return r;
 }
 static inline JET SFX(jdiv)(JET a, JET b) {
     JET r;
     r.v = a.v / b.v;
-    const double ib = 1.0 / (double)b.v, q = (double)a.v * ib;
+    const TREAL ib = (TREAL)1 / (TREAL)b.v, q = (TREAL)a.v * ib;
     for (int i = 0; i < J_nv; ++i) r.g[i] = (a.g[i] - q * b.g[i]) * ib;
     /* d2 (a / b) = (a_ij - q_i b_j - q_j b_i - q b_ij) / b */
     IF2(for (int i = 0; i < J_nv; ++i) for (int j = 0; j < J_nv; ++j)
@@ -226,7 +236,7 @@ static inline JET SFX(jdiv)(JET a, JET b) {
 static inline JET SFX(jsqrt)(JET a) {
     JET r;
     r.v = SQRT(a.v);
-    const double s = sqrt((double)a.v), i2s = 1.0 / (2.0 * s);
+    const TREAL s = (TREAL)sqrt((double)a.v), i2s = (TREAL)1 / ((TREAL)2 * s);
     for (int i = 0; i < J_nv; ++i) r.g[i] = a.g[i] * i2s;
     /* (a_ij - 2 s_i s_j) / 2s */
     IF2(for (int i = 0; i < J_nv; ++i) for (int j = 0; j < J_nv; ++j) r.h[i][j] = a.h[i][j] * i2s - r.g[i] * r.g[j] / s;)
@@ -247,7 +257,7 @@ static inline JET SFX(jmin)(JET a, JET b) {
     if (a.v < b.v) return a;
     if (b.v < a.v) return b;
     JET r = a;
-    for (int i = 0; i < J_nv; ++i) r.g[i] = 0.5 * (a.g[i] + b.g[i]);
+    for (int i = 0; i < J_nv; ++i) r.g[i] = (TREAL)0.5 * (a.g[i] + b.g[i]);
     return r;
 }
 static inline JET SFX(jmax)(JET a, JET b) {
@@ -255,7 +265,7 @@ static inline JET SFX(jmax)(JET a, JET b) {
     if (a.v > b.v) return a;
     if (b.v > a.v) return b;
     JET r = a;
-    for (int i = 0; i < J_nv; ++i) r.g[i] = 0.5 * (a.g[i] + b.g[i]);
+    for (int i = 0; i < J_nv; ++i) r.g[i] = (TREAL)0.5 * (a.g[i] + b.g[i]);
     return r;
 }
 #define jmin SFX(jmin)
@@ -399,7 +409,7 @@ static inline JET SFX(activation)(JET x, const orc_opt_params* p) {
     JET z = jmulc((REAL)p->alpha, x);
     if (p->act == 0) return jdiv(jmin(jmax(jadd(z, jc((REAL)3)), jc((REAL)0)), jc((REAL)6)), jc((REAL)6));
     JET r = jc((REAL)1 / ((REAL)1 + EXP(-z.v))); /* lax.logistic; JVP y (1 - y) */
-    const double gg = (double)r.v * (1.0 - (double)r.v);
+    const TREAL gg = (TREAL)r.v * ((TREAL)1 - (TREAL)r.v);
     for (int i = 0; i < J_nv; ++i) r.g[i] = gg * z.g[i];
     return r;
 }
@@ -457,14 +467,14 @@ static JET SFX(eval_candidate)(const OBJ* O, int N, const int32_t* cand, int k, 
     const int nc = with_grad ? 2 : 0; /* cell variables sit behind the thetas */
     /* theta_t, mu_t, nu_t as first-order duals w.r.t. the cell: value + d / d cell (the only history the loop carries) */
     REAL th[ORC_MAX_ORDER], mu[ORC_MAX_ORDER], nu[ORC_MAX_ORDER];
-    double dth[ORC_MAX_ORDER][2], dmu[ORC_MAX_ORDER][2], dnu[ORC_MAX_ORDER][2];
+    TREAL dth[ORC_MAX_ORDER][2], dmu[ORC_MAX_ORDER][2], dnu[ORC_MAX_ORDER][2];
     for (int i = 0; i < n; ++i) {
         th[i] = (REAL)theta0[i]; mu[i] = nu[i] = (REAL)0;
         dth[i][0] = dth[i][1] = dmu[i][0] = dmu[i][1] = dnu[i][0] = dnu[i][1] = 0.0;
     }
     JET px[ORC_MAX_ORDER + 2], py[ORC_MAX_ORDER + 2];
     REAL last_loss = (REAL)0;
-    double dlast[2] = {0.0, 0.0};
+    TREAL dlast[2] = {0.0, 0.0};
     int poison = 0;
     /* hard validity is a bool and fun = 1 ignores the path: nothing of the contribution is differentiated (no NaN either) */
     const int differentiated = with_grad && (p->approx || p->fun_id != 3);
@@ -494,7 +504,7 @@ static JET SFX(eval_candidate)(const OBJ* O, int N, const int32_t* cand, int k, 
                 }
             REAL c1, c2;
             SFX(adam_consts)(p, t, &c1, &c2);
-            double dgs[ORC_MAX_ORDER][2]; /* d g_i / d cell, with d theta_t / d cell of THIS step for every unknown */
+            TREAL dgs[ORC_MAX_ORDER][2]; /* d g_i / d cell, with d theta_t / d cell of THIS step for every unknown */
             for (int i = 0; i < n; ++i) {
                 dgs[i][0] = dgs[i][1] = 0.0;
 #if JSECOND
@@ -510,7 +520,7 @@ static JET SFX(eval_candidate)(const OBJ* O, int N, const int32_t* cand, int k, 
                 for (int u = 0; u < (p->g_ulps < 0 ? -p->g_ulps : p->g_ulps); ++u)
                     g = (sizeof(REAL) == 4) ? (REAL)nextafterf((float)g, p->g_ulps > 0 ? INFINITY : -INFINITY)
                                             : (REAL)nextafter((double)g, p->g_ulps > 0 ? INFINITY : -INFINITY);
-                const double* dg = dgs[i];
+                const TREAL* dg = dgs[i];
                 /* oracle/ref.py:633-637 */
                 const REAL b1 = (REAL)p->b1, b2 = (REAL)p->b2, ob1 = (REAL)(1.0 - p->b1), ob2 = (REAL)(1.0 - p->b2);
                 mu[i] = b1 * mu[i] + ob1 * g;
@@ -521,15 +531,15 @@ static JET SFX(eval_candidate)(const OBJ* O, int N, const int32_t* cand, int k, 
                 th[i] = th[i] + (REAL)(-p->lr) * (mh / den);
                 if (with_grad)
                     for (int c = 0; c < 2; ++c) {
-                        dmu[i][c] = (double)b1 * dmu[i][c] + (double)ob1 * dg[c];
-                        dnu[i][c] = (double)b2 * dnu[i][c] + (double)ob2 * (2.0 * (double)g * dg[c]);
-                        const double dmh = dmu[i][c] / (double)c1, dnh = dnu[i][c] / (double)c2;
+                        dmu[i][c] = (TREAL)b1 * dmu[i][c] + (TREAL)ob1 * dg[c];
+                        dnu[i][c] = (TREAL)b2 * dnu[i][c] + (TREAL)ob2 * ((TREAL)2 * (TREAL)g * dg[c]);
+                        const TREAL dmh = dmu[i][c] / (TREAL)c1, dnh = dnu[i][c] / (TREAL)c2;
                         /* sqrt'(0) = inf: the reference's reverse mode meets 0 * inf when g has been 0 exactly all along */
-                        double dsq;
-                        if (nh == (REAL)0) { dsq = 0.0; if (differentiated) poison = 1; }
-                        else dsq = dnh / (2.0 * sqrt((double)nh));
-                        const double dupd = (dmh - ((double)mh / (double)den) * dsq) / (double)den;
-                        dth[i][c] += (double)(REAL)(-p->lr) * dupd;
+                        TREAL dsq;
+                        if (nh == (REAL)0) { dsq = 0; if (differentiated) poison = 1; }
+                        else dsq = dnh / ((TREAL)2 * (TREAL)sqrt((double)nh));
+                        const TREAL dupd = (dmh - ((TREAL)mh / (TREAL)den) * dsq) / (TREAL)den;
+                        dth[i][c] += (TREAL)(REAL)(-p->lr) * dupd;
                     }
             }
             /* the interaction points after t updates, for the steps the caller wants to see (trajectory agreement) */

@@ -39,6 +39,13 @@ try:
         got = {s: ctx.value_and_grads(tx, X, Y, strict_nan=s, grid_role=L.GRID_TX if role == "tx" else L.GRID_RX, **kw) for s in (False, True)}
 except Exception as e:  # noqa: BLE001
     print("(no GPU side:", type(e).__name__, ")")
+if got is not None:
+    for s_ in (False, True):
+        gn, on = np.isnan(got[s_]["grad_rx"]).any(-1), np.isnan(grad).any(-1)
+        d = np.argwhere(gn != on)
+        print(f"NaN cells: GPU {'exhaustive' if s_ else 'culled'} {int(gn.sum())}, oracle {int(on.sum())}; differing: {d[:12].tolist()}")
+        for r_, c_ in d[:4]:
+            print(f"    ({r_}, {c_}) = ({X[r_, c_]!r}, {Y[r_, c_]!r}): GPU {got[s_]['grad_rx'][r_, c_]} oracle {grad[r_, c_]} value {value[r_, c_]!r}")
 if got is not None and not cells:
     g = got[strict]["grad_rx"].astype(np.float64)
     rel = 3e-4 if kw["approx"] and kw["function"] == "sigmoid" else 1e-5

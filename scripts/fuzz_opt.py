@@ -69,21 +69,38 @@ def check_case(ctx, case, kinds, xys, phis, fixed, X, Y, kw, min_order, max_orde
         got = ctx.power_map(fixed, X, Y, **gkw)
     stable, v64, scale = cond["stable"], cond["value64"], cond["scale"]
     bar = np.maximum(1e-5 * scale + 1e-5 * np.abs(v64), 2.0 * cond["dist"]) + 1e-30
-    bad = stable & ~(np.abs(got - v64) <= bar)
+    ok = np.abs(got - v64) <= bar
+    # a solver left in Adam's period-2 limit cycle: either of its two points (CO.opt_conditioning, `parity`)
+    ok |= cond["parity"] & (np.abs(got - cond["value32_next"]) <= bar + cond["dist"])
+    bad = stable & ~ok
     if bad.any():
         w = tuple(np.argwhere(bad)[0])
         msgs.append(f"value ({int(bad.sum())} of {int(stable.sum())} stable cells, first {w}: GPU {got[w]!r} oracle64 {v64[w]!r} oracle32 {cond['value32'][w]!r})")
     n_grad = 0
     if with_grad:
-        g64, g32 = cond["grad64"], cond["grad32"]
-        fin = np.isfinite(g64).all(-1) & np.isfinite(g32).all(-1) & stable
+        g64, g32, g32t = cond["grad64"], cond["grad32"], cond["grad32t"]
+        fin = np.isfinite(g64).all(-1) & np.isfinite(g32).all(-1) & stable & ~cond["parity"]
         with np.errstate(invalid="ignore"):
             gs = np.maximum(np.abs(np.nan_to_num(g64)).max(-1), 1e-3 * float(np.nanmax(np.abs(np.where(np.isfinite(g64), g64, 0.0)), initial=0.0)) + 1e-30)[..., None]
             # the gradient through the loop must itself be well conditioned: the oracle's fp32 and fp64 runs within 1e-2 of the cell's scale
             fin &= (np.abs(g32 - g64) <= 1e-2 * gs).all(-1)
-            gbar = np.maximum(1e-5 * gs + 1e-5 * np.abs(g64), 2.0 * np.abs(g32 - g64))
+            # 1e-5 of the cell's gradient scale, or twice what the oracle's own fp32 runs lose (values in fp32; derivatives in fp32 too)
+            gbar = np.maximum(1e-5 * gs + 1e-5 * np.abs(g64), 2.0 * np.maximum(np.abs(g32 - g64), np.nan_to_num(np.abs(g32t - g64))))
             gbad = fin & ~(np.abs(g - g64) <= gbar).all(-1)
         n_grad = int(fin.sum())
+        # offenders: the yardstick of tests/test_gpu_opt.py -- the reference chain's OWN fp32 reverse mode through the loop
+        # (oracle/ref.py under torch) on that cell: within twice ITS distance from fp64
+        if gbad.any() and gbad.sum() <= 8:
+            from oracle import ref as R
+
+            rkw = dict(solver=kw["solver"], steps=kw["steps"], approx=kw["approx"], alpha=kw["alpha"], tol=kw["tol"], patch=kw["patch"], fun=kw["fun"],
+                       grid_role="tx" if role == L.GRID_TX else "rx", **({"function": kw["function"]} if kw["approx"] else {}))
+            for w in np.argwhere(gbad):
+                w = tuple(w)
+                t = {dt: R.opt_value_and_grads(kinds, np.asarray(xys, np.float64), phis, fixed, X[w[0]:w[0] + 1, w[1]:w[1] + 1], Y[w[0]:w[0] + 1, w[1]:w[1] + 1],
+                                               cands, th, dtype=dt, **rkw)["grad_cell"][0, 0] for dt in ("float64", "float32")}
+                if np.isfinite(t["float32"]).all() and (np.abs(g[w] - t["float64"]) <= np.maximum(gbar[w], 2.0 * np.abs(t["float32"] - t["float64"]))).all():
+                    gbad[w] = False
         if gbad.any():
             w = tuple(np.argwhere(gbad)[0])
             msgs.append(f"gradient ({int(gbad.sum())} of {n_grad} cells, first {w}: GPU {g[w]} oracle64 {g64[w]} oracle32 {g32[w]})")
