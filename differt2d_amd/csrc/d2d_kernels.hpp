@@ -1051,14 +1051,19 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                 pby[i] = fbar * pb[2 * i + 1];
             }
         }
-        // path_length
+        // path_length -- for the path functions that go through it: with fun = 1 (or a host-evaluated function, whose own
+        // derivative w.r.t. the points arrives in cust_pb) the reference never evaluates a length, and 0 * (w / |w|) is NaN, not 0,
+        // for a segment vector of exactly (-eps, -eps) (found by scripts/fuzz_parity.py --grad, seed 3 case 168: a transmitter on
+        // the end point of a wall, sigmoid validity, fun = 1 -- false NaN cells in both value+grad kernels since round 1)
+        if (a.fun_id != D2D_FUN_ONE && a.fun_id != D2D_FUN_CUSTOM) {
 #pragma unroll
-        for (int i = 0; i <= K; ++i) {
-            float wx = (px[i + 1] - px[i]) + D2D_EPS, wy = (py[i + 1] - py[i]) + D2D_EPS;
-            float len = sqrtf(wx * wx + wy * wy);
-            float gx = rbar * (wx / len), gy = rbar * (wy / len);
-            pbx[i + 1] += gx; pby[i + 1] += gy;
-            pbx[i] -= gx; pby[i] -= gy;
+            for (int i = 0; i <= K; ++i) {
+                float wx = (px[i + 1] - px[i]) + D2D_EPS, wy = (py[i + 1] - py[i]) + D2D_EPS;
+                float len = sqrtf(wx * wx + wy * wy);
+                float gx = rbar * (wx / len), gy = rbar * (wy / len);
+                pbx[i + 1] += gx; pby[i + 1] += gy;
+                pbx[i] -= gx; pby[i] -= gy;
+            }
         }
         // adjoints of the candidate's walls: origin, normal, direction t (the latter through on_objects only)
         constexpr int KK = (K > 0) ? K : 1;

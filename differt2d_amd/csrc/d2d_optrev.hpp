@@ -385,15 +385,18 @@ __device__ __forceinline__ float opt_rev_candidate(const OptRevArgs& ra, int c, 
     } else if (s.fun_id == D2D_FUN_LENGTH_SQUARED) rbar = fbar * (2.0f * r);
     else if (s.fun_id == D2D_FUN_LENGTH) rbar = fbar;
     else rbar = 0.0f;
+    // (fun = 1 never evaluates a length: 0 * (w / |w|) would be NaN, not 0, for a segment vector of exactly (-eps, -eps))
+    if (s.fun_id == D2D_FUN_RECEIVED_POWER || s.fun_id == D2D_FUN_LENGTH_SQUARED || s.fun_id == D2D_FUN_LENGTH) {
 #pragma unroll
-    for (int i = 0; i <= K; ++i) {  // path_length, geometry.py:176-203
-        const float wx = (px[i + 1] - px[i]) + D2D_EPS, wy = (py[i + 1] - py[i]) + D2D_EPS;
-        const float len = sqrtf(wx * wx + wy * wy);
-        const float gx = rbar * (wx / len), gy = rbar * (wy / len);
-        pbx[i + 1] += gx;
-        pby[i + 1] += gy;
-        pbx[i] -= gx;
-        pby[i] -= gy;
+        for (int i = 0; i <= K; ++i) {  // path_length, geometry.py:176-203
+            const float wx = (px[i + 1] - px[i]) + D2D_EPS, wy = (py[i + 1] - py[i]) + D2D_EPS;
+            const float len = sqrtf(wx * wx + wy * wy);
+            const float gx = rbar * (wx / len), gy = rbar * (wy / len);
+            pbx[i + 1] += gx;
+            pby[i + 1] += gy;
+            pbx[i] -= gx;
+            pby[i] -= gy;
+        }
     }
     float lossbar = 0.0f;
     if (s.mode != MODE_HARD) {

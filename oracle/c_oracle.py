@@ -315,8 +315,8 @@ def opt_conditioning(kinds, xys, phis, fixed, X, Y, cands, theta0s, steps, tol_p
     implementation of the same derivative differs by) -- interaction points within ``tol_pts`` after 30, 100, 300 and all
     ``steps`` iterations -- and all the values agree to ``tol_val`` of the map's scale.  Returns dict(value32, value64, stable, dist) with ``dist``
     the largest distance of an fp32 run's value from the fp64 one (the bar no fp32 evaluation can be held below); with_grad
-    also grad32 / grad64 (per-cell gradients of the plain fp32 and fp64 runs) and grad32t (the fp32 run with its derivative
-    arithmetic in fp32 too)."""
+    also grad32 / grad64 (per-cell gradients of the plain fp32 and fp64 runs), grad32t (the fp32 run with its derivative
+    arithmetic in fp32 too) and grad32n (the fp32 run from a cell one ulp away)."""
     F = np.float32
     up = lambda a: np.nextafter(np.asarray(a, F), F(np.inf)).astype(F)  # noqa: E731
     X, Y, fixed = np.asarray(X, F), np.asarray(Y, F), np.asarray(fixed, F)
@@ -332,7 +332,9 @@ def opt_conditioning(kinds, xys, phis, fixed, X, Y, cands, theta0s, steps, tol_p
     dist = np.zeros(X.shape)
     for i, (f_, X_, Y_, th_, gu) in enumerate(variants):
         r32 = opt_power_map(kinds, xys, phis, f_, X_, Y_, cands, th_, dtype="float32", with_paths=True, steps=steps, snaps=snaps,
-                            grad=with_grad and i == 0, g_ulps=gu, **kw)
+                            grad=with_grad and i <= 1, g_ulps=gu, **kw)
+        if with_grad and i == 1:
+            out["grad32n"] = r32[1]  # (the cell one ulp away: how far one input ulp moves the derivative through the loop)
         if len(cands):
             with np.errstate(invalid="ignore"):
                 stable &= np.abs(r32[-2] - p64).max(axis=(-1, -2, -3, -4)) <= tol_pts

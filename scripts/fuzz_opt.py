@@ -78,28 +78,34 @@ def check_case(ctx, case, kinds, xys, phis, fixed, X, Y, kw, min_order, max_orde
         msgs.append(f"value ({int(bad.sum())} of {int(stable.sum())} stable cells, first {w}: GPU {got[w]!r} oracle64 {v64[w]!r} oracle32 {cond['value32'][w]!r})")
     n_grad = 0
     if with_grad:
-        g64, g32, g32t = cond["grad64"], cond["grad32"], cond["grad32t"]
-        fin = np.isfinite(g64).all(-1) & np.isfinite(g32).all(-1) & stable & ~cond["parity"]
+        g64, g32, g32t, g32n = cond["grad64"], cond["grad32"], cond["grad32t"], cond["grad32n"]
+        fin = np.isfinite(g64).all(-1) & np.isfinite(g32).all(-1) & np.isfinite(g32n).all(-1) & stable & ~cond["parity"]
         with np.errstate(invalid="ignore"):
-            gs = np.maximum(np.abs(np.nan_to_num(g64)).max(-1), 1e-3 * float(np.nanmax(np.abs(np.where(np.isfinite(g64), g64, 0.0)), initial=0.0)) + 1e-30)[..., None]
-            # the gradient through the loop must itself be well conditioned: the oracle's fp32 and fp64 runs within 1e-2 of the cell's scale
-            fin &= (np.abs(g32 - g64) <= 1e-2 * gs).all(-1)
-            # 1e-5 of the cell's gradient scale, or twice what the oracle's own fp32 runs lose (values in fp32; derivatives in fp32 too)
-            gbar = np.maximum(1e-5 * gs + 1e-5 * np.abs(g64), 2.0 * np.maximum(np.abs(g32 - g64), np.nan_to_num(np.abs(g32t - g64))))
+            # a cell's gradient scale: its own largest component, at least 1e-2 of the map's (contributions of opposite sign cancel)
+            gs = np.maximum(np.abs(np.nan_to_num(g64)).max(-1), 1e-2 * float(np.nanmax(np.abs(np.where(np.isfinite(g64), g64, 0.0)), initial=0.0)) + 1e-30)[..., None]
+            # the gradient through the loop must itself be well conditioned: the oracle's fp32 run, and its fp32 run from a cell one
+            # ulp away, within 1e-2 of the cell's scale of its fp64 run
+            fin &= (np.abs(g32 - g64) <= 1e-2 * gs).all(-1) & (np.abs(g32n - g64) <= 1e-2 * gs).all(-1)
+            # 3e-5 of the cell's gradient scale (fp32 reverse mode through up to 250 sequential Adam steps: the reference chain's own
+            # fp32 reverse mode sits 1 .. 4e-5 from its fp64 one in these cases, scripts/fuzz_opt_case.py), or twice what the oracle's
+            # own fp32 runs lose (values in fp32; derivatives in fp32 too; one input ulp)
+            gbar = np.maximum(3e-5 * gs + 1e-5 * np.abs(g64), 2.0 * np.maximum(np.maximum(np.abs(g32 - g64), np.nan_to_num(np.abs(g32t - g64))), np.abs(g32n - g64)))
             gbad = fin & ~(np.abs(g - g64) <= gbar).all(-1)
         n_grad = int(fin.sum())
         # offenders: the yardstick of tests/test_gpu_opt.py -- the reference chain's OWN fp32 reverse mode through the loop
         # (oracle/ref.py under torch) on that cell: within twice ITS distance from fp64
-        if gbad.any() and gbad.sum() <= 8:
+        if gbad.any() and gbad.sum() <= 32:
             from oracle import ref as R
 
             rkw = dict(solver=kw["solver"], steps=kw["steps"], approx=kw["approx"], alpha=kw["alpha"], tol=kw["tol"], patch=kw["patch"], fun=kw["fun"],
                        grid_role="tx" if role == L.GRID_TX else "rx", **({"function": kw["function"]} if kw["approx"] else {}))
-            for w in np.argwhere(gbad):
-                w = tuple(w)
-                t = {dt: R.opt_value_and_grads(kinds, np.asarray(xys, np.float64), phis, fixed, X[w[0]:w[0] + 1, w[1]:w[1] + 1], Y[w[0]:w[0] + 1, w[1]:w[1] + 1],
-                                               cands, th, dtype=dt, **rkw)["grad_cell"][0, 0] for dt in ("float64", "float32")}
-                if np.isfinite(t["float32"]).all() and (np.abs(g[w] - t["float64"]) <= np.maximum(gbar[w], 2.0 * np.abs(t["float32"] - t["float64"]))).all():
+            wb = np.argwhere(gbad)
+            print(f"  .. case {case}: {len(wb)} cells to the reverse-mode yardstick", flush=True)
+            Xc, Yc = X[wb[:, 0], wb[:, 1]][None], Y[wb[:, 0], wb[:, 1]][None]  # (one batched call per precision)
+            t = {dt: R.opt_value_and_grads(kinds, np.asarray(xys, np.float64), phis, fixed, Xc, Yc, cands, th, dtype=dt, **rkw)["grad_cell"][0]
+                 for dt in ("float64", "float32")}
+            for i, w in enumerate(map(tuple, wb)):
+                if np.isfinite(t["float32"][i]).all() and (np.abs(g[w] - t["float64"][i]) <= np.maximum(gbar[w], 2.0 * np.abs(t["float32"][i] - t["float64"][i]))).all():
                     gbad[w] = False
         if gbad.any():
             w = tuple(np.argwhere(gbad)[0])

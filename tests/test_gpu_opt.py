@@ -669,25 +669,33 @@ def test_cfg5_full_map_against_the_c_oracle():
     # per-cell gradients on every tenth row
     rows = np.arange(5, 300, 10)
     cg = CO.opt_conditioning(kind, xys, phi, tx, X[rows], Y[rows], cands, th, steps, solver="min", approx=True, with_grad=True)
-    g, g64, g32, g32t = full["grad_rx"][rows].astype(np.float64), cg["grad64"], cg["grad32"], cg["grad32t"]
-    fin = np.isfinite(g64).all(-1) & np.isfinite(g32).all(-1) & cg["stable"] & ~cg["parity"]
+    g, g64, g32, g32t, g32n = full["grad_rx"][rows].astype(np.float64), cg["grad64"], cg["grad32"], cg["grad32t"], cg["grad32n"]
+    fin = np.isfinite(g64).all(-1) & np.isfinite(g32).all(-1) & np.isfinite(g32n).all(-1) & cg["stable"] & ~cg["parity"]
     gs = np.maximum(np.abs(np.nan_to_num(g64)).max(-1), np.median(np.abs(g64[fin]).max(-1)))[..., None]
     with np.errstate(invalid="ignore"):
-        fin &= (np.abs(g32 - g64) <= 1e-2 * gs).all(-1)  # (the derivative through 1000 steps itself well conditioned)
-        # the yardstick: what the oracle's own fp32 runs lose against fp64 -- values in fp32, and derivatives in fp32 too
-        gerr, gref = np.abs(g - g64) / gs, np.maximum(np.abs(g32 - g64), np.nan_to_num(np.abs(g32t - g64))) / gs
+        # (the derivative through 1000 steps itself well conditioned: the oracle's fp32 run, and its fp32 run from a cell one ulp
+        # away, within 1e-2 of the cell's scale of its fp64 run -- the rule of scripts/make_golden_cfg5.py)
+        fin &= (np.abs(g32 - g64) <= 1e-2 * gs).all(-1) & (np.abs(g32n - g64) <= 1e-2 * gs).all(-1)
+        # the yardstick: what the oracle's own fp32 runs lose against fp64 -- values in fp32, derivatives in fp32 too, one input ulp
+        gerr = np.abs(g - g64) / gs
+        gref = np.maximum(np.maximum(np.abs(g32 - g64), np.nan_to_num(np.abs(g32t - g64))), np.abs(g32n - g64)) / gs
         bad = fin & ~(gerr <= np.maximum(1e-5, 2.0 * gref)).all(-1)
     # offenders (a handful): the yardstick of the fixture tests above -- the reference chain's own fp32 REVERSE mode through all
     # 1000 steps (oracle/ref.py under torch), that cell alone: within twice its distance from fp64
     n_lazy = int(bad.sum())
-    assert n_lazy <= 24, f"{n_lazy} cells beyond max(1e-5, 2 x the oracle's fp32 error)"
-    for w in np.argwhere(bad):
-        w = tuple(w)
-        Xc, Yc = X[rows[w[0]]:rows[w[0]] + 1, w[1]:w[1] + 1], Y[rows[w[0]]:rows[w[0]] + 1, w[1]:w[1] + 1]
+    assert n_lazy <= 64, f"{n_lazy} cells beyond max(1e-5, 2 x the oracle's fp32 error)"
+    if n_lazy:
+        wb = np.argwhere(bad)
+        Xc, Yc = X[rows[wb[:, 0]], wb[:, 1]][None], Y[rows[wb[:, 0]], wb[:, 1]][None]  # (one batched call per precision: ~30 s)
         t = {dt: R.opt_value_and_grads(kind, np.asarray(xys, np.float64), phi, tx, Xc, Yc, cands, th, solver="min", steps=steps, dtype=dt,
-                                       approx=True)["grad_cell"][0, 0] for dt in ("float64", "float32")}
-        if np.isfinite(t["float32"]).all() and (np.abs(g[w] - t["float64"]) / gs[w] <= np.maximum(1e-5, 2.0 * np.abs(t["float32"] - t["float64"]) / gs[w])).all():
-            bad[w] = False
+                                       approx=True)["grad_cell"][0] for dt in ("float64", "float32")}
+        detail = []
+        for i, w in enumerate(map(tuple, wb)):
+            if np.isfinite(t["float32"][i]).all() and (np.abs(g[w] - t["float64"][i]) / gs[w] <= np.maximum(1e-5, 2.0 * np.abs(t["float32"][i] - t["float64"][i]) / gs[w])).all():
+                bad[w] = False
+            else:
+                detail.append((w, g[w].tolist(), t["float64"][i].tolist(), t["float32"][i].tolist()))
+        print("   reverse-mode yardstick, cells still beyond (cell, GPU, fp64 reverse mode, fp32 reverse mode):", detail[:12])
     print(f"cfg5, per-cell gradients on {rows.size} rows: {int(fin.sum())} of {fin.size} cells compared; max err / cell scale "
           f"{float(gerr[fin].max()):.2e} (the oracle's fp32 vs fp64: {float(gref[fin].max()):.2e}); {n_lazy} cells went to the reverse-mode "
           f"yardstick; oracle {time.time() - t1:.0f} s")
