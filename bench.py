@@ -155,13 +155,13 @@ def committed_traffic(approx):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        kib = float(d["FETCH_SIZE"]) + float(d["WRITE_SIZE"])
+        val = lambda k: float(d[k]["mean_per_dispatch"] if isinstance(d[k], dict) else d[k])  # noqa: E731
+        fetch, write = val("FETCH_SIZE"), val("WRITE_SIZE")
     except (OSError, ValueError, KeyError, TypeError):
         return None, None
-    return kib * 1024.0, (f"profiles/{os.path.basename(files[-1])}: FETCH_SIZE {float(d['FETCH_SIZE']):.0f} KiB + WRITE_SIZE "
-                          f"{float(d['WRITE_SIZE']):.0f} KiB per dispatch as counted (4-byte-per-lane loads; the guide's x2 FETCH "
-                          f"correction, calibrated on 16-B streaming reads, would make it {(2 * float(d['FETCH_SIZE']) + float(d['WRITE_SIZE'])) * 1024 / 1e6:.1f} MB), "
-                          f"kernel {d.get('_meta', {}).get('kernel', '?')}")
+    return (fetch + write) * 1024.0, (f"profiles/{os.path.basename(files[-1])}: FETCH_SIZE {fetch:.0f} KiB + WRITE_SIZE {write:.0f} KiB per dispatch "
+                                      f"as counted (4-byte-per-lane loads; the guide's x2 FETCH correction, calibrated on 16-B streaming reads, "
+                                      f"would make it {(2 * fetch + write) * 1024 / 1e6:.1f} MB), kernel {d.get('_meta', {}).get('kernel', '?')}")
 
 
 def row_crcs(a):
