@@ -6,7 +6,7 @@ through the Adam loop -- orders 1..2 (order 3 in small scenes), both solvers, al
 Sequential fp32 Adam steps are not reproducible to the last bit between two gradient implementations and chaotic where a
 solve has not settled, so cells are compared where the ORACLE ALONE calls the sweep well conditioned (CO.opt_conditioning:
 every candidate's trajectory agrees between its fp64 run, its fp32 run and fp32 runs from inputs one ulp away); there the GPU
-sits within 1e-5 of the map's scale (+ 1e-5 relative) of the fp64 oracle, or within twice the oracle's own fp32 distance.
+sits within 1e-5 of the map's scale (+ 1e-5 relative) of the fp64 oracle, or within four times the oracle's own fp32 distance.
 
 usage: python scripts/fuzz_opt.py [n_cases] [seed]"""
 
@@ -68,7 +68,9 @@ def check_case(ctx, case, kinds, xys, phis, fixed, X, Y, kw, min_order, max_orde
     else:
         got = ctx.power_map(fixed, X, Y, **gkw)
     stable, v64, scale = cond["stable"], cond["value64"], cond["scale"]
-    bar = np.maximum(1e-5 * scale + 1e-5 * np.abs(v64), 2.0 * cond["dist"]) + 1e-30
+    # (four times the oracle's own fp32-to-fp64 distance: a cell that amplifies rounding a hundredfold does so for every fp32
+    # evaluation, and by a factor that varies from one evaluation order to the next)
+    bar = np.maximum(1e-5 * scale + 1e-5 * np.abs(v64), 4.0 * cond["dist"]) + 1e-30
     ok = np.abs(got - v64) <= bar
     # a solver left in Adam's period-2 limit cycle: either of its two points (CO.opt_conditioning, `parity`)
     ok |= cond["parity"] & (np.abs(got - cond["value32_next"]) <= bar + cond["dist"])

@@ -88,7 +88,9 @@ def test_cfg2_full_map_against_live_oracle(ctx, mode):
     from oracle import c_oracle as CO
 
     tx, walls, X, Y = _workload()
-    want_p, want_c = CO.power_and_count_maps(walls, tx, X, Y, min_order=0, max_order=2, prune=True, **MODES[mode])
+    # (prune = 2: the oracle's exact per-cell shortcuts, held to the plain evaluation by tests/test_oracle_c.py -- and, here, to
+    # the committed CRCs of the map the plain evaluation produced)
+    want_p, want_c = CO.power_and_count_maps(walls, tx, X, Y, min_order=0, max_order=2, prune=2, **MODES[mode])
     gold = np.load(GOLD)
     assert np.array_equal(_row_crcs(want_p), gold[f"rx_{mode}_power_crc"]), "the oracle built here disagrees with the fixture"
     assert np.array_equal(_row_crcs(want_c), gold[f"rx_{mode}_count_crc"])
@@ -116,7 +118,7 @@ def test_cfg2_sigmoid_full_map_properties(ctx):
     got = ctx.power_map(tx, X, Y, min_order=0, max_order=2, approx=True, function="sigmoid")
     assert np.isfinite(got).all() and (got >= 0).all()
     rows = np.linspace(0, 1023, 64).astype(int)
-    want = CO.power_map(walls, tx, X[rows], Y[rows], min_order=0, max_order=2, prune=True, approx=True, function="sigmoid")
+    want = CO.power_map(walls, tx, X[rows], Y[rows], min_order=0, max_order=2, prune=2, approx=True, function="sigmoid")
     np.testing.assert_allclose(got[rows], want, rtol=1e-6, atol=1e-9)
     same = got[rows] == want
     print(f"   sigmoid, 65 536 cells: {int((~same).sum())} differ in some bit, max rel {np.max(np.abs(got[rows] - want) / np.maximum(np.abs(want), 1e-30)):.2e}")
