@@ -11,7 +11,7 @@ from differt2d_amd.engine import Context
 from oracle import c_oracle as CO
 F = np.float32
 role, mode = sys.argv[1], sys.argv[2]
-kw = dict(approx=False) if mode == "hard" else dict(approx=True, function="hard_sigmoid")
+kw = {"hard": dict(approx=False), "hsig": dict(approx=True, function="hard_sigmoid"), "sigmoid": dict(approx=True, function="sigmoid")}[mode]
 tx, walls = random_scene(50, seed=1234)
 x = np.linspace(0.0, 1.0, 1024).astype(F)
 X, Y = np.meshgrid(x, x)
@@ -32,6 +32,7 @@ rowscale = np.nanmax(np.abs(grad), axis=(1, 2), keepdims=True)
 bar = 1e-5 * gabs[..., None] + 1e-5 * np.abs(grad) + 1e-6 * rowscale
 r = np.where(fin, err / bar, 0.0)
 bad = np.argwhere(r.max(-1) > 1)
+print(f"{role} {mode}: {rows.size} rows, {int(np.isnan(grad).any(-1).sum())} NaN cells, {int((gabs > 0).sum())} cells with a path")
 print(len(bad), "cells beyond the bar; worst", r.max(), "; kink cells among them", int(kink[tuple(bad.T)].sum()) if len(bad) else 0)
 for b in bad[:12]:
     b = tuple(b)
