@@ -256,6 +256,7 @@ struct d2d_ctx {
     long long rl_meta_static = 0, rl_meta_chunks = 0;  // n_static / max_chunks of the last launch that built lists
     long long pend_static = 0, pend_chunks = 0;        // ... of the launch the pending h_meta read-back describes
     long long fb_hint = 0;             // patches the last such launch left to the enumerating kernel
+    float rl_vkey[6] = {-1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // validity parameters of the last launch with lists
     long long rl_launches = 0;         // launches with lists since the plan last changed (the read-back thins out: 1, 2, 3, then every 16th)
     DevBuf<unsigned long long> d_rl_pool;
     DevBuf<float4> d_rl_box;           // bounding boxes of the leaf regions, then of the top regions (region_box_kernel)
@@ -1501,7 +1502,13 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             a.rl = c->d_rl.p;
             c->rl_plan = rp;
             c->rl_max_order = p->max_order;
-            c->rl_launches = (c->rl_meta_static == rp.n_static && c->rl_meta_chunks == rp.max_chunks) ? c->rl_launches + 1 : 1;
+            // (the lists' lengths follow the validity parameters as much as the plan: a context that goes from hard to hard_sigmoid
+            // validity on the same grid -- bench.py's configs[3] legs -- must look at its first launches again: without this the
+            // overflow of the hard_sigmoid lists was noticed sixteen launches late, each of them seconds long)
+            const float vkey[6] = {(float)mode, p->alpha, p->tol, p->patch, p->seg_tol, (float)(p->min_order * 16 + p->max_order)};
+            const bool same_params = std::memcmp(vkey, c->rl_vkey, sizeof vkey) == 0;
+            std::memcpy(c->rl_vkey, vkey, sizeof vkey);
+            c->rl_launches = (same_params && c->rl_meta_static == rp.n_static && c->rl_meta_chunks == rp.max_chunks) ? c->rl_launches + 1 : 1;
             c->rl_meta_static = rp.n_static;
             c->rl_meta_chunks = rp.max_chunks;
             {
