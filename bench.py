@@ -333,7 +333,7 @@ def cfg5_leg(ctx, timed, steps=1000, n=5):
     scene = Scene.square_scene()
     ris = RIS(xys=[[0.5, 0.3], [0.5, 0.7]], phi=np.pi / 4)
     scene = scene.add_objects(ris, *ris.get_vertices())
-    X, Y = scene.grid(n=300)
+    X, Y = scene.grid(300, 300)  # (the reference's scene.grid(n=300) is 50 x 300 cells: BASELINE.json's configs[4] says 300 x 300)
     tx = scene.transmitters["tx"].xy
     cands = scene.all_path_candidates(order=1)
     rng = np.random.default_rng(1234)

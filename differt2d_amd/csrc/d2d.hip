@@ -246,6 +246,7 @@ struct d2d_ctx {
     long long region_slices = 0;       // slices of first walls per enumerated region (0: chosen from the number of allowed walls)
     long long region_budget_mb = 24576; // device memory all list pools together may grow to (one pool per rotating set)
     long long rl_pool_mb = 256;        // its current size: quadrupled (up to the budget) after a launch whose lists did not fit
+    bool rl_pool_by_option = false;    // "region_budget_mb" was set by the caller: no automatic first size
     hipStream_t aux_stream = nullptr;  // the patch schedule's sort runs here, beside the shadow masks and the region lists
     hipStream_t sort_stream = nullptr; // .. and here when aux_stream carries the whole preparation (pipeline)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -1382,6 +1383,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             if ((long long)c->h_meta[1] + c->pend_static > c->pend_chunks && c->rl_pool_mb < pool_cap_mb)
                 c->rl_pool_mb = std::min(pool_cap_mb, c->rl_pool_mb * 4);  // the pool ran out: a bigger one from now on
         }
+        // third-order lists over a big scene start with 1 GB per set: configs[3]'s hard_sigmoid lists are 577 MB, and the ONE launch
+        // that finds a 256 MB pool too small takes 8.7 s instead of 0.04 (its patches enumerate) -- 288 GB of HBM are there to be used
+        if (!c->rl_pool_by_option && p->max_order >= 3 && c->cw.size() >= 64 && c->rl_pool_mb < 1024) c->rl_pool_mb = 1024;
         if (c->rl_pool_mb > pool_cap_mb) c->rl_pool_mb = pool_cap_mb;
         d2d_host::RegionPlan rp =
             d2d_host::region_plan(tiles_x, tiles_y, (long long)c->cw.size(), p->min_order, p->max_order, (int)c->region_size,
@@ -2069,6 +2073,7 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
         if (value < 1 || value > (256ll << 10)) return fail(D2D_ERR_INVALID, "region_budget_mb must lie in 1..262144, got %lld", (long long)value);
         c->region_budget_mb = value;
         c->rl_pool_mb = std::min<long long>(256, value);
+        c->rl_pool_by_option = true;
     }
     else return fail(D2D_ERR_INVALID, "d2d_set_option: unknown option '%s'", name);
     return D2D_OK;
