@@ -203,7 +203,6 @@ struct WaveStats {
     // kernel that already parks scalars in VGPR lanes; one wave never counts past 2^32)
     unsigned c[16];  // [9] tile-culling levels evaluated; [10..15] shader-clock ticks per phase (diagnostic)
     int shadow;                // wave state, not a counter: the wall that occluded the wave's previous candidate
-    int shadow1 = -1, shadow2 = -1;  // D2D_SHADOW_LRU: the two walls that ended loops before that one (most recent first)
     unsigned work;             // every build: work done for this patch in units of ~25 wave-instructions (feeds the schedule)
 };
 
@@ -223,9 +222,6 @@ __device__ __forceinline__ int late_index(int i) {
 }
 
 // counter I += x in a vector register (see WaveStats)
-#ifndef D2D_SHADOW_LRU
-#define D2D_SHADOW_LRU 0  // A/B: the single-wall loop (sigmoid validity) tries the last THREE walls that ended a loop first
-#endif
 #ifndef D2D_WALL_PAIRS_MODES
 #define D2D_WALL_PAIRS_MODES 3  // bit m: validity mode m takes two walls per trip (A/B)
 #endif
@@ -836,127 +832,6 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                 wA = wnA;
                 wB = wnB;
             }
-        }
-    }
-    } else if constexpr (D2D_SHADOW_LRU != 0) {
-    // One wall per trip, and the walls that ended the loops of the wave's last THREE candidates first (most recent first): with
-    // sigmoid validity a loop only ends once EVERY lane has met an occluder saturated beyond 17.5, different lanes meet different
-    // ones, and one remembered wall settles far fewer candidates than it does in hard mode (76 of 150 tests per candidate at cfg2).
-    auto one_wall = [&](const float4& ww, int jw) -> bool {  // true: every lane is decided
-        // The K + 1 segments against this wall: first the divide-free filter of all of them (pure vector work, no branch:
-        // a segment that ends on this very wall is computed and masked, that is rarer than a branch is dear), then ONE
-        // wave-level decision whether any lane needs an exact test at all (9 % of the tests at cfg2), and only then the
-        // segments that do, one by one.
-        float fa_[K + 1], fb_[K + 1], fd_[K + 1];
-        unsigned wbits = 0u;  // bit i: this lane needs the exact test of segment i
-#pragma unroll
-        for (int i = 0; i <= K; ++i) {
-            const int ig0 = (i == 0) ? -1 : cand[i - 1];
-            const int ig1 = (i == K) ? -1 : cand[i];
-            const bool skip = (jw == ig0 || jw == ig1);  // wave-uniform: a segment ignores the walls it joins
-            float Cx = ww.x - px[i], Cy = ww.y - py[i];
-            float fa = by[i] * Cx - bx[i] * Cy;   // geometry.py:157
-            float fb = ww.z * Cy - ww.w * Cx;     // geometry.py:158
-            float fd = ww.w * bx[i] - ww.z * by[i]; // geometry.py:159
-            // divide-free filter: t = fl(num/fd) certainly outside [flt_lo, flt_hi]?  num/fd lies outside iff
-            // (num - lo fd)(num - hi fd) > 0, whatever the sign of fd; each factor is one fma, so its sign is the exact
-            // difference's, and a product that underflows to 0 (tiny fd, or a numerator on a window edge) counts as "not
-            // certainly outside": the exact test decides.  One compare per segment instead of six and their mask algebra.
-            float pa = __builtin_fmaf(-a.flt_lo, fd, fa) * __builtin_fmaf(-a.flt_hi, fd, fa);
-            float pb = __builtin_fmaf(-a.flt_lo, fd, fb) * __builtin_fmaf(-a.flt_hi, fd, fb);
-            bool miss = fmaxf(pa, pb) > 0.0f;
-            if (MODE == MODE_SIG && !skip) any_test = true;
-            // (branch-free on purpose: as `if (STATS && !skip) ++count` -- a branch with a side effect between the filter's compare
-            // and its use -- the instrumented kernel's maps differed from the product kernel's at shadow boundaries, 0.5 % of the
-            // cells at cfg2, from round 1 on; found in round 4, scripts/stats_cmp.py and tests/test_gpu_forward.py hold them equal)
-            if (STATS) stat_add<4>(st, skip ? 0 : 1);
-            wbits |= (!skip && active && (!miss || bad)) ? (1u << i) : 0u;
-            fa_[i] = fa;
-            fb_[i] = fb;
-            fd_[i] = fd;
-        }
-        D2D_WORK(K + 1);
-        if (wave_any(wbits != 0u)) {
-#pragma unroll
-            for (int i = 0; i <= K; ++i) {
-                if (!wave_any((wbits >> i) & 1u)) continue;
-                if (STATS) stat_add<5>(st, 1);
-                D2D_WORK(2);
-                const float fa = fa_[i], fb = fb_[i], fd = fd_[i];
-                // exact path, geometry.py:163-171
-                bool dz = (fd == 0.0f);
-                float dd = dz ? 1.0f : fd;
-                float ta, tb;
-                div2_exact(fa, fb, dd, ta, tb);
-                ta = dz ? __builtin_inff() : ta;
-                tb = dz ? __builtin_inff() : tb;
-                if (MODE == MODE_HARD) {
-                    bool h = (ta >= a.seg_lo) && (ta <= a.seg_hi) && (tb >= a.seg_lo) && (tb <= a.seg_hi);
-                    hit_b = hit_b || h;
-                } else if (MODE == MODE_HSIG) {
-                    nanflag = nanflag || (ta != ta) || (tb != tb);
-                    float c = fminf(fminf(clampact(ta - a.seg_lo, a.alpha), clampact(a.seg_hi - ta, a.alpha)),
-                                    fminf(clampact(tb - a.seg_lo, a.alpha), clampact(a.seg_hi - tb, a.alpha)));
-                    // arg-max as the reference's ascending (j, i) scan finds it: the first of equal maxima
-                    if (GRAD && (c > hit_c || (c == hit_c && hit_j >= 0 && (jw < hit_j || (jw == hit_j && i < hit_i))))) {
-                        hit_i = i;
-                        hit_j = jw;
-                    }
-                    if (GRAD) hit2 = (c > hit_c) ? hit_c : fmaxf(hit2, c);
-                    hit_c = fmaxf(hit_c, c);
-                } else {
-                    nanflag = nanflag || (ta != ta) || (tb != tb);
-                    float z = fminf(fminf(a.alpha * (ta - a.seg_lo), a.alpha * (a.seg_hi - ta)),
-                                    fminf(a.alpha * (tb - a.seg_lo), a.alpha * (a.seg_hi - tb)));
-                    if (GRAD && (z > hit_z || (z == hit_z && hit_j >= 0 && (jw < hit_j || (jw == hit_j && i < hit_i))))) {
-                        hit_i = i;
-                        hit_j = jw;
-                    }
-                    if (GRAD) hit2 = (z > hit_z) ? hit_z : fmaxf(hit2, z);
-                    hit_z = fmaxf(hit_z, z);
-                }
-            }
-            // decided lanes: occlusion already makes valid exactly 0 (only an exact test can change that: a wall whose
-            // filters settle every lane costs one wave-level decision, not two)
-            if (MODE == MODE_HARD) active = active && (!hit_b || bad);
-            else if (MODE == MODE_HSIG) active = active && (hit_c != 6.0f || bad);
-            else active = active && (hit_z < 17.5f || bad);
-            if (!wave_any(active)) return true;
-        }
-        return false;
-    };
-    auto remember = [&](int jw) {
-        if (jw != st.shadow) {
-            if (jw != st.shadow1) st.shadow2 = st.shadow1;
-            st.shadow1 = st.shadow;
-            st.shadow = jw;
-        }
-    };
-    const int c1 = (st.shadow1 >= 0 && st.shadow1 < a.N && st.shadow1 != sh) ? st.shadow1 : -1;
-    const int c2 = (st.shadow2 >= 0 && st.shadow2 < a.N && st.shadow2 != sh && st.shadow2 != c1) ? st.shadow2 : -1;
-    bool done = a.N <= 0;
-    if (!done && sh >= 0) {
-        const float4 w1 = ldc4(a.occl, c1 >= 0 ? c1 : sh), w2 = ldc4(a.occl, c2 >= 0 ? c2 : sh);
-        if (one_wall(w, sh)) { done = true; }
-        else if (c1 >= 0 && one_wall(w1, c1)) { remember(c1); done = true; }
-        else if (c2 >= 0 && one_wall(w2, c2)) { remember(c2); done = true; }
-    }
-    if (!done) {
-        auto skip = [&](int x) -> int {
-            while (x == sh || x == c1 || x == c2) ++x;
-            return x;
-        };
-        int jj = skip(0);
-        float4 wj = (sh >= 0) ? ldc4(a.occl, jj < a.N ? jj : 0) : w;  // (w holds wall 0 when nothing is remembered)
-        while (jj < a.N) {
-            const int nx = skip(jj + 1);
-            const float4 wn = ldc4(a.occl, nx < a.N ? nx : jj);  // (the next wall's load flies while this one is tested)
-            if (one_wall(wj, jj)) {
-                remember(jj);
-                break;
-            }
-            jj = nx;
-            wj = wn;
         }
     }
     } else {
