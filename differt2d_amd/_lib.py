@@ -1,5 +1,5 @@
 """
-ctypes binding of libd2d.so (C ABI: include/d2d.h).  No torch, no JAX, no CPU fallback:
+ctypes binding of libd2d.so (C ABI: include/d2d.h).  No PyTorch, no JAX, no CPU fallback:
 if the HIP library is missing or no MI355X is visible, every compute call raises.
 """
 

@@ -11,7 +11,7 @@ is ``fun`` itself and its derivative w.r.t. the path's points, per (candidate, c
   (arithmetic operators, ``path.length()``, NumPy ufuncs and the common NumPy functions: ``np.sqrt``, ``np.sum``,
   ``np.where``, ``np.linalg.norm`` ..., indexing, array methods) -- and the derivative is read off that record in reverse
   order with JAX's conventions (``minimum`` / ``maximum`` split a tie evenly, ``abs'(0) = 0``, ``sqrt'(0) = inf``, ``where``
-  passes nothing to the branch not taken).  A few dozen lines of NumPy: no torch, no JAX, nothing imported on demand; it
+  passes nothing to the branch not taken).  A few dozen lines of NumPy: no PyTorch, no JAX, nothing imported on demand; it
   sees the user's function only, batched over (cells) once per candidate.  An operation the record does not know raises,
   and the sweep is refused (``D2DUnsupported``) rather than differentiated wrongly.
 """

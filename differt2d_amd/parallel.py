@@ -15,9 +15,9 @@ than assembling the final map:
 
 Data plane AND barrier / max-over-ranks: RCCL directly on the library's device buffers (``d2d_comm_*``, xGMI on
 an MI355X node).  Rendezvous (shipping the 128-byte unique id): a file in /tmp (:func:`file_rendezvous`), so the
-GPU processes import no torch -- torch bundles its own libamdhip64 / librccl under the system ROCm's SONAMEs and
-must stay out of a process that drives the system RCCL.  (The CPU tests of the partition logic move host arrays through
-``torch.distributed``/gloo instead: ``tests/gloo_comm.py``, test infrastructure, not part of this package.)
+GPU processes import no deep-learning framework -- PyTorch bundles its own libamdhip64 / librccl under the system ROCm's SONAMEs
+and must stay out of a process that drives the system RCCL.  (The CPU tests of the partition logic move host arrays through a
+gloo process group instead: ``tests/gloo_comm.py``, test infrastructure, not part of this package.)
 """
 
 from __future__ import annotations
@@ -84,10 +84,10 @@ class RowShards:
 
 def file_rendezvous(rank: int, world: int, make_id: Callable[[], bytes], timeout: float = 300.0) -> bytes:
     """Ships rank 0's 128-byte RCCL unique id to the other ranks of ONE node through a directory in /tmp, so that
-    the GPU processes need no torch / MPI at run time (torch.distributed.run is only the launcher).
+    the GPU processes need no PyTorch / MPI at run time (PyTorch's distributed launcher, if used at all, only starts the ranks).
 
     The directory is ``$D2D_RDZV_DIR`` or ``/tmp/d2d_rdzv_<MASTER_PORT>_<parent pid>`` (all workers of one
-    torchrun agent share the parent pid).  Rank 0 writes ``id.bin`` atomically; it removes the directory in
+    launcher agent share the parent pid).  Rank 0 writes ``id.bin`` atomically; it removes the directory in
     :func:`file_rendezvous_cleanup` once every rank has initialised its communicator."""
     import os
     import time
