@@ -757,6 +757,40 @@ def test_gradient_of_an_arbitrary_fun_against_autodiff_of_the_oracle(approx, fun
     assert np.nanmax(np.abs(G2 - G)) <= 1e-5 * scale
 
 
+def test_a_custom_fun_that_is_not_finite_for_an_invalid_candidate_is_not_skipped():
+    """the reference adds valid * fun for EVERY candidate, so a path function that is inf for one of them makes the
+    cell NaN (0 * inf) whether that candidate is valid or not; the custom-function kernel used to return early when valid == 0
+    in every lane of the wave and dropped the NaN that the plain sweep (GPU trace + host fun) keeps."""
+    from differt2d_amd.geometry import Point
+    from differt2d_amd.scene import Scene
+
+    scene = Scene.square_scene_with_obstacle().with_transmitters(tx=Point(xy=np.array([0.2, 0.2], F)))
+    X, Y = scene.grid(9, 7)
+
+    def blows_up(transmitter, receiver, path, interacting_objects):  # (never called for its value: value_and_grad below)
+        raise AssertionError("fun.value_and_grad should have been used")
+
+    def vg(transmitter, receiver, path, interacting_objects):
+        xys = np.asarray(path.xys, np.float64)
+        v = (xys[..., 1:, :] - xys[..., :-1, :]) + float(np.finfo(np.float32).eps)
+        ln = np.sqrt((v * v).sum(-1))
+        bar = np.zeros_like(xys)
+        u = v / ln[..., None]
+        bar[..., 1:, :] += u
+        bar[..., :-1, :] -= u
+        val = ln.sum(-1)
+        if any(o is scene.objects[0] for o in interacting_objects):
+            val = np.full_like(val, np.inf)
+        return val, bar
+
+    blows_up.value_and_grad = vg
+    blows_up._d2d_native = False
+    Z, G = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=blows_up, reduce_all=True, value_and_grad=True, max_order=1, approx=False)
+    # object 0 is the bottom wall: for most cells its reflection is a valid path (inf), for the others valid = 0 and 0 * inf = NaN
+    assert not np.isfinite(Z).any(), "a candidate with fun = inf makes every cell inf or NaN, as in the reference's sum"
+    assert np.isnan(Z).any() and np.isinf(Z).any()
+
+
 def test_custom_fun_values_are_checked_by_the_library():
     """D2D_FUN_CUSTOM without rows, with the wrong number of candidates, on a forward launch: loud errors (include/d2d.h)."""
     from conftest import random_scene, unit_grid
