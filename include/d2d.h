@@ -291,6 +291,11 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *                  1 (default) = one workgroup of 16 waves per region of 4 x 4 patches, 2 = one wave per patch (same flags),
  *                  0 = off (round 3's behaviour: NaN only inside the candidates the sweep evaluates; A/B);
  *                  "nan_scan_stats": non-zero = count its work (d2d_debug_nan_scan; slows the scan down)
+ *                  "nan_scan_async": non-zero (default) = the scan runs BESIDE the sweep on a stream of its own and leaves flags
+ *                  that a small kernel applies once both are through; zero = behind the sweep on the sweep's stream (same results)
+ *                  "nan_scan_prio": priority of that stream, 0 (default) = lowest, 1 = highest (A/B: the highest is slower)
+ *   "comm_prio": priority of the stream the RCCL collectives run on beside the next sweep: -1 lowest, 0 (default) normal, 1 highest;
+ *                  set it BEFORE the first collective (D2D_ERR_STATE afterwards)
  *   "sig_narrow_filter": sigmoid validity, forward sweeps: 1 (default) = the divide-free filter of the occlusion tests drops what is
  *                  certainly below z = -17.5 (1 - sigmoid(z) is exactly 1.0f there), 0 = what is certainly below -89 (same results)
  *   "opt_parallel": zero = MinPath / FermatPath sweeps walk the candidates one after the other in every lane (same results)
