@@ -970,6 +970,16 @@ static int opt_sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, in
     a.h2 = p->height * p->height;
     a.fun_id = p->fun_id;
     a.out_mode = p->out_mode;
+    if (p->fun_id == D2D_FUN_CUSTOM) {
+        // a host-evaluated path function: rows in this enumeration's order, chained through the reverse pass over the stored
+        // trajectory (the forward-tangent variant carries no seed for them)
+        if (!grad_mode || c->opt_grad_mode != 0)
+            return fail(D2D_ERR_UNSUPPORTED, "fun_id D2D_FUN_CUSTOM with an optimiser-based solver needs the reverse-mode value+grad sweep (option opt_grad_mode 0)");
+        if (c->cust_C != (long long)C)
+            return fail(D2D_ERR_STATE, "d2d_set_path_fun_values holds %lld candidates, this sweep walks %lld", c->cust_C, (long long)C);
+        a.cust_f = c->d_cust_f.p;
+        a.cust_pb = c->d_cust_pb.p;
+    }
     const unsigned blocks = (unsigned)((a.cells + 63) / 64);
     if (grad_mode) {
         // one (cell, candidate) per lane, the candidates side by side; value, per-cell gradient and VJP partial sums go
@@ -1124,8 +1134,8 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     if (p->fun_id == D2D_FUN_CUSTOM) {
         // a host-evaluated path function (d2d_set_path_fun_values): the exhaustive value+grad kernel walks every candidate in the
         // reference's order, which is the order the host's rows come in
-        if (!grad_mode || p->solver != D2D_SOLVER_IMAGE)
-            return fail(D2D_ERR_UNSUPPORTED, "fun_id D2D_FUN_CUSTOM is for d2d_power_map_vg_launch with the image solver only");
+        if (!grad_mode) return fail(D2D_ERR_UNSUPPORTED, "fun_id D2D_FUN_CUSTOM is for d2d_power_map_vg_launch only");
+        if (p->solver == D2D_SOLVER_MINPATH || p->solver == D2D_SOLVER_FERMAT) return opt_sweep_launch(c, p, tx, grad_mode);
         long long want = 0;
         for (int k = p->min_order; k <= p->max_order; ++k) {
             long long ck = 1;

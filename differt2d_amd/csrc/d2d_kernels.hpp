@@ -4268,6 +4268,8 @@ struct OptSweepArgs {
     float h2;
     int fun_id;
     int out_mode;
+    const float* __restrict__ cust_f;   // [C][cells]                          D2D_FUN_CUSTOM (the reverse-mode value+grad sweep only)
+    const float* __restrict__ cust_pb;  // [C][cells][D2D_MAX_ORDER + 2][2]
 };
 
 // valid * fun of one (cell, candidate): solve, validate, evaluate (scene.py:1892-1918 with an optimiser-based path class)

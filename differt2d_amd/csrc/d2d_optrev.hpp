@@ -316,7 +316,7 @@ __device__ __forceinline__ float seg_test(int mode, float alpha, float lo, float
 // Returns the contribution itself (the forward sweep's float code on the same final theta: the value map is bit-identical).
 template <int K>
 __device__ __forceinline__ float opt_rev_candidate(const OptRevArgs& ra, int c, const int (&cd)[D2D_MAX_ORDER], float cellx, float celly,
-                                                   float cot, bool active, long lane_cell, float& grx, float& gry, float* row) {
+                                                   float cot, bool active, long lane_cell, long idx, float& grx, float& gry, float* row) {
     constexpr int KK = K > 0 ? K : 1;
     const OptGradArgs& a = ra.g;
     const OptSweepArgs& s = a.s;
@@ -366,6 +366,7 @@ __device__ __forceinline__ float opt_rev_candidate(const OptRevArgs& ra, int c, 
     if (s.fun_id == D2D_FUN_RECEIVED_POWER) f = num / (s.h2 + r * r);
     else if (s.fun_id == D2D_FUN_LENGTH_SQUARED) f = r * r;
     else if (s.fun_id == D2D_FUN_LENGTH) f = r;
+    else if (s.fun_id == D2D_FUN_CUSTOM) f = s.cust_f[(long)c * s.cells + idx];  // d2d_set_path_fun_values: the host's fun on the traced path
     else f = 1.0f;
     const float contribution = valid * f;
 
@@ -385,6 +386,15 @@ __device__ __forceinline__ float opt_rev_candidate(const OptRevArgs& ra, int c, 
     } else if (s.fun_id == D2D_FUN_LENGTH_SQUARED) rbar = fbar * (2.0f * r);
     else if (s.fun_id == D2D_FUN_LENGTH) rbar = fbar;
     else rbar = 0.0f;
+    if (s.fun_id == D2D_FUN_CUSTOM) {
+        // the host's d fun / d xys (its derivative w.r.t. the end points as arguments of `fun` folded into rows 0 and K + 1)
+        const float* pb = s.cust_pb + ((long)c * s.cells + idx) * (2 * (D2D_MAX_ORDER + 2));
+#pragma unroll
+        for (int i = 0; i < K + 2; ++i) {
+            pbx[i] = fbar * pb[2 * i];
+            pby[i] = fbar * pb[2 * i + 1];
+        }
+    }
     // (fun = 1 never evaluates a length: 0 * (w / |w|) would be NaN, not 0, for a segment vector of exactly (-eps, -eps))
     if (s.fun_id == D2D_FUN_RECEIVED_POWER || s.fun_id == D2D_FUN_LENGTH_SQUARED || s.fun_id == D2D_FUN_LENGTH) {
 #pragma unroll
@@ -606,6 +616,10 @@ __device__ __forceinline__ float opt_rev_candidate(const OptRevArgs& ra, int c, 
     const float fbx = s.grid_is_tx ? bxb : axb, fby = s.grid_is_tx ? byb : ayb;  // the launch's fixed end point
     grx = active ? cbx : 0.0f;
     gry = active ? cby : 0.0f;
+    if (s.fun_id == D2D_FUN_CUSTOM && active && !(fabsf(f) < 3.0e38f)) {
+        // a host function that is not finite here: f * d valid holds a 0 * inf (or a NaN) whether the candidate is valid or not
+        grx = gry = __builtin_nanf("");
+    }
     if (row) {
         const float wgt = active ? cot : 0.0f;
         const float sfx = wave_sum(wgt * fbx), sfy = wave_sum(wgt * fby);
@@ -672,7 +686,7 @@ __global__ void __launch_bounds__(64) power_opt_rev_kernel(OptRevArgs ra, int c_
     for (int i = 0; i < D2D_MAX_ORDER; ++i) cd[i] = s.cand[c * D2D_MAX_ORDER + i];
     float grx = 0.0f, gry = 0.0f;
     float* r = a.partial ? row : nullptr;
-    const float v = opt_rev_candidate<K>(ra, c, cd, cellx, celly, cot, active, lane_cell, grx, gry, r);
+    const float v = opt_rev_candidate<K>(ra, c, cd, cellx, celly, cot, active, lane_cell, idx, grx, gry, r);
     if (active) {
         a.contrib[(long)c * s.cells + idx] = v;
         a.gcontrib[((long)c * s.cells + idx) * 2] = grx;

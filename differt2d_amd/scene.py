@@ -704,16 +704,16 @@ class Scene(Plottable):
         return acc
 
     def _emit_grid_grad(self, X, Y, fixed: Point, grid_is_rx: bool, point_cls, fun, fun_args, fun_kwargs, common,
-                        filter_objects, path_cls):
+                        filter_objects, path_cls, path_cls_kwargs=None, key=None):
         """Value and per-cell gradient of a sweep with an arbitrary Python ``fun`` (reference scene.py:1892-1923 with any JAX
         callable): the paths of all (cell, candidate) are traced on the GPU, ``fun`` and its derivative w.r.t. the path points
         are evaluated on the host once per candidate (fun_grad.py: ``fun.value_and_grad`` or a tape of ``fun``'s operations),
-        and the exhaustive value+grad kernel chains them through the hand-derived adjoint of the validity and of the image
-        method (include/d2d.h: d2d_set_path_fun_values, D2D_FUN_CUSTOM).  ImagePath only."""
+        and the value+grad kernel chains them through the hand-derived adjoint of the validity and of the path method -- the
+        image method, or the reverse pass over the MinPath / FermatPath solver's stored Adam trajectory, started from the same
+        initial guesses the paths were traced with (include/d2d.h: d2d_set_path_fun_values, D2D_FUN_CUSTOM).  A function of
+        ``path.loss`` is refused by the tape (fun_grad.py)."""
         from .fun_grad import value_and_xys_bar
 
-        if self._solver_of(path_cls) != "image":
-            raise L.D2DUnsupported(-4, "grad / value_and_grad of a path function that is not fused natively: ImagePath only")
         candidates = self.all_path_candidates(common["min_order"], common["max_order"], order=common.get("order"),
                                               filter_objects=filter_objects)
         cells = X.size
@@ -730,7 +730,8 @@ class Scene(Plottable):
         p = dict(common)
         p.pop("order", None)
         p["min_order"], p["max_order"] = 0, L.D2D_MAX_ORDER
-        out = ctx.trace_paths(make_params(solver="image", **p), txs, rxs, candidates)
+        sextra, theta0 = self._solver_setup(path_cls, path_cls_kwargs, candidates, key)
+        out = ctx.trace_paths(make_params(**sextra, **p), txs, rxs, candidates, theta0=theta0)
         f = np.zeros((len(candidates),) + X.shape, F)
         bar = np.zeros((len(candidates),) + X.shape + (L.D2D_MAX_ORDER + 2, 2), F)
         for c, cand in enumerate(candidates):
@@ -743,7 +744,9 @@ class Scene(Plottable):
         self._upload(ctx, filter_objects)
         ctx.set_grid(X, Y)
         ctx.set_path_fun_values(f, bar)
-        params = make_params(fun="custom", grid_role=L.GRID_RX if grid_is_rx else L.GRID_TX, **common)
+        if theta0 is not None:
+            ctx.set_theta0(theta0)
+        params = make_params(fun="custom", grid_role=L.GRID_RX if grid_is_rx else L.GRID_TX, **sextra, **common)
         ctx.launch_vg(params, fixed.xy, scene_vjp=False)
         value, grad = ctx.get_map(), ctx.get_grad_rx()
         ctx.set_path_fun_values(None)
@@ -764,7 +767,7 @@ class Scene(Plottable):
                 # (value_and_grad takes precedence over grad, reference scene.py:1920-1923)
                 pick = (lambda vg: vg) if value_and_grad else (lambda vg: vg[1])
                 gen = ((name, self._emit_grid_grad(X, Y, pt, grid_is_rx, point_cls, fun, fun_args, fun_kwargs, common,
-                                                   filter_objects, path_cls)) for name, pt in fixed_items)
+                                                   filter_objects, path_cls, path_cls_kwargs, key)) for name, pt in fixed_items)
                 if reduce_all:
                     Z, G = np.zeros(X.shape, F), np.zeros(X.shape + (2,), F)
                     for _, (v, g) in gen:

@@ -217,8 +217,10 @@ int d2d_set_cotangent(d2d_ctx* ctx, const float* cot);
  *                                                 derivative w.r.t. tx.xy / rx.xy as arguments of fun is added to rows 0 / order+1),
  * candidates in the sweep's order (orders min_order..max_order, lexicographic over the allowed objects -- the order of
  * d2d_trace_paths' candidate list built by the reference's all_path_candidates).  A following d2d_power_map_vg_launch with
- * params->fun_id == D2D_FUN_CUSTOM (image solver; every candidate of every cell is evaluated, as under strict_nan) then
- * chains them through the hand-derived adjoint of the validity and of the image method: d2d_get_map returns
+ * params->fun_id == D2D_FUN_CUSTOM (image solver: every candidate of every cell is evaluated, as under strict_nan;
+ * MinPath / FermatPath: the reverse pass over the stored trajectory, option "opt_grad_mode" 0, with the theta0 rows the
+ * paths were traced with) then
+ * chains them through the hand-derived adjoint of the validity and of the path method: d2d_get_map returns
  * sum_c valid_c * f_c and d2d_get_grad_rx its derivative w.r.t. the cell, d2d_get_scene_vjp the pull-back to the fixed
  * end point and the wall end points THROUGH THE PATHS (fun's own dependence on the objects is the caller's).
  * Host arrays, copied before the call returns; NULL / 0 drops them; dropped by d2d_set_grid, by a different scene and by

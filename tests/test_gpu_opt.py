@@ -431,6 +431,90 @@ def test_scene_mirror_exposes_the_solver_gradients():
     assert abs(fd - out["phi_bar"][4]) <= 0.05 * abs(fd) + 1e-3, (fd, out["phi_bar"][4])
 
 
+def _power_like_host(transmitter, receiver, path, interacting_objects, r_coef=0.5, height=0.1):
+    """received_power written with operators only, kept away from the recogniser: the host-evaluated route."""
+    r = path.length()
+    return (r_coef ** (path.xys.shape[-2] - 2)) / (height * height + r * r)
+
+
+_power_like_host._d2d_native = False
+
+
+def _odd_host(transmitter, receiver, path, interacting_objects, w=0.3):
+    r = path.length()
+    dx = receiver.xy[..., 0] - transmitter.xy[..., 0]
+    return w * r * r.sqrt() + dx * dx + path.xys[..., -2, 0] * receiver.xy[..., 1]
+
+
+_odd_host._d2d_native = False
+
+
+def _odd_oracle(pts, xp=None, w=0.3):
+    from oracle import ref as R
+
+    r = R.path_length(pts, xp)
+    dx = pts[-1][..., 0] - pts[0][..., 0]
+    return w * r * r.sqrt() + dx * dx + pts[-2][..., 0] * pts[-1][..., 1]
+
+
+@pytest.mark.parametrize("role", ["rx", "tx"])
+@pytest.mark.parametrize("solver", ["min", "fermat"])
+def test_gradient_of_a_host_evaluated_fun_through_the_solver(solver, role):
+    """value_and_grad of a sweep whose `fun` only the host can evaluate, with MinPath / FermatPath (reference
+    scene.py:1892-1923: any callable, any path class): paths traced on the GPU from the same initial guesses, `fun` and
+    d fun / d xys from a tape of its operations, chained through the reverse pass over the solver's stored trajectory.
+    (a) a callable that computes what received_power computes: values, NaN cells and per-cell gradient of the natively fused
+    sweep; (b) a function nothing in the library knows (length^1.5, both end points as arguments, an interior path point):
+    against reverse-mode autodiff of the oracle through the Adam loop with the same function, at the image-method bar."""
+    from differt2d_amd.geometry import FermatPath, MinPath, Point
+    from differt2d_amd.utils import received_power
+    from oracle import ref as R
+
+    steps = 40
+    scene, xys, kind, phi, X, Y, cands, theta0 = _opt_case(steps, solver, True, grid=(8, 6), role=role)
+    fixed = scene.transmitters["tx"].xy
+    if role == "rx":
+        sweep = scene.accumulate_on_receivers_grid_over_paths
+    else:
+        scene = scene.with_transmitters().with_receivers(rx=Point(xy=fixed))
+        sweep = scene.accumulate_on_transmitters_grid_over_paths
+    kw = dict(path_cls=MinPath if solver == "min" else FermatPath, min_order=0, max_order=1, approx=True, reduce_all=True,
+              value_and_grad=True, path_cls_kwargs={"steps": steps, "theta0": theta0})
+    Z0, G0 = sweep(X, Y, fun=received_power, fun_kwargs=dict(r_coef=0.5, height=0.1), **kw)
+    Z1, G1 = sweep(X, Y, fun=_power_like_host, **kw)
+    np.testing.assert_allclose(Z1, Z0, rtol=2e-6, atol=1e-6)
+    assert np.array_equal(np.isnan(G1), np.isnan(G0)) and np.isfinite(G0).mean() > 0.8
+    scale = float(np.nanmax(np.abs(G0)))
+    assert scale > 0 and np.nanmax(np.abs(G1 - G0)) <= 1e-5 * scale
+    # (b)
+    Z, G = sweep(X, Y, fun=_odd_host, fun_kwargs=dict(w=0.25), **kw)
+    okw = dict(solver=solver, steps=steps, grid_role=role, approx=True, fun=_odd_oracle, fun_kwargs=dict(w=0.25))
+    w64 = R.opt_value_and_grads(kind, xys, phi, fixed, X, Y, cands, theta0, dtype="float64", **okw)
+    w32 = R.opt_value_and_grads(kind, xys, phi, fixed, X, Y, cands, theta0, dtype="float32", **okw)
+    stable = _oracle_stable(w64["value"], w32["value"], w64["grad_cell"], w32["grad_cell"])
+    assert stable.mean() >= 0.8
+    _tight(Z[stable], w64["value"][stable], w32["value"][stable], f"{solver} {role} host fun: value")
+    _tight(G[stable], w64["grad_cell"][stable], w32["grad_cell"][stable], f"{solver} {role} host fun: per-cell gradient")
+
+
+def test_a_host_evaluated_fun_with_the_forward_tangent_sweep_is_refused():
+    """The forward-tangent variant of the solver gradients (option opt_grad_mode 1) carries no seed for a host function."""
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import default_context
+    from differt2d_amd.geometry import MinPath
+
+    scene, xys, kind, phi, X, Y, cands, theta0 = _opt_case(10, "min", True)
+    ctx = default_context()
+    ctx.set_option("opt_grad_mode", 1)
+    try:
+        with pytest.raises(L.D2DUnsupported):
+            scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=_odd_host, path_cls=MinPath, approx=True, reduce_all=True,
+                                                          value_and_grad=True, path_cls_kwargs={"steps": 10, "theta0": theta0})
+    finally:
+        ctx.set_option("opt_grad_mode", 0)
+        ctx.set_path_fun_values(None)
+
+
 def test_cfg5_full_size_value_and_gradient_on_sampled_cells():
     """BASELINE.json configs[4] at full size: square scene + RIS + its two diffraction vertices, 300 x 300 receivers, order 1,
     MinPath with 1000 Adam steps, hard_sigmoid validity -- value map, per-cell gradient and the scene VJP (incl. the RIS's
