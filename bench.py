@@ -239,7 +239,7 @@ def api_leg(tx, walls, resident_ms, sizes=(300, 1024), n_calls=12):
     hands X, Y and the objects over again and returns the map as a host array.  `first` = the first call on a context that
     has never seen this grid (upload, allocation of the launch's buffers, no work history); `steady` = the median of the
     following calls.  Arrays as scene.grid() returns them (immutable: recognised by identity) and plain writable arrays
-    (recognised by a content hash of their 2 x 4 m n bytes)."""
+    (recognised byte for byte against the context's host copy of their 2 x 4 m n bytes)."""
     from differt2d_amd.geometry import Point
     from differt2d_amd.scene import Scene
     from differt2d_amd.utils import received_power

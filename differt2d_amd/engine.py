@@ -162,7 +162,8 @@ class Context:
     # -- grid sweep -------------------------------------------------------------------
     def set_grid(self, X, Y):
         """Makes (X, Y) the resident grid.  A grid that is resident already is recognised -- by identity when both arrays
-        are immutable (read-only, like the reference's JAX arrays: no byte of them is read then), else by a content hash --
+        are immutable (read-only, like the reference's JAX arrays: no byte of them is read then), else byte for byte against
+        the library's host copy of the resident arrays --
         and is not uploaded again; the schedule's work history and the regions' boxes stay valid (include/d2d.h)."""
         Xc = np.ascontiguousarray(X, dtype=np.float32)
         Yc = np.ascontiguousarray(Y, dtype=np.float32)

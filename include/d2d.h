@@ -159,10 +159,10 @@ int d2d_list_candidates(d2d_ctx* ctx, int32_t min_order, int32_t max_order, int3
  *      for one transmitter at a time; X, Y as produced by Plottable.grid, differt2d/abc.py:57-81) -------- */
 
 /* Uploads the receiver grid (row-major [m][n], any coordinates) and (re)allocates the resident
- * output maps; the value map is zeroed.  A grid that is resident already (same m, n and bit patterns: a 64-bit content
- * hash decides) is not uploaded again and keeps everything keyed to it (the regions' bounding boxes, the work history of
- * the patch schedule): the reference's callers pass X, Y with every call (differt2d/scene.py:1803-1826).  Equality is the
- * hash's word: 64 bits, not cryptographic, not verified byte for byte. */
+ * output maps; the value map is zeroed.  A grid that is resident already (same m, n and bit patterns, compared byte for
+ * byte with a host copy the context keeps: 8 bytes of host memory per cell) is not uploaded again and keeps everything
+ * keyed to it (the regions' bounding boxes, the work history of the patch schedule): the reference's callers pass X, Y with
+ * every call (differt2d/scene.py:1803-1826). */
 int d2d_set_grid(d2d_ctx* ctx, const float* X, const float* Y, int32_t m, int32_t n);
 /* The same with a caller-supplied version token instead of the content hash: version != 0 asserts that equal versions
  * mean equal contents (an immutable array the caller has passed before, like the reference's JAX arrays); 0 = hash.  A strided

@@ -505,8 +505,8 @@ def test_trace_paths_checks_the_number_of_theta0_rows():
 
 def test_repeated_api_calls_reuse_the_resident_grid_and_the_work_history():
     """A caller of the reference's API hands X, Y and the objects over with every call (scene.py:1803-1826).  The grid and the
-    scene that are resident already must be recognised -- immutable arrays by identity, writable ones by their content
-    hash -- so that nothing is uploaded again and the patch schedule keeps its work history (the keys of the schedule are
+    scene that are resident already must be recognised -- immutable arrays by identity, writable ones byte for byte against
+    the context's host copy -- so that nothing is uploaded again and the patch schedule keeps its work history (the keys of the schedule are
     then the ones derived from the counted work, not the cold launch's proxy).  A grid that differs in one bit is a new grid."""
     from differt2d_amd.engine import default_context
     from differt2d_amd.geometry import Point
@@ -548,6 +548,14 @@ def test_repeated_api_calls_reuse_the_resident_grid_and_the_work_history():
                 r1 = ctx.grid_reuses()
                 m2 = scene.accumulate_on_receivers_grid_over_paths(X, Y2, **kw)
                 assert ctx.grid_reuses() == r1 and m2.shape == X.shape
+                # ... and the same ARRAY written in place is a new grid too: the map follows the new contents
+                from oracle import c_oracle as CO
+
+                Y2[60:110, :] += F(0.0031)
+                m3 = scene.accumulate_on_receivers_grid_over_paths(X, Y2, **kw)
+                assert ctx.grid_reuses() == r1
+                assert np.array_equal(m3, CO.power_map(walls, tx, X, Y2, min_order=0, max_order=2), equal_nan=True)
+                assert not np.array_equal(m3[60:110], m2[60:110]) and np.array_equal(m3[:60], m2[:60], equal_nan=True)
                 with pytest.raises(Exception):
                     ctx.debug_get_work(n_patches + 1)
         # a changed object is a new scene: the history goes (debug_get_work raises until a sweep has run), results follow
