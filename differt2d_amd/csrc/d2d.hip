@@ -1643,7 +1643,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     const dim3 grid_queue((unsigned)std::min<long long>(tiles, std::max<long long>(256, c->fb_hint)));
     if (txg_culled && !grad_mode) {
         const size_t lds_t = (size_t)(3 * c->N + 1) * sizeof(float4);
-        if (lds_t > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+        if (lds_t > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
         a.grad = nullptr; a.cot = nullptr; a.partial = nullptr;
         HIP_TRY(d2d::launch_txg(mode, a.rl != nullptr, false, p->max_order, grid, lds_t, c->stream, a));
         if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none)
@@ -1701,7 +1701,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
                                  (size_t)(2 * d2d::NAN_W + 1) * (size_t)((c->N + 31) / 32) * sizeof(unsigned) + 16;
             const bool regions = c->nan_scan_mode != 2 && lds_r + 512 <= d2d_host::LDS_LIMIT && c->N <= 4095;
             const size_t lds_n = regions ? lds_r : (size_t)(3 * c->N) * sizeof(float4) + (size_t)c->N * sizeof(int) + 16;
-            if (lds_n > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the NaN scan's LDS table", c->N);
+            if (lds_n > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the NaN scan's LDS table", c->N);
             unsigned long long* ns = nullptr;
             if (c->nan_scan_stats) {
                 int rc2;
@@ -1741,7 +1741,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         if (!txg && !p->strict_nan) {
             // culled value+grad sweep (default)
             const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4) + 512;  // tables, adjoint table, culling queue
-            if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+            if (lds2 > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
             a.cullq_off = (int)((size_t)(4 * c->N + 1) * sizeof(float4));
             HIP_TRY(d2d::launch_fwd_grad(mode, a.rl != nullptr, p->max_order, grid_patches, lds2, c->stream, a));
             if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
@@ -1754,7 +1754,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         } else if (txg_culled) {
             // TX grid, culled value+grad sweep
             const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4);
-            if (lds2 > 64 * 1024) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+            if (lds2 > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
             HIP_TRY(d2d::launch_txg(mode, a.rl != nullptr, true, p->max_order, grid_patches, lds2, c->stream, a));
             if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none)
                 d2d::SweepArgs af = a;
@@ -1790,7 +1790,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         return D2D_OK;
     }
     const size_t tab_lds = d2d_host::tab_lds_bytes(c->N);  // tables (+ adjoint table) + one culling queue
-    if (tab_lds > d2d_host::LDS_LIMIT) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~1300)", c->N);
+    if (tab_lds > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~2400)", c->N);
     // Launches that hold only a few patches per SIMD are bound by their dearest patch: share every patch between
     // D2D_SPLIT_W waves there (power_fwd_split_kernel).  Big grids are throughput-bound: one wave per patch.
     constexpr int D2D_SPLIT_W = d2d::SPLIT_W;

@@ -160,7 +160,9 @@ inline int check_params(const d2d_params* p, std::string& err) {
 }
 
 // ---- buffer sizes of the forward sweep ----------------------------------------------------------------------------
-constexpr size_t LDS_LIMIT = 64 * 1024;  // dynamic LDS a launch may ask for (of the CU's 160 KB: several workgroups stay resident)
+constexpr size_t LDS_LIMIT = 64 * 1024;  // dynamic LDS the launches that have a choice ask for (of the CU's 160 KB: several workgroups stay resident)
+constexpr size_t LDS_MAX = 156 * 1024;    // ... and what a launch without a choice may take: one workgroup per CU (gfx950 grants a workgroup the
+                                          // CU's whole 160 KB without an attribute, scripts/probes/lds_limit_probe.hip; 4 KB left for static LDS)
 constexpr size_t F4 = 16;                // sizeof(float4)
 
 // one-wave-per-patch kernels: [2N] refl + [N] flt + [N] adjoint table (float4 each) + 1 spare + one 512-byte culling queue

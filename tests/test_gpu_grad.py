@@ -150,6 +150,39 @@ def test_culled_and_strict_gradients_agree_on_a_larger_grid(ctx):
             np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-6 * np.abs(b[k]).max())
 
 
+def test_value_and_grad_in_a_scene_of_2000_walls(ctx):
+    """The value+grad kernels with 128 KB of tables and adjoint tables in LDS (2 000 short walls; tests/test_gpu_forward.py has the
+    forward sweep): orders 0..1 over all walls, both grid roles -- the culled sweep against the exhaustive kernel (values and
+    per-cell gradients bit for bit, NaN positions included, scene VJP to rounding) and, on a block of cells, against the C gradient
+    oracle."""
+    from differt2d_amd import _lib as L
+    from oracle import c_oracle as CO
+
+    rng = np.random.default_rng(11)
+    c = rng.random((2000, 2))
+    ang = rng.random(2000) * np.pi
+    d = np.stack([np.cos(ang), np.sin(ang)], -1) * 0.006
+    tx, walls = np.array([0.4503, 0.5211], F), np.stack([c - d, c + d], 1).astype(F)
+    X, Y = unit_grid(24, 16)
+    X, Y = (X * F(0.3) + F(0.31)).astype(F), (Y * F(0.2) + F(0.42)).astype(F)
+    ctx.set_scene(walls)
+    for role, rname in ((L.GRID_RX, "rx"), (L.GRID_TX, "tx")):
+        for approx in (False, True):
+            kw = dict(min_order=0, max_order=1, approx=approx, grid_role=role)
+            a = ctx.value_and_grads(tx, X, Y, strict_nan=False, **kw)
+            b = ctx.value_and_grads(tx, X, Y, strict_nan=True, **kw)
+            assert np.array_equal(a["value"], b["value"]) and np.count_nonzero(a["value"]) > 100
+            assert np.array_equal(a["grad_rx"], b["grad_rx"], equal_nan=True)
+            for k in ("tx_bar", "walls_bar"):
+                assert np.array_equal(np.isnan(a[k]), np.isnan(b[k])), k
+                np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=1e-6 * np.nanmax(np.abs(b[k])), err_msg=k)
+            if (rname == "rx") != approx:  # (the oracle's dual numbers take seconds per 50 cells here: RX hard, TX hard_sigmoid, 8 x 6 cells)
+                sub = (slice(5, 11), slice(8, 16))
+                v, g = CO.power_map_grad(walls, tx, X[sub], Y[sub], min_order=0, max_order=1, approx=approx, grid_role=rname)
+                assert np.array_equal(a["value"][sub], v)
+                _close(a["grad_rx"][sub], g, f"2000 walls, {rname} grid, approx={approx}")
+
+
 @pytest.mark.parametrize("approx", [False, True])
 def test_cfg3_full_size_value_and_grad(ctx, approx):
     """BASELINE.json configs[2] at full size (50 walls, 1024 x 1024 cells, orders 0..2, value + grad): the value map of
