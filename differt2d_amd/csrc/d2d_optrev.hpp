@@ -314,7 +314,9 @@ __device__ __forceinline__ float seg_test(int mode, float alpha, float lo, float
 //   grx, gry      d (valid * fun) / d cell
 //   row[5 N + 2]  += cot * d / d (object end points [4 N], fixed end point [2], phi [N])   (LDS)
 // Returns the contribution itself (the forward sweep's float code on the same final theta: the value map is bit-identical).
-template <int K>
+// CUST: the instance that serves a host-evaluated path function (D2D_FUN_CUSTOM; its loads and selects cost the fused
+// functions' instance 3 % at cfg5 when they share one)
+template <int K, bool CUST>
 __device__ __forceinline__ float opt_rev_candidate(const OptRevArgs& ra, int c, const int (&cd)[D2D_MAX_ORDER], float cellx, float celly,
                                                    float cot, bool active, long lane_cell, long idx, float& grx, float& gry, float* row) {
     constexpr int KK = K > 0 ? K : 1;
@@ -366,7 +368,7 @@ __device__ __forceinline__ float opt_rev_candidate(const OptRevArgs& ra, int c, 
     if (s.fun_id == D2D_FUN_RECEIVED_POWER) f = num / (s.h2 + r * r);
     else if (s.fun_id == D2D_FUN_LENGTH_SQUARED) f = r * r;
     else if (s.fun_id == D2D_FUN_LENGTH) f = r;
-    else if (s.fun_id == D2D_FUN_CUSTOM) f = s.cust_f[(long)c * s.cells + idx];  // d2d_set_path_fun_values: the host's fun on the traced path
+    else if (CUST && s.fun_id == D2D_FUN_CUSTOM) f = s.cust_f[(long)c * s.cells + idx];  // d2d_set_path_fun_values: the host's fun on the traced path
     else f = 1.0f;
     const float contribution = valid * f;
 
@@ -386,7 +388,7 @@ __device__ __forceinline__ float opt_rev_candidate(const OptRevArgs& ra, int c, 
     } else if (s.fun_id == D2D_FUN_LENGTH_SQUARED) rbar = fbar * (2.0f * r);
     else if (s.fun_id == D2D_FUN_LENGTH) rbar = fbar;
     else rbar = 0.0f;
-    if (s.fun_id == D2D_FUN_CUSTOM) {
+    if (CUST && s.fun_id == D2D_FUN_CUSTOM) {
         // the host's d fun / d xys (its derivative w.r.t. the end points as arguments of `fun` folded into rows 0 and K + 1)
         const float* pb = s.cust_pb + ((long)c * s.cells + idx) * (2 * (D2D_MAX_ORDER + 2));
 #pragma unroll
@@ -616,7 +618,7 @@ __device__ __forceinline__ float opt_rev_candidate(const OptRevArgs& ra, int c, 
     const float fbx = s.grid_is_tx ? bxb : axb, fby = s.grid_is_tx ? byb : ayb;  // the launch's fixed end point
     grx = active ? cbx : 0.0f;
     gry = active ? cby : 0.0f;
-    if (s.fun_id == D2D_FUN_CUSTOM && active && !(fabsf(f) < 3.0e38f)) {
+    if (CUST && s.fun_id == D2D_FUN_CUSTOM && active && !(fabsf(f) < 3.0e38f)) {
         // a host function that is not finite here: f * d valid holds a 0 * inf (or a NaN) whether the candidate is valid or not
         grx = gry = __builtin_nanf("");
     }
@@ -664,7 +666,7 @@ __device__ __forceinline__ float opt_rev_candidate(const OptRevArgs& ra, int c, 
 // One (cell, candidate) per lane; candidate = c_first + blockIdx.y (wave-uniform, all of order K: the enumeration is by ascending
 // order, so every order is a contiguous range and gets a launch -- and a register allocation -- of its own), cells
 // [cell0, cell0 + chunk_cells).
-template <int K>
+template <int K, bool CUST>
 __global__ void __launch_bounds__(64) power_opt_rev_kernel(OptRevArgs ra, int c_first) {
     extern __shared__ float row[];  // [5 N + 2]
     const OptGradArgs& a = ra.g;
@@ -686,7 +688,7 @@ __global__ void __launch_bounds__(64) power_opt_rev_kernel(OptRevArgs ra, int c_
     for (int i = 0; i < D2D_MAX_ORDER; ++i) cd[i] = s.cand[c * D2D_MAX_ORDER + i];
     float grx = 0.0f, gry = 0.0f;
     float* r = a.partial ? row : nullptr;
-    const float v = opt_rev_candidate<K>(ra, c, cd, cellx, celly, cot, active, lane_cell, idx, grx, gry, r);
+    const float v = opt_rev_candidate<K, CUST>(ra, c, cd, cellx, celly, cot, active, lane_cell, idx, grx, gry, r);
     if (active) {
         a.contrib[(long)c * s.cells + idx] = v;
         a.gcontrib[((long)c * s.cells + idx) * 2] = grx;
