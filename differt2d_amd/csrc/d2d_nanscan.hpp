@@ -203,11 +203,12 @@ __device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const flo
         Px[j] = fx;
         Py[j] = fy;
     }
+    float dP_prev = 0.0f;  // how far the fp32 point of the previous level may sit from its exact value (the thin quad's allowances)
 #pragma unroll
     for (int lvl = K - 1; lvl >= 0; --lvl) {
         const WallC& wl = w[lvl];
         float amin = __builtin_inff(), amax = -__builtin_inff(), bmin = __builtin_inff(), bmax = -__builtin_inff();
-        float magP = 0.0f, magJ = 0.0f;
+        float magP = 0.0f, magJ = 0.0f, vnabs = 0.0f;
         float cmin = __builtin_inff(), cmax = -__builtin_inff(), emin = __builtin_inff(), emax = -__builtin_inff();
         float c2min = __builtin_inff(), c2max = -__builtin_inff(), e2min = __builtin_inff(), e2max = -__builtin_inff();
         bool vpos = true, vneg = true;
@@ -220,6 +221,7 @@ __device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const flo
             bmax = fmaxf(bmax, jb);
             magP = fmaxf(magP, fabsf(Px[j]) + fabsf(Py[j]));
             magJ = fmaxf(magJ, fabsf(Jx[lvl][j]) + fabsf(Jy[lvl][j]));
+            vnabs = fmaxf(vnabs, fabsf(__builtin_fmaf(wl.ox - Px[j], wl.nx, (wl.oy - Py[j]) * wl.ny)));
             if (near_test) {
                 const float vn = __builtin_fmaf(wl.ox - Px[j], wl.nx, (wl.oy - Py[j]) * wl.ny);
                 const float dv = 32.0f * eps * ((fabsf(Px[j]) + fabsf(Py[j])) + (fabsf(wl.ox) + fabsf(wl.oy))) + abs3;
@@ -240,7 +242,47 @@ __device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const flo
         if (!(magP < 1e18f) || !(magJ < 1e18f)) return true;
         // (the cell's own fp32 images sit within a few ulps per reflection of the corners' hull: inside this margin)
         const float du = 64.0f * eps * (fabsf(wl.nx) + fabsf(wl.ny)) * (magP + magJ);
-        if (!((amin - bmax > du) || (amax - bmin < -du))) return true;
+        bool tight = false;
+        float E_tight = 0.0f;
+        if (K == 2 && lvl == 0) {
+            // Order 2, the second step.  Bounded independently, the point pt1 (an interval of wall 1's line) and the image J0(c)
+            // (the parallelogram of the corners' images) leave un0 = (pt1 - J0) . n0 a wide range; but they move TOGETHER with the
+            // cell: pt1 - J1 = mu (F - J1) with mu = (o1 - J1) . n1 / un1 (nan_probe's first step), pt1 is its own mirror image in
+            // wall 1 and J0 that of J1, hence pt1 - J0 = mu R1(F - J1) and
+            //     un0 = - mu A,   A = (J1(c) - F) . R1 n0     (R1 x = x - 2 (x . n1) n1)
+            // with A AFFINE in the cell (reflections are affine): one sign at the 4 corners, beyond what rounding can undo
+            // (the fp32 pt1 within dP_prev of the exact one, J1 a few ulps from the mirror image of J0, the dot product's own
+            // rounding -- divided by the smallest |mu|), holds for every cell of the box.  (un1 has one sign over the box: the
+            // level above passed.)
+            const WallC& w1 = w[1];
+            const float nn = __builtin_fmaf(wl.nx, w1.nx, wl.ny * w1.ny);
+            const float px_ = __builtin_fmaf(-2.0f * nn, w1.nx, wl.nx), py_ = __builtin_fmaf(-2.0f * nn, w1.ny, wl.ny);  // R1 n0
+            float unmax = 0.0f, vjmin = __builtin_inff(), aamin = __builtin_inff(), magJ1 = 0.0f;
+            bool vjp = true, vjn = true, ap = true, an = true;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float un1 = __builtin_fmaf(fx - Jx[1][v], w1.nx, (fy - Jy[1][v]) * w1.ny);
+                const float vj = __builtin_fmaf(w1.ox - Jx[1][v], w1.nx, (w1.oy - Jy[1][v]) * w1.ny);
+                const float av = __builtin_fmaf(Jx[1][v] - fx, px_, (Jy[1][v] - fy) * py_);
+                unmax = fmaxf(unmax, fabsf(un1));
+                vjmin = fminf(vjmin, fabsf(vj));
+                aamin = fminf(aamin, fabsf(av));
+                magJ1 = fmaxf(magJ1, fabsf(Jx[1][v]) + fabsf(Jy[1][v]));
+                vjp = vjp && vj > 0.0f; vjn = vjn && vj < 0.0f;
+                ap = ap && av > 0.0f; an = an && av < 0.0f;
+            }
+            const float n1l = fabsf(wl.nx) + fabsf(wl.ny);
+            const float mj = 32.0f * eps * (magJ1 + (fabsf(w1.ox) + fabsf(w1.oy)) + (fabsf(fx) + fabsf(fy)));
+            if (!(vjp || vjn) || !(ap || an) || !(vjmin > 2.0f * mj) || !(unmax < 1e18f) || !(magJ1 < 1e18f)) return true;
+            const float mu_lo = 0.98f * (vjmin - mj) / (unmax + mj);                   // |mu| >= this
+            const float err = (dP_prev + 32.0f * eps * magJ1) * n1l + du;              // fl(un0) against -mu A
+            const float ma = 1.02f * err / mu_lo + 2.0f * mj * (fabsf(px_) + fabsf(py_));  // ... and fl(A) against A
+            if (!(aamin > ma) || !(mu_lo > 0.0f)) return true;
+            const float u0lo = mu_lo * (aamin - ma) - err;                              // |fl(un0)| >= this over the box
+            if (!(u0lo > 0.0f)) return true;
+            E_tight = __builtin_fmaf(1.02f * vnabs / u0lo, magP + magJ, (fabsf(wl.ox) + fabsf(wl.oy)) + magP);
+            tight = true;
+        } else if (!((amin - bmax > du) || (amax - bmin < -du))) return true;
         if (near_test && !(vpos || vneg)) {
             if (APPROX) return true;
             const float dm = 256.0f * eps * (magP + magJ);  // hard mode, rule (3): can u = P - J enter the double cone?
@@ -249,6 +291,10 @@ __device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const flo
         }
         bool fin = true;
         float smin = __builtin_inff(), smax = -__builtin_inff(), E = 0.0f;
+        if (tight) {
+            E = E_tight;  // (the last level: only the magnitudes are asked for below)
+            smin = smax = 0.0f;
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float vx = wl.ox - Px[j], vy = wl.oy - Py[j];
@@ -266,6 +312,7 @@ __device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const flo
                 smax = fmaxf(smax, s);
                 E = fmaxf(E, mag);
             }
+        }
         }
         if (!fin) return true;
         E = E + (fabsf(wl.ox) + fabsf(wl.oy)) + magJ + magP;
@@ -287,6 +334,8 @@ __device__ __forceinline__ bool nan_possible_txg(const float (&cx)[4], const flo
             }
             break;
         }
+        // (what nan_quad allows the fp32 point around the exact one: 64 eps 2 E off the line, M along it)
+        dP_prev = 1.5f * (64.0f * eps * 2.0f * E) + M * (fabsf(wl.tx) + fabsf(wl.ty));
         nan_quad(wl, smin - M, smax + M, E, Px, Py);
     }
     return false;
