@@ -128,7 +128,10 @@ int d2d_synchronize(d2d_ctx* ctx);
 /* ---- scene (replaces Scene.objects / Scene.from_walls_array, differt2d/scene.py:191, 413-426) -- */
 
 /* objects: xys[N][2][2] (origin, dest; a Vertex stores its point in both rows), kind[N]
- * (D2D_WALL / D2D_RIS / D2D_VERTEX, NULL = all walls), phi[N] (RIS angle, NULL = pi/4). */
+ * (D2D_WALL / D2D_RIS / D2D_VERTEX, NULL = all walls), phi[N] (RIS angle, NULL = pi/4).
+ * Size: the image-method sweeps keep per-object tables in LDS -- up to ~1 300 objects in 64 KB with several workgroups per CU,
+ * up to ~2 400 with one workgroup per CU (156 of gfx950's 160 KB); a sweep over a bigger scene returns D2D_ERR_UNSUPPORTED.
+ * Scenes above 4 095 objects sweep without region lists (12-bit object indices in the list entries). */
 int d2d_set_scene(d2d_ctx* ctx, const float* xys, const uint8_t* kind, const float* phi, int32_t n_objects);
 /* (A scene that is resident already -- bit-identical arguments -- is recognised: nothing is uploaded and the scene-only
  * masks and the schedule's work history stay valid; the candidate mask is reset to "all" as always.) */
