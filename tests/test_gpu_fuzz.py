@@ -32,7 +32,7 @@ def test_gradient_fuzz_against_the_c_gradient_oracle():
 def test_solver_fuzz_against_the_c_oracle():
     """scripts/fuzz_opt.py: MinPath / FermatPath sweeps (values, and per-cell gradients through the Adam loop every other case)
     on random Wall / RIS / Vertex scenes against oracle/d2d_oracle_opt.c, on the cells the oracle calls well conditioned."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_opt.py"), "40", "2026"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_opt.py"), "30", "2026"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert " 0 mismatches" in out.stdout
