@@ -2135,7 +2135,10 @@ __device__ __forceinline__ long region_of(const SweepArgs& a, int tcol, int trow
 constexpr int NAN_W = D2D_NAN_W;
 constexpr int NAN_R = 4;            // patches per region along x; NAN_W / NAN_R along y
 constexpr int NAN_RY = NAN_W / NAN_R;
-constexpr int NAN_LCAP = 2048;
+#ifndef D2D_NAN_LCAP
+#define D2D_NAN_LCAP 2048  // A/B: entries of a region's list per round (a round = LCAP / 64 batches between two barriers)
+#endif
+constexpr int NAN_LCAP = D2D_NAN_LCAP;
 constexpr int NAN_RB = NAN_LCAP / 64;
 constexpr int HEAVY_PARTS = D2D_HEAVY_PARTS;  // the dearest patches of a launch are cut into this many parts (power_fwd_kernel)
 constexpr int TILE_W = 8;  // a wave covers an 8 x 8 patch of RX cells: neighbouring cells share skips
