@@ -497,6 +497,24 @@ def test_gradient_of_a_host_evaluated_fun_through_the_solver(solver, role):
     _tight(G[stable], w64["grad_cell"][stable], w32["grad_cell"][stable], f"{solver} {role} host fun: per-cell gradient")
 
 
+def test_host_evaluated_fun_with_several_random_starts_and_a_key():
+    """The same route with the reference's own initial guesses (a Threefry key, one key per candidate) and `many` = 3 starts
+    per candidate: the trace and the reverse pass pick the same best start, so the host-evaluated received_power equals the
+    fused one."""
+    from differt2d_amd.geometry import MinPath
+    from differt2d_amd.utils import received_power
+
+    scene, xys, kind, phi, X, Y, cands, theta0 = _opt_case(30, "min", True, grid=(8, 6))
+    kw = dict(path_cls=MinPath, min_order=0, max_order=1, approx=True, reduce_all=True, value_and_grad=True, key=7,
+              path_cls_kwargs={"steps": 30, "many": 3})
+    Z0, G0 = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=received_power, fun_kwargs=dict(r_coef=0.5, height=0.1), **kw)
+    Z1, G1 = scene.accumulate_on_receivers_grid_over_paths(X, Y, fun=_power_like_host, **kw)
+    np.testing.assert_allclose(Z1, Z0, rtol=2e-6, atol=1e-6)
+    assert np.array_equal(np.isnan(G1), np.isnan(G0)) and np.isfinite(G0).mean() > 0.8
+    scale = float(np.nanmax(np.abs(G0)))
+    assert scale > 0 and np.nanmax(np.abs(G1 - G0)) <= 1e-5 * scale
+
+
 def test_a_host_evaluated_fun_with_the_forward_tangent_sweep_is_refused():
     """The forward-tangent variant of the solver gradients (option opt_grad_mode 1) carries no seed for a host function."""
     from differt2d_amd import _lib as L
