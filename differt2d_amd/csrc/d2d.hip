@@ -1699,7 +1699,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             // two levels (a workgroup of 16 waves per region of 4 x 4 patches) when the region's list fits beside the tables
             const size_t lds_r = (size_t)(3 * c->N) * sizeof(float4) + (size_t)d2d::NAN_LCAP * sizeof(unsigned long long) +
                                  (size_t)(2 * d2d::NAN_W + 1) * (size_t)((c->N + 31) / 32) * sizeof(unsigned) + 16;
-            const bool regions = c->nan_scan_mode != 2 && lds_r + 512 <= d2d_host::LDS_LIMIT && c->N <= 4095;
+            // (+ the kernel's static LDS: boxes, counters, the region's probe queue, its cells and their flag words)
+            const size_t lds_static = 512 + (size_t)d2d::NAN_WQCAP * sizeof(unsigned long long) + (size_t)d2d::NAN_W * (64 * sizeof(float2) + 16);
+            const bool regions = c->nan_scan_mode != 2 && lds_r + lds_static <= d2d_host::LDS_LIMIT && c->N <= 4095;
             const size_t lds_n = regions ? lds_r : (size_t)(3 * c->N) * sizeof(float4) + (size_t)c->N * sizeof(int) + 16;
             if (lds_n > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the NaN scan's LDS table", c->N);
             unsigned long long* ns = nullptr;

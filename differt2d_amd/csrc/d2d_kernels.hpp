@@ -2140,6 +2140,7 @@ constexpr int NAN_RY = NAN_W / NAN_R;
 #endif
 constexpr int NAN_LCAP = D2D_NAN_LCAP;
 constexpr int NAN_RB = NAN_LCAP / 64;
+constexpr int NAN_WQCAP = 2048;     // (patch, candidate) items of a region waiting for their probe (d2d_nanscan.hpp; beyond it a wave probes its own)
 constexpr int HEAVY_PARTS = D2D_HEAVY_PARTS;  // the dearest patches of a launch are cut into this many parts (power_fwd_kernel)
 constexpr int TILE_W = 8;  // a wave covers an 8 x 8 patch of RX cells: neighbouring cells share skips
 constexpr int TILE_H = 8;

@@ -567,6 +567,7 @@ __device__ __forceinline__ void nan_decode_batch(long long id, int Nc, int n_chu
 
 template <int K, bool APPROX, bool TXG>
 __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float4* tab, unsigned long long* list, int* lcount, unsigned* wallbits,
+                                                 unsigned long long* wq, int* wqn, const float2* cells, unsigned long long* cellmask, unsigned* wallbits_all, int nwords,
                                                  const unsigned* nearbits, const unsigned* region_near, const float (&rbx)[4], const float (&rby)[4], const float (&pbx)[4], const float (&pby)[4],
                                                  float cx, float cy, bool force, bool patch_exists, bool& cell_nan, bool& any_nan,
                                                  unsigned long long& n_probe, int& round) {
@@ -582,8 +583,28 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
 #pragma unroll
         for (int d = 1; d <= K - 2; ++d) nb *= (Nc - 1);
     }
+    // the exact probe of one (patch, candidate) item, lanes = the cells of patch p; flags go to the patch's words in LDS
+    auto probe_item = [&](unsigned long long cu, int p, float pcx, float pcy) {
+        int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
+        float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
+#pragma unroll
+        for (int d = 0; d < K; ++d) {
+            ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
+            // RX grids: the transmitter's image chain (wave-uniform); TX grids: the lane's cell's (geometry.py:1086-1091)
+            image_of(ldc4(a.refl, 2 * ce[d]), d == 0 ? (TXG ? pcx : a.txx) : ex[d > 0 ? d - 1 : 0], d == 0 ? (TXG ? pcy : a.txy) : ey[d > 0 ? d - 1 : 0],
+                     ex[d], ey[d]);
+        }
+        const bool z = TXG ? nan_probe<K, APPROX>(a, ce, ex, ey, pcx, pcy, a.txx, a.txy) : nan_probe<K, APPROX>(a, ce, ex, ey, a.txx, a.txy, pcx, pcy);
+        const unsigned long long zm = __ballot(z);
+        if (zm != 0ull && lane == 0) {
+            atomicOr(&cellmask[p], zm);
+#pragma unroll
+            for (int d = 0; d < K; ++d) atomicOr(&wallbits_all[p * nwords + (ce[d] >> 5)], 1u << (ce[d] & 31));
+        }
+    };
     for (long long r0 = 0; r0 < nb; r0 += NAN_RB, ++round) {  // (workgroup-uniform)
         int* const cnt_p = lcount + (round & 1);
+        if (threadIdx.x == 0) *wqn = 0;  // (the previous round's queue was emptied before its last barrier)
         // ---- region level: batch r0 + t * NAN_W + wv
 #pragma unroll 1
         for (int t = 0; t < NAN_RB / NAN_W; ++t) {
@@ -672,32 +693,45 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
                     }
                 }
                 unsigned long long mask = __ballot(alive);
-                n_probe += (unsigned long long)__builtin_popcountll(mask);
+                const int cnt = __builtin_popcountll(mask);
+                n_probe += (unsigned long long)cnt;
+                if (cnt) {
+                    // the probes of a region are dealt to ALL its waves (the patches a zero line crosses are few, and the slowest wave
+                    // of a region probed 1.45 - 1.7 x the average): (patch, candidate) items go to a queue of the workgroup ...
+                    int base = 0;
+                    if (lane == 0) {
+                        base = atomicAdd(wqn, cnt);
+                        if (base + cnt > NAN_WQCAP) {
+                            atomicSub(wqn, cnt);
+                            base = -1;
+                        }
+                    }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= 0) {
+                        if (alive) wq[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = code | ((unsigned long long)wv << 56);
+                        mask = 0ull;
+                    }
+                }
+                // ... unless it is full: then the wave probes its own
                 while (mask) {
                     const int b = __builtin_ctzll(mask);
                     mask &= mask - 1;
                     const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(code & 0xffffffffull), b);
                     const unsigned hi32 = (K >= 3) ? (unsigned)__builtin_amdgcn_readlane((int)(code >> 32), b) : 0u;
                     const unsigned long long cu = ((unsigned long long)hi32 << 32) | lo32;
-                    int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
-                    float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
-#pragma unroll
-                    for (int d = 0; d < K; ++d) {
-                        ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
-                        // RX grids: the transmitter's image chain (wave-uniform); TX grids: the lane's cell's (geometry.py:1086-1091)
-                        image_of(ldc4(a.refl, 2 * ce[d]), d == 0 ? (TXG ? cx : a.txx) : ex[d > 0 ? d - 1 : 0], d == 0 ? (TXG ? cy : a.txy) : ey[d > 0 ? d - 1 : 0],
-                                 ex[d], ey[d]);
-                    }
-                    const bool z = TXG ? nan_probe<K, APPROX>(a, ce, ex, ey, cx, cy, a.txx, a.txy) : nan_probe<K, APPROX>(a, ce, ex, ey, a.txx, a.txy, cx, cy);
-                    cell_nan = cell_nan || z;
-                    if (wave_any(z)) {
-                        any_nan = true;
-                        if (lane == 0) {
-#pragma unroll
-                            for (int d = 0; d < K; ++d) wallbits[ce[d] >> 5] |= 1u << (ce[d] & 31);
-                        }
-                    }
+                    probe_item(cu, wv, cx, cy);
                 }
+            }
+        }
+        __syncthreads();
+        {
+            // ---- the queue: item i to wave i mod NAN_W, the cells of the item's patch from LDS
+            const int nq = *wqn;
+            for (int i = wv; i < nq; i += NAN_W) {
+                const unsigned long long it = wq[i];
+                const int p = (int)(it >> 56);
+                const float2 c = cells[p * 64 + lane];
+                probe_item(it & 0x00ffffffffffffffull, p, c.x, c.y);
             }
         }
         __syncthreads();  // the list is rewritten by the next round
@@ -710,6 +744,10 @@ __global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a
     __shared__ float pbox[NAN_W][4];
     __shared__ int lcount[2];
     __shared__ int sbad;
+    __shared__ unsigned long long swq[NAN_WQCAP];    // the region's probes: (patch, candidate) items dealt to all waves (nan_region_order)
+    __shared__ int swqn;
+    __shared__ float2 scells[NAN_W * 64];            // the region's cells, patch by patch
+    __shared__ unsigned long long scellmask[NAN_W];  // flagged cells per patch
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 2 * a.N; i += 64 * NAN_W) tab[i] = ldc4(a.refl, i);
     for (int i = threadIdx.x; i < a.N; i += 64 * NAN_W) tab[2 * a.N + i] = ldc4(a.flt, i);
@@ -722,7 +760,9 @@ __global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a
     if (threadIdx.x == 0) {
         lcount[0] = lcount[1] = 0;
         sbad = 0;
+        swqn = 0;
     }
+    if (threadIdx.x < NAN_W) scellmask[threadIdx.x] = 0ull;
     __syncthreads();
     unsigned* wallbits = wallbits_all + wv * nwords;
     const int tiles_x = (a.n + TILE_W - 1) / TILE_W, tiles_y = (a.m + TILE_H - 1) / TILE_H;
@@ -738,6 +778,7 @@ __global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a
     const int crow = row < a.m ? row : a.m - 1;
     const long idx = (long)crow * a.n + ccol;
     const float cx = a.X[idx], cy = a.Y[idx];
+    scells[wv * 64 + lane] = make_float2(cx, cy);
     const bool lane_bad = !(fabsf(cx) < 1e18f) || !(fabsf(cy) < 1e18f) || !(fabsf(a.txx) < 1e18f) || !(fabsf(a.txy) < 1e18f);
     float x0 = cx, x1 = cx, y0 = cy, y1 = cy;
 #pragma unroll
@@ -794,13 +835,19 @@ __global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a
         any_nan = wave_any(cell_nan);
     }
     if (a.min_order <= 1 && a.max_order >= 1)
-        nan_region_order<1, APPROX, TXG>(a, tab, list, lcount, wallbits, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<1, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
     if (a.min_order <= 2 && a.max_order >= 2)
-        nan_region_order<2, APPROX, TXG>(a, tab, list, lcount, wallbits, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<2, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3)
-        nan_region_order<3, APPROX, TXG>(a, tab, list, lcount, wallbits, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<3, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
     if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4)
-        nan_region_order<4, APPROX, TXG>(a, tab, list, lcount, wallbits, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<4, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+    {
+        // what the region's probes found in this wave's patch (nan_region_order ends on a barrier)
+        const unsigned long long cm = scellmask[wv];
+        cell_nan = cell_nan || (((cm >> lane) & 1ull) != 0ull);
+        any_nan = any_nan || (cm != 0ull);
+    }
     const float qnan = __builtin_nanf("");
     const unsigned long long flagged = __ballot(cell_nan && in_range && patch_exists);
     if (a.nan_cell_bits != nullptr) {
