@@ -280,6 +280,11 @@ def test_errors_are_loud(ctx):
         ctx.launch(make_params(max_order=7), [0.1, 0.1])
     with pytest.raises(L.D2DError):
         ctx.launch(make_params(approx=True, alpha=0.0), [0.1, 0.1])
+    # a scene whose tables do not fit one CU's LDS (include/d2d.h: d2d_set_scene) is refused, not truncated
+    _, big = _short_walls(3000, seed=3)
+    ctx.set_scene(big)
+    with pytest.raises(L.D2DUnsupported):
+        ctx.launch(make_params(max_order=1), [0.1, 0.1])
 
 
 @pytest.mark.parametrize("approx,function", MODES)
