@@ -738,8 +738,11 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
     }
 }
 
+#ifndef D2D_NAN_MIN_WAVES
+#define D2D_NAN_MIN_WAVES 1  // A/B: waves per SIMD the region scan must leave room for (8: two of its workgroups per CU, <= 64 VGPRs)
+#endif
 template <bool APPROX, bool TXG, int MAXK>
-__global__ void __launch_bounds__(64 * NAN_W) nan_scan_region_kernel(SweepArgs a, unsigned long long* __restrict__ stats) {
+__global__ void __launch_bounds__(64 * NAN_W, D2D_NAN_MIN_WAVES) nan_scan_region_kernel(SweepArgs a, unsigned long long* __restrict__ stats) {
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, the region's list [NAN_LCAP], then [2 NAN_W + 1][ceil(N / 32)] flag bits
     __shared__ float pbox[NAN_W][4];
     __shared__ int lcount[2];
