@@ -285,6 +285,48 @@ def api_leg(tx, walls, resident_ms, sizes=(300, 1024), n_calls=12):
     return out
 
 
+def reference_harness_leg(n_calls=30):
+    """The reference's OWN benchmark workload, the only one anybody holding a DiffeRT2d install (CodSpeed, GitHub runners) can put
+    a number beside (reference tests/benchmarks/test_scene.py:9-29, fixtures tests/benchmarks/conftest.py:8-9, tests/conftest.py:14-20):
+    `Scene.basic_scene()` (7 walls, one transmitter, one receiver), `X, Y = scene.grid(n)` for n in {5, 25, 50}, and
+    `scene.accumulate_on_transmitters_grid_over_paths(X, Y, fun=received_power, reduce_all=True, approx=approx, key=key)` with
+    the defaults min_order = 0, max_order = 1 (8 candidates per cell) for approx in {False, True} -- through the Python mirror of
+    that entry point, wall time per call, host arrays in and host array out (what pytest-benchmark's lambda times; the reference
+    adds .block_until_ready()).  `first` = the first call of this grid and mode on the scene's context.  Beside it the CPU
+    restatement (oracle/d2d_oracle.c, all usable cores) on the same call, and the parity of the two maps (bit for bit)."""
+    from differt2d_amd.random import PRNGKey
+    from differt2d_amd.scene import Scene
+    from differt2d_amd.utils import received_power
+    from oracle import c_oracle as CO
+
+    scene = Scene.basic_scene()
+    key = PRNGKey(1234)
+    walls = np.stack([np.asarray(o.xys, np.float32) for o in scene.objects])
+    rx = np.asarray(next(iter(scene.receivers.values())).xy, np.float32)
+    out = {"what": "reference tests/benchmarks/test_scene.py: Scene.basic_scene() (7 walls), X, Y = scene.grid(n), "
+                   "accumulate_on_transmitters_grid_over_paths(X, Y, fun=received_power, reduce_all=True, approx=approx, key=key), "
+                   "orders 0..1; wall ms per call through the Python mirror incl. PCIe both ways; cpu = the C/OpenMP restatement "
+                   f"of the same call on {usable_cores()} cores (not JAX)", "calls": n_calls}
+    for n in (5, 25, 50):
+        X, Y = scene.grid(n)
+        for approx in (False, True):
+            ts = []
+            for _ in range(n_calls):
+                t0 = time.perf_counter()
+                Z = scene.accumulate_on_transmitters_grid_over_paths(X, Y, fun=received_power, reduce_all=True, approx=approx, key=key)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            kw = dict(min_order=0, max_order=1, approx=approx, grid_role="tx")
+            want = CO.power_map(walls, rx, X, Y, **kw)
+            tc = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                CO.power_map(walls, rx, X, Y, **kw)
+                tc.append((time.perf_counter() - t0) * 1e3)
+            out[f"n={n},approx={approx}"] = {"first_ms": ts[0], "steady_ms": float(np.median(ts[2:])), "min_ms": float(np.min(ts[2:])),
+                                            "cpu_ms": float(np.median(tc)), "cells_differing_from_oracle": int((~((Z == want) | (np.isnan(Z) & np.isnan(want)))).sum())}
+    return out
+
+
 def strong_leg(ctx, world, rank, distributed, do_gather, timed, which="cfg4", steps=5, approx=False):
     """A BASELINE.json configuration with its rows split over the ranks -- configs[3] (200 walls, 2048 x 2048, orders 0..3) or
     configs[1] (the timed workload's own 1024 x 1024 grid) -- the STRONG-scaling companion of the timed (weak) workload, in the
@@ -624,6 +666,7 @@ def main():
         extras["strong_cfg4_hard_sigmoid"] = strong_leg(ctx, world, rank, distributed, do_gather, timed, "cfg4", steps=3, approx=True)
         extras["cfg5"] = cfg5_leg(ctx, timed)
         extras["api"] = api_leg(tx, walls, ms_per_step)
+        extras["reference_harness"] = reference_harness_leg()
 
     if rank == 0:
         approx = timed_mode != "hard"

@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("D2D_LIB") or os.path.join(CSRC, "libd2d.so")
 D2D_MAX_ORDER = 4
 D2D_NUM_STATS = 16
 D2D_COMM_ID_BYTES = 128
-D2D_ABI_VERSION = 9
+D2D_ABI_VERSION = 10
 
 D2D_WALL, D2D_RIS, D2D_VERTEX = 0, 1, 2
 SOLVER_IMAGE, SOLVER_MINPATH, SOLVER_FERMAT = 0, 1, 2

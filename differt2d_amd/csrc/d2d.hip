@@ -225,6 +225,7 @@ struct d2d_ctx {
     // the scan BESIDE the sweep ("nan_scan_async", default on): on a stream of its own, its flags applied by nan_apply_kernel once
     // both are through (sweep 0.14 ms + scan 0.26 ms one behind the other at cfg3)
     bool nan_scan_async = true;
+    long long nan_wqcap = 0, nan_rb = 0;  // "nan_scan_wqcap" / "nan_scan_rb": the region scan's queue entries / batches per round in use (0: all; tests)
     long long nan_scan_prio = 0;        // "nan_scan_prio": 0 the scan stream has the lowest priority, 1 the highest (A/B)
     hipStream_t scan_stream = nullptr;  // created at the first use
     long long scan_stream_prio = -1;
@@ -697,6 +698,7 @@ int d2d_synchronize(d2d_ctx* c) {
     int rc = set_device(c);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->scan_stream) HIP_TRY(hipStreamSynchronize(c->scan_stream));  // (joined by every launch that forks it; a failed launch may have left it running)
     for (int w = 0; w < 3; ++w)
         if (c->inflight[w]) {
             HIP_TRY(hipEventSynchronize(c->ev_done[w]));
@@ -1707,15 +1709,33 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             unsigned long long* ns = nullptr;
             if (c->nan_scan_stats) {
                 int rc2;
-                if ((rc2 = c->d_nan_stats.ensure(4))) return rc2;
-                HIP_TRY(hipMemsetAsync(c->d_nan_stats.p, 0, 4 * sizeof(unsigned long long), st));
+                if ((rc2 = c->d_nan_stats.ensure(8))) return rc2;
+                HIP_TRY(hipMemsetAsync(c->d_nan_stats.p, 0, 8 * sizeof(unsigned long long), st));
                 ns = c->d_nan_stats.p;
             }
             const dim3 grid_regions((unsigned)(((tiles_x + d2d::NAN_R - 1) / d2d::NAN_R) * ((tiles_y + d2d::NAN_RY - 1) / d2d::NAN_RY)));
-            HIP_TRY(d2d::launch_nan_scan(p->approx != 0, txg, p->max_order, regions, regions ? grid_regions : grid_patches, lds_n, st, as, ns));
+            d2d::SweepArgs ac = as;
+            ac.nan_wqcap = (int)c->nan_wqcap;
+            ac.nan_rb = (int)c->nan_rb;
+            HIP_TRY(d2d::launch_nan_scan(p->approx != 0, txg, p->max_order, regions, regions ? grid_regions : grid_patches, lds_n, st, ac, ns));
             return D2D_OK;
         };
+        // every size check of the sweeps below comes BEFORE the scan is forked onto its own stream: nothing may fail between the
+        // fork and the join (a scan left running would read tables that a later d2d_set_scene rewrites)
+        if (!txg && !p->strict_nan) {
+            if ((size_t)(4 * c->N + 1) * sizeof(float4) + 512 > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+        } else if (txg_culled) {
+            if ((size_t)(4 * c->N + 1) * sizeof(float4) > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+        }
         bool scan_beside = false;
+        // ... and should a launch fail behind the fork all the same (a HIP error), the scan is waited for before the error is returned
+        struct ScanJoin {
+            d2d_ctx* c;
+            bool armed = false;
+            ~ScanJoin() {
+                if (armed && c->scan_stream) (void)hipStreamSynchronize(c->scan_stream);
+            }
+        } scan_join{c};
         if (scan && c->nan_scan_async) {
             if (c->scan_stream == nullptr || c->scan_stream_prio != c->nan_scan_prio) {
                 if (c->scan_stream) { HIP_TRY(hipStreamSynchronize(c->scan_stream)); HIP_TRY(hipStreamDestroy(c->scan_stream)); c->scan_stream = nullptr; }
@@ -1736,6 +1756,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             // (the previous launch's nan_apply_kernel has read the flags: stream order through the fork event)
             HIP_TRY(hipEventRecord(c->ev_scan_fork, c->stream));
             HIP_TRY(hipStreamWaitEvent(c->scan_stream, c->ev_scan_fork, 0));
+            scan_join.armed = true;
             if ((rc = launch_scan(c->scan_stream, as))) return rc;
             HIP_TRY(hipEventRecord(c->ev_scan_done, c->scan_stream));
             scan_beside = true;
@@ -1773,6 +1794,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             as.nan_row_bits = grad_mode == 2 ? c->d_nan_rows.p : nullptr;
             as.nan_row_words = 1 + (c->N + 31) / 32;
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_scan_done, 0));
+            scan_join.armed = false;  // joined: the main stream is behind the scan from here on
             HIP_TRY(d2d::launch_nan_apply(c->stream, as, (long)tiles));
         } else if (scan) {
             if ((rc = launch_scan(c->stream, a))) return rc;
@@ -2072,6 +2094,13 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
         c->comm_prio = value > 0 ? 1 : (value < 0 ? -1 : 0);
     }
     else if (!strcmp(name, "nan_scan_async")) c->nan_scan_async = value != 0;
+    else if (!strcmp(name, "nan_scan_wqcap")) {
+        if (value < 0 || value > d2d::NAN_WQCAP) return fail(D2D_ERR_INVALID, "nan_scan_wqcap must be in [0, %d], got %lld", d2d::NAN_WQCAP, (long long)value);
+        c->nan_wqcap = value;
+    } else if (!strcmp(name, "nan_scan_rb")) {
+        if (value < 0 || value > d2d::NAN_RB) return fail(D2D_ERR_INVALID, "nan_scan_rb must be in [0, %d], got %lld", d2d::NAN_RB, (long long)value);
+        c->nan_rb = value;
+    }
     else if (!strcmp(name, "nan_scan_prio")) c->nan_scan_prio = value != 0 ? 1 : 0;
     else if (!strcmp(name, "prep_fused")) c->prep_fused = value != 0;
     else if (!strcmp(name, "opt_parallel")) c->opt_parallel = value != 0;
@@ -2149,12 +2178,12 @@ int d2d_debug_nan_scan(d2d_ctx* c, int64_t* out) {
     if (!c || !out) return fail(D2D_ERR_INVALID, "NULL argument");
     int rc = set_device(c);
     if (rc) return rc;
-    out[0] = out[1] = out[2] = 0;
+    for (int i = 0; i < 6; ++i) out[i] = 0;
     if (!c->d_nan_stats.p) return D2D_OK;
-    unsigned long long h[4];
-    HIP_TRY(hipMemcpyAsync(h, c->d_nan_stats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 3; ++i) out[i] = (int64_t)h[i];
+    unsigned long long h[8];
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (the launch joined the scan's stream)
+    HIP_TRY(hipMemcpy(h, c->d_nan_stats.p, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 6; ++i) out[i] = (int64_t)h[i];
     return D2D_OK;
 }
 

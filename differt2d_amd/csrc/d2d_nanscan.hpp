@@ -445,7 +445,8 @@ __device__ __forceinline__ void nan_scan_order(const SweepArgs& a, const float4*
 }
 
 // a.grad: [m][n][2] the culled sweep's per-cell gradient; a.partial: its per-patch rows of the scene VJP, or null.
-// stats (may be null): [0] (patch, candidate) pairs probed, [1] flagged cells, [2] patches with a flag.
+// stats (may be null): [0] (patch, candidate) pairs probed, [1] flagged cells, [2] patches with a flag; the region kernel also
+// [3] probes made by the wave itself (queue full), [4] refused queue items (must be 0), [5] rounds.
 template <bool APPROX, bool TXG, int MAXK>
 __global__ void __launch_bounds__(64) nan_scan_kernel(SweepArgs a, unsigned long long* __restrict__ stats) {
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, then [N] int flags
@@ -570,9 +571,12 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
                                                  unsigned long long* wq, int* wqn, const float2* cells, unsigned long long* cellmask, unsigned* wallbits_all, int nwords,
                                                  const unsigned* nearbits, const unsigned* region_near, const float (&rbx)[4], const float (&rby)[4], const float (&pbx)[4], const float (&pby)[4],
                                                  float cx, float cy, bool force, bool patch_exists, bool& cell_nan, bool& any_nan,
-                                                 unsigned long long& n_probe, int& round) {
+                                                 unsigned long long& n_probe, int& round, unsigned long long& n_self, unsigned long long& n_bad) {
     static_assert(K >= 1, "order 0 has no scan");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // entries of the probe queue / batches per round in use: the compile-time sizes, or less ("nan_scan_caps": tests make overflow the rule)
+    const int wqcap = a.nan_wqcap > 0 && a.nan_wqcap < NAN_WQCAP ? a.nan_wqcap : NAN_WQCAP;
+    const int rb = a.nan_rb > 0 && a.nan_rb < NAN_RB ? a.nan_rb : NAN_RB;
     const bool plen = a.fun_id != D2D_FUN_ONE;
     const int Nc = a.Nc;
     if (Nc < 1 || (K >= 2 && Nc < 2)) return;  // (workgroup-uniform)
@@ -587,6 +591,15 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
     auto probe_item = [&](unsigned long long cu, int p, float pcx, float pcy) {
         int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
         float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
+        // (wave-uniform) an item names a patch of this region and K objects of the scene; anything else is refused and counted,
+        // never used as an address (the scene's tables are a few KB: an index of 4095 reads 128 KB past them)
+        bool item_ok = (unsigned)p < (unsigned)NAN_W;
+#pragma unroll
+        for (int d = 0; d < K; ++d) item_ok = item_ok && (int)((cu >> (12 * d)) & 0xfffull) < a.N;
+        if (!item_ok) {
+            n_bad += 1ull;
+            return;
+        }
 #pragma unroll
         for (int d = 0; d < K; ++d) {
             ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
@@ -602,14 +615,19 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
             for (int d = 0; d < K; ++d) atomicOr(&wallbits_all[p * nwords + (ce[d] >> 5)], 1u << (ce[d] & 31));
         }
     };
-    for (long long r0 = 0; r0 < nb; r0 += NAN_RB, ++round) {  // (workgroup-uniform)
+    for (long long r0 = 0; r0 < nb; r0 += rb, ++round) {  // (workgroup-uniform)
         int* const cnt_p = lcount + (round & 1);
         if (threadIdx.x == 0) *wqn = 0;  // (the previous round's queue was emptied before its last barrier)
-        // ---- region level: batch r0 + t * NAN_W + wv
+#ifdef D2D_NAN_QUEUE_R5
+        for (int i = threadIdx.x; i < NAN_WQCAP; i += 64 * NAN_W) wq[i] = ~0ull;  // (probe build: the sentinel; ordered by the barrier below)
+#endif
+        // ---- region level: batches [r0, r0 + rb) of the order, batch r0 + t * NAN_W + wv to wave wv: at most 64 rb <= NAN_LCAP
+        // survivors per round, the list cannot overflow
+        const long long r1 = (r0 + rb < nb) ? r0 + rb : nb;
 #pragma unroll 1
-        for (int t = 0; t < NAN_RB / NAN_W; ++t) {
+        for (int t = 0; t < (NAN_RB + NAN_W - 1) / NAN_W; ++t) {
             const long long id = r0 + (long long)t * NAN_W + wv;
-            if (id >= nb) break;
+            if (id >= r1) break;
             int pos[D2D_MAX_ORDER] = {0, 0, 0, 0};
             int chunk = 0;
             nan_decode_batch<K>(id, Nc, n_chunks, pos, chunk);
@@ -697,11 +715,19 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
                 n_probe += (unsigned long long)cnt;
                 if (cnt) {
                     // the probes of a region are dealt to ALL its waves (the patches a zero line crosses are few, and the slowest wave
-                    // of a region probed 1.45 - 1.7 x the average): (patch, candidate) items go to a queue of the workgroup ...
+                    // of a region probed 1.45 - 1.7 x the average): (patch, candidate) items go to a queue of the workgroup.  The
+                    // reservation is MONOTONE -- the counter only grows, no wave ever takes its claim back -- so that a slot below the
+                    // cap belongs to exactly one lane whatever the interleaving, and the slots below min(counter, cap) have all been
+                    // written once the barrier is passed.  (Round 5 reserved and rolled back when the queue was full: a successful
+                    // reservation between another wave's add and its subtraction left the final count covering slots nobody wrote.)
+#ifdef D2D_NAN_QUEUE_R5
+                    // PROBE BUILD ONLY (scripts/nan_queue_race.py): round 5's reserve-and-roll-back, kept to SHOW its race -- the
+                    // queue is filled with a sentinel every round (below), and a drained sentinel is a slot the final count covers
+                    // but nobody wrote; the item check in probe_item refuses it and counts it in stats[4].
                     int base = 0;
                     if (lane == 0) {
                         base = atomicAdd(wqn, cnt);
-                        if (base + cnt > NAN_WQCAP) {
+                        if (base + cnt > wqcap) {
                             atomicSub(wqn, cnt);
                             base = -1;
                         }
@@ -711,6 +737,17 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
                         if (alive) wq[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = code | ((unsigned long long)wv << 56);
                         mask = 0ull;
                     }
+                    n_self += (unsigned long long)__builtin_popcountll(mask);
+#else
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(wqn, cnt);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int slot = base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                    const bool queued = alive && slot < wqcap;
+                    if (queued) wq[slot] = code | ((unsigned long long)wv << 56);
+                    mask = __ballot(alive && !queued);
+                    n_self += (unsigned long long)__builtin_popcountll(mask);
+#endif
                 }
                 // ... unless it is full: then the wave probes its own
                 while (mask) {
@@ -726,7 +763,8 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
         __syncthreads();
         {
             // ---- the queue: item i to wave i mod NAN_W, the cells of the item's patch from LDS
-            const int nq = *wqn;
+            const int nq_all = *wqn;
+            const int nq = nq_all < wqcap ? nq_all : wqcap;  // (the counter keeps counting past the cap: those lanes probed their own)
             for (int i = wv; i < nq; i += NAN_W) {
                 const unsigned long long it = wq[i];
                 const int p = (int)(it >> 56);
@@ -830,7 +868,7 @@ __global__ void __launch_bounds__(64 * NAN_W, D2D_NAN_MIN_WAVES) nan_scan_region
     // a coordinate that is not comfortably finite anywhere in the region: no bound holds, every candidate is probed
     const bool force = sbad != 0;
     bool cell_nan = false, any_nan = false;
-    unsigned long long n_probe = 0ull;
+    unsigned long long n_probe = 0ull, n_self = 0ull, n_bad = 0ull;
     int round = 0;
     if (a.min_order <= 0 && a.max_order >= 0 && a.fun_id != D2D_FUN_ONE) {
         // order 0 has no scan, but its one segment has rule (3): px[0] = transmitter, px[1] = receiver
@@ -838,13 +876,13 @@ __global__ void __launch_bounds__(64 * NAN_W, D2D_NAN_MIN_WAVES) nan_scan_region
         any_nan = wave_any(cell_nan);
     }
     if (a.min_order <= 1 && a.max_order >= 1)
-        nan_region_order<1, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<1, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, n_self, n_bad);
     if (a.min_order <= 2 && a.max_order >= 2)
-        nan_region_order<2, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<2, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, n_self, n_bad);
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3)
-        nan_region_order<3, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<3, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, n_self, n_bad);
     if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4)
-        nan_region_order<4, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round);
+        nan_region_order<4, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, n_self, n_bad);
     {
         // what the region's probes found in this wave's patch (nan_region_order ends on a barrier)
         const unsigned long long cm = scellmask[wv];
@@ -881,6 +919,9 @@ __global__ void __launch_bounds__(64 * NAN_W, D2D_NAN_MIN_WAVES) nan_scan_region
         atomicAdd(&stats[0], n_probe);
         atomicAdd(&stats[1], (unsigned long long)__builtin_popcountll(flagged));
         if (any_nan && patch_exists) atomicAdd(&stats[2], 1ull);
+        atomicAdd(&stats[3], n_self);  // probes a wave made itself because the region's queue was full
+        atomicAdd(&stats[4], n_bad);   // queue items refused because they named no patch / object (must stay 0)
+        if (wv == 0) atomicAdd(&stats[5], (unsigned long long)round);  // rounds (list fills) of this region
     }
 }
 

@@ -306,9 +306,10 @@ class Context:
 
     def debug_nan_scan(self) -> dict:
         """Diagnostic: counters of the last value+grad launch's NaN scan (needs ``set_option("nan_scan_stats", 1)``)."""
-        o = np.zeros(3, np.int64)
+        o = np.zeros(6, np.int64)
         L.check(self._lib.d2d_debug_nan_scan(self._ctx, o))
-        return {"probes": int(o[0]), "nan_cells": int(o[1]), "nan_patches": int(o[2])}
+        return {"probes": int(o[0]), "nan_cells": int(o[1]), "nan_patches": int(o[2]), "self_probes": int(o[3]), "bad_items": int(o[4]),
+                "rounds": int(o[5])}
 
     def last_kernel_ms(self) -> float:
         """Duration of the sweep kernel of the last launch (needs ``set_option("time_kernel", 1)``)."""

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define D2D_MAX_ORDER 4 /* highest interaction order a sweep accepts */
-#define D2D_ABI_VERSION 9
+#define D2D_ABI_VERSION 10
 
 typedef enum d2d_status {
     D2D_OK = 0,
@@ -299,6 +299,9 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *                  "nan_scan_async": non-zero (default) = the scan runs BESIDE the sweep on a stream of its own and leaves flags
  *                  that a small kernel applies once both are through; zero = behind the sweep on the sweep's stream (same results)
  *                  "nan_scan_prio": priority of that stream, 0 (default) = lowest, 1 = highest (A/B: the highest is slower)
+ *                  "nan_scan_wqcap" / "nan_scan_rb": entries of a region's probe queue / batches per round of its list that the
+ *                  two-level scan USES (0 = default: all it has; tests set them small so that a full queue and a full list are the
+ *                  rule instead of a rare event -- same flags whatever the values)
  *   "comm_prio": priority of the stream the RCCL collectives run on beside the next sweep: -1 lowest, 0 (default) normal, 1 highest;
  *                  set it BEFORE the first collective (D2D_ERR_STATE afterwards)
  *   "sig_narrow_filter": sigmoid validity, forward sweeps: 1 (default) = the divide-free filter of the occlusion tests drops what is
@@ -347,8 +350,10 @@ int d2d_debug_get_schedule(d2d_ctx* ctx, int32_t* order, uint8_t* key, int64_t n
  * [4] / [5] / [6] entries of the leaf lists of order 2 / 3 / 4, [7] leaf regions.  Waits for the stream. */
 int d2d_debug_region_stats(d2d_ctx* ctx, int64_t* out /* [8] */);
 /* Counters of the last value+grad launch's NaN scan (option "nan_scan_stats" = 1; zeros otherwise): out[0] (patch, candidate)
- * pairs whose backward scan was probed cell by cell, [1] cells flagged NaN, [2] patches with a flagged cell.  Waits for the stream. */
-int d2d_debug_nan_scan(d2d_ctx* ctx, int64_t* out /* [3] */);
+ * pairs whose backward scan was probed cell by cell, [1] cells flagged NaN, [2] patches with a flagged cell; two-level scan only:
+ * [3] probes a wave made itself because its region's queue was full, [4] queue items refused because they named no patch of the
+ * region or no object of the scene (an internal error: always 0), [5] rounds of the regions' lists.  Waits for the stream. */
+int d2d_debug_nan_scan(d2d_ctx* ctx, int64_t* out /* [6] */);
 
 /* The work history behind the schedule: what each of the n patches took in the last culled sweep (units of ~25
  * wave-instructions, counted by the kernels). */

@@ -1,6 +1,6 @@
 """ctypes binding of libd2d.so (MI355X fused power-map sweep) -- the file a DiffeRT2d maintainer drops into the
 reference as ``differt2d/_d2d.py``.  It depends on ``ctypes`` and NumPy only and mirrors
-``include/d2d.h`` (ABI version 9); ``tests/test_gpu_integration.py`` imports THIS file and checks it against the
+``include/d2d.h`` (ABI version 10); ``tests/test_gpu_integration.py`` imports THIS file and checks it against the
 repository's own engine.
 
 The library is found through ``$DIFFERT2D_LIBD2D`` (default: ``libd2d.so`` on the loader path).
@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-D2D_ABI_VERSION = 9
+D2D_ABI_VERSION = 10
 D2D_GRID_RX, D2D_GRID_TX = 0, 1
 D2D_OUT_OVERWRITE, D2D_OUT_ADD = 0, 1
 D2D_FUN_RECEIVED_POWER = 0

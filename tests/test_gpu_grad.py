@@ -150,6 +150,80 @@ def test_culled_and_strict_gradients_agree_on_a_larger_grid(ctx):
             np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-6 * np.abs(b[k]).max())
 
 
+def _same_flags_and_gradients(a, b, tag):
+    assert np.array_equal(a["value"], b["value"], equal_nan=True), tag
+    for k in ("grad_rx", "tx_bar", "walls_bar"):
+        assert np.array_equal(np.isnan(a[k]), np.isnan(b[k])), f"{tag}: NaN positions of {k} differ"
+    fin = ~np.isnan(b["grad_rx"])
+    assert np.array_equal(a["grad_rx"][fin], b["grad_rx"][fin]), tag
+    for k in ("tx_bar", "walls_bar"):
+        f2 = ~np.isnan(b[k])
+        if f2.any():
+            np.testing.assert_allclose(a[k][f2], b[k][f2], rtol=1e-5, atol=1e-6 * float(np.abs(b[k][f2]).max()), err_msg=f"{tag}: {k}")
+
+
+def test_nan_scan_with_a_full_queue_and_a_full_list():
+    """The region scan's two bounded buffers -- the list of a round's survivors and the queue its probes are dealt through -- are
+    sized so that they rarely fill; here they are made tiny ("nan_scan_wqcap" = 64 items instead of 2048, "nan_scan_rb" = 2
+    batches = 128 list entries per round instead of 2048) so that a FULL queue and many rounds are the rule.  Round 5's queue took
+    a reservation back when it was full and could then count slots nobody had written (the driver's GPU suite aborted in
+    test_culled_and_strict_gradients_agree_on_a_larger_grid); the reservation is monotone now, every decoded item is
+    checked before it addresses anything, and this test holds both: the counters say the queue overflowed (self_probes > 0), no
+    item was ever refused (bad_items == 0), and the flags / gradients equal the exhaustive kernel's -- on the scene that aborted, on
+    coarse and crowded ones (50 - 200 walls on 16^2 .. 128^2 cells: a region is a large part of the scene, nearly every candidate
+    survives its box test), on lattice scenes where exact zeros are common, in both grid roles, launch after launch on one
+    context (and after a small grid on the same context, the order of the suite that aborted)."""
+    from differt2d_amd import _lib as L
+    from differt2d_amd.engine import Context
+
+    rng = np.random.default_rng(2)
+    with Context(0) as c:
+        c.set_option("nan_scan_stats", 1)
+        overflowed = nan_cells = 0
+        for caps in ((64, 2), (1, 1), (0, 0)):  # tiny, degenerate (one queue slot, one batch per round), the product's sizes
+            c.set_option("nan_scan_wqcap", caps[0])
+            c.set_option("nan_scan_rb", caps[1])
+            # (a small grid first: the launch order of the suite that aborted)
+            tx, walls = random_scene(10, seed=17)
+            X, Y = unit_grid(19, 13)
+            c.set_scene(walls)
+            c.value_and_grads(tx, X, Y, max_order=2, approx=True)
+            for nw, g, seed in ((50, 128, 1234), (50, 32, 1234), (120, 64, 7), (200, 16, 9)):
+                tx, walls = random_scene(nw, seed=seed)
+                X, Y = unit_grid(g)
+                c.set_scene(walls)
+                for role in (L.GRID_RX, L.GRID_TX):
+                    for approx in (False, True):
+                        if caps == (1, 1) and (nw > 50 or g > 32):
+                            continue  # (one batch per round: thousands of barriers per region; the small case is enough)
+                        kw = dict(min_order=0, max_order=2, approx=approx, grid_role=role)
+                        b = c.value_and_grads(tx, X, Y, strict_nan=True, **kw)
+                        for rep in range(3 if caps[0] else 1):
+                            a = c.value_and_grads(tx, X, Y, strict_nan=False, **kw)
+                            st = c.debug_nan_scan()
+                            assert st["bad_items"] == 0, (caps, nw, g, role, approx, st)
+                            if caps[0]:
+                                overflowed += int(st["self_probes"] > 0)
+                            _same_flags_and_gradients(a, b, f"caps {caps}, {nw} walls, {g}^2, role {role}, approx {approx}, launch {rep}")
+            # lattice scenes: exact zeros in the backward scan are common (NaN cells to find)
+            for case in range(8):
+                n = int(rng.integers(4, 12))
+                walls = (np.round(rng.random((n, 2, 2)) * 4) / 4).astype(F)
+                walls[(walls[:, 0] == walls[:, 1]).all(-1)] += F(0.125)
+                tx = (np.round(rng.random(2) * 8) / 8).astype(F)
+                xs = np.linspace(0, 1, int(rng.integers(17, 66))).astype(F)
+                X, Y = np.meshgrid(xs, xs)
+                c.set_scene(walls)
+                kw = dict(min_order=0, max_order=2, approx=bool(case % 2), grid_role=L.GRID_TX if case % 4 >= 2 else L.GRID_RX)
+                b = c.value_and_grads(tx, X, Y, strict_nan=True, **kw)
+                a = c.value_and_grads(tx, X, Y, strict_nan=False, **kw)
+                assert c.debug_nan_scan()["bad_items"] == 0
+                _same_flags_and_gradients(a, b, f"caps {caps}, lattice case {case}")
+                nan_cells += int(np.isnan(b["grad_rx"]).any(-1).sum())
+        print(f"launches with a full queue: {overflowed}; NaN cells compared on the lattice scenes: {nan_cells}")
+        assert overflowed >= 40 and nan_cells > 100
+
+
 def test_value_and_grad_in_a_scene_of_2000_walls(ctx):
     """The value+grad kernels with 128 KB of tables and adjoint tables in LDS (2 000 short walls; tests/test_gpu_forward.py has the
     forward sweep): orders 0..1 over all walls, both grid roles -- the culled sweep against the exhaustive kernel (values and
