@@ -1191,7 +1191,9 @@ __device__ __forceinline__ void eval_candidate(const SweepArgs& a, const int (&c
                     tie = occ && hit2 == hit_c && hit_c < 6.0f;
                 } else {
                     vmax = sigmoidf_(hit_z);
-                    tie = occ && vmax < 1.0f && sigmoidf_(hit2) == vmax;
+                    // (... and so have tests that tie at a value saturated to exactly 0 -- hit2 starts at -3e38, sigmoid 0: without
+                    // the lower guard an unoccluded lane whose only test rounds to 0 sent its wave through both passes for nothing)
+                    tie = occ && vmax < 1.0f && vmax > 0.0f && sigmoidf_(hit2) == vmax;
                 }
             }
             if (wave_any(tie)) {

@@ -327,7 +327,16 @@ _FUNCTIONS = {
     np.zeros_like: lambda x, **kw: np.zeros_like(_val(x), **kw),
     np.ones_like: lambda x, **kw: np.ones_like(_val(x), **kw),
     np.diff: lambda x, n=1, axis=-1: _diff(x, n, axis),
+    np.dot: lambda a, b: _dot_1d(a, b),
+    np.vdot: lambda a, b: _dot_1d(a, b),
 }
+
+
+def _dot_1d(a, b):
+    """``np.dot`` of scalars / vectors (what an objective of ``optimize.minimize`` uses: ``jnp.dot(x, x)``)."""
+    if np.ndim(_val(a)) > 1 or np.ndim(_val(b)) > 1:
+        raise TapeError("np.dot of matrices is not recorded; write it with * and sum")
+    return _sum(_as_tape(a) * b)
 
 
 def _diff(x, n, axis):

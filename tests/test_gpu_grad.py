@@ -325,7 +325,7 @@ def test_cfg3_full_map_nan_positions_equal_the_exhaustive_kernels(role, mode):
 @pytest.mark.parametrize("mode", ["hard", "hsig", "sigmoid"])
 @pytest.mark.parametrize("role", ["rx", "tx"])
 def test_cfg3_rows_against_the_c_gradient_oracle(role, mode):
-    """An independent checker at FULL size: every one of the 1024 rows of configs[2] (1 048 576 cells; TX grids every fourth row;
+    """An independent checker at FULL size: every second row of configs[2] and the 64 rows around the fixed end point (557 056 cells; TX grids every fourth row;
     sigmoid, whose oracle costs 6x as much per row: 32 / 16 rows around the fixed end point) against oracle/d2d_oracle_grad.c -- forward-mode dual
     numbers through the C oracle's op chain, no adjoint code, nothing shared with the kernels (validated against reverse-mode
     autodiff of oracle/ref.py in tests/test_oracle_grad_c.py) -- computed live on the host cores.  The GPU runs its DEFAULT
@@ -349,9 +349,11 @@ def test_cfg3_rows_against_the_c_gradient_oracle(role, mode):
     if mode == "sigmoid":
         rows = np.arange(i0 + 16, i0 + 48) if role == "rx" else np.arange(i0 + 24, i0 + 40)
     elif role == "rx":
-        rows = np.arange(1024)
+        # (every second row + the 64 rows around the fixed end point: 544 rows; scripts/diag_rows.py <role> <mode> all runs all 1 024,
+        # profiles/r06_parity_runs.txt -- the whole -m gpu suite has 900 s on the driver's box)
+        rows = np.unique(np.concatenate([np.arange(i0, i0 + 64), np.arange(0, 1024, 2)]))
     else:
-        rows = np.unique(np.concatenate([np.arange(i0, i0 + 64), np.arange(0, 1024, 4)]))
+        rows = np.unique(np.concatenate([np.arange(i0, i0 + 64), np.arange(0, 1024, 4), [197, 439]]))  # (197, 439: the tie cells of round 5's full-map run)
     at = int(np.searchsorted(rows, i0 + 31))  # two rows next to the fixed end point, by position in `rows`
     with Context(0) as c:
         c.set_scene(walls)
@@ -371,40 +373,61 @@ def test_cfg3_rows_against_the_c_gradient_oracle(role, mode):
     rel = 3e-4 if mode == "sigmoid" else 1e-5
     bar = rel * gabs[..., None] + rel * np.abs(grad) + 1e-6 * rowscale
     worst = float(np.nanmax(np.where(fin, err / bar, 0.0)))
-    # the oracle's shortcut (prune) against its plain evaluation on two rows next to the fixed end point: the same values, the
-    # same NaN cells, and the same gradients wherever no min / max met a tie between arguments of different derivative (the
-    # shortcut stops at the first occluder saturated to exactly 1; a later one ALSO at exactly 1 with a non-zero derivative
-    # would take half of it under JAX's tie rule -- the culled kernels stop the same way, DESIGN.md "known deviation")
-    sub = np.arange(at, at + 2)
-    v0, g0, kink = CO.power_map_grad(walls, tx, X[rows[sub]], Y[rows[sub]], min_order=0, max_order=2, prune=0,
+    # The checker must not share the kernels' shortcut.  `prune = 1` stops a candidate's occlusion fold at the
+    # first occluder saturated to exactly 1 -- as the culled kernels do; the PLAIN oracle (prune = 0) follows every fold of every
+    # candidate, JAX's tie rule included.  It runs (a) on whole rows spread over the map -- the two rows next to the fixed end
+    # point, the rows round 5's full-map diagnostic named (TX hard_sigmoid: 197, 439) and a dozen more -- where the GPU is
+    # compared with it DIRECTLY, and (b) on every cell of the full comparison that is beyond the bar.
+    plain_rows = np.unique(np.concatenate([rows[at:at + 2], rows[np.isin(rows, [197, 439])],
+                                           rows[np.linspace(0, rows.size - 1, 2 if mode == "sigmoid" else 8).astype(int)]]))
+    sub = np.searchsorted(rows, plain_rows)
+    v0, g0, kink = CO.power_map_grad(walls, tx, X[plain_rows], Y[plain_rows], min_order=0, max_order=2, prune=0,
                                      grid_role=role, with_kink=True, **kw)
     assert np.array_equal(v0, value[sub]) and np.array_equal(np.isnan(g0), np.isnan(grad[sub]))
     smooth = ~kink.astype(bool)[..., None].repeat(2, -1)
-    assert (np.nan_to_num(np.abs(g0 - grad[sub])) <= bar[sub])[smooth].all()
-    assert (np.nan_to_num(np.abs(g0 - g[sub])) <= bar[sub])[smooth].all()
+    assert (np.nan_to_num(np.abs(g0 - grad[sub])) <= bar[sub])[smooth].all(), "the oracle's shortcut changes a gradient away from a tie"
+    d_plain = np.nan_to_num(np.abs(g0 - g[sub]))
+    plain_over = np.argwhere(((d_plain > bar[sub]) & ~np.isnan(g0)).any(-1))
+    # ... on those rows the GPU may differ from the plain oracle beyond the bar only in a cell where the oracle itself met a tie of
+    # a minimum / maximum between arguments of different derivative (the known deviation, DESIGN.md K2 "Ties": a candidate that
+    # culling never evaluates, hidden by an occluder saturated to exactly 1, while another occluder sits exactly on a kink of relu6)
+    not_tie = [(int(plain_rows[r_]), int(c_)) for r_, c_ in plain_over if not kink[r_, c_]]
     lit = gabs > 0
-    # Cells beyond that bar (a handful in a million) are held to the oracle's own conditioning instead: the oracle is run
-    # again on those cells with the cell and the fixed end point moved by ONE ulp either way, and the GPU must sit within
-    # twice the largest change that makes to the oracle's gradient (a reflection point next to a wall's end: the activation's
-    # slope alpha / 6 multiplies every rounding of the point; no fp32 evaluation order is pinned tighter than its inputs).
+    # Cells of the FULL comparison beyond the plain bar (a handful in a million): each is given to the plain oracle on its own.
+    #   * the GPU within the bar of the plain oracle: the shortcut was off, not the GPU;
+    #   * else a tie cell of the plain oracle: the known deviation, counted and reported (cfg3: RX 3 cells, TX hard_sigmoid 2);
+    #   * else the oracle's own conditioning: the oracle again with the cell and the fixed end point moved by ONE ulp either way --
+    #     the GPU must sit within twice the largest change that makes to the oracle's gradient (a reflection point next to a wall's
+    #     end: the activation's slope alpha / 6 multiplies every rounding of the point; no fp32 evaluation order is pinned tighter
+    #     than its inputs);  anything else fails the test.
     over = np.argwhere((fin & (err > bar)).any(-1))
-    assert len(over) <= 64, f"{len(over)} cells beyond the plain bar, worst {worst:.2f} x"
-    n_tie_over = int(tie[tuple(over.T)].sum()) if len(over) else 0
+    assert len(over) <= 16, f"{len(over)} cells beyond the plain bar, worst {worst:.2f} x"
+    n_tie_over = n_plain_ok = 0
     unexplained = []
     for r_, c_ in over:
         Xc, Yc = X[rows[r_]:rows[r_] + 1, c_:c_ + 1], Y[rows[r_]:rows[r_] + 1, c_:c_ + 1]
+        _, gp, kp = CO.power_map_grad(walls, tx, Xc, Yc, min_order=0, max_order=2, prune=0, grid_role=role, with_kink=True, **kw)
+        if (np.nan_to_num(np.abs(gp[0, 0] - g[r_, c_])) <= bar[r_, c_]).all():
+            n_plain_ok += 1
+            continue
+        if kp[0, 0]:
+            n_tie_over += 1
+            continue
         sens = np.zeros(2)
         for dx, dy, dt in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
             nudge = lambda a, d: np.nextafter(np.asarray(a, F), F(np.inf * d)) if d else np.asarray(a, F)  # noqa: E731
-            _, g2 = CO.power_map_grad(walls, nudge(tx, dt), nudge(Xc, dx), nudge(Yc, dy), min_order=0, max_order=2, prune=1,
+            _, g2 = CO.power_map_grad(walls, nudge(tx, dt), nudge(Xc, dx), nudge(Yc, dy), min_order=0, max_order=2, prune=0,
                                       grid_role=role, **kw)
-            sens = np.maximum(sens, np.nan_to_num(np.abs(g2[0, 0] - grad[r_, c_]), nan=np.inf))
-        if (err[r_, c_] > bar[r_, c_] + 2.0 * sens).any():
-            unexplained.append((int(rows[r_]), int(c_), g[r_, c_].tolist(), grad[r_, c_].tolist(), sens.tolist()))
-    print(f"{role} {mode}: {rows.size} rows, {int(lit.sum())} cells with a path, {int(np.isnan(grad).any(-1).sum())} NaN cells, "
-          f"{int(kink.sum())} tie cells of {kink.size} on the 2 plain rows, worst error / bar {worst:.3f}; max |grad| {float(np.nanmax(np.abs(grad))):.3e}; "
-          f"{len(over)} cells beyond the plain bar ({n_tie_over} of them cells where the oracle met a min / max tie), {len(unexplained)} "
-          f"of them beyond the oracle's one-ulp sensitivity")
+            sens = np.maximum(sens, np.nan_to_num(np.abs(g2[0, 0] - gp[0, 0]), nan=np.inf))
+        if (np.abs(gp[0, 0] - g[r_, c_]) > bar[r_, c_] + 2.0 * sens).any():
+            unexplained.append((int(rows[r_]), int(c_), g[r_, c_].tolist(), gp[0, 0].tolist(), sens.tolist()))
+    print(f"{role} {mode}: {rows.size} rows, {int(lit.sum())} cells with a path, {int(np.isnan(grad).any(-1).sum())} NaN cells, worst error / bar "
+          f"{worst:.3f}; max |grad| {float(np.nanmax(np.abs(grad))):.3e}; plain oracle (prune = 0) on {plain_rows.size} whole rows: "
+          f"{int(kink.sum())} tie cells of {kink.size}, {len(plain_over)} cells where the GPU is beyond the bar ({len(plain_over) - len(not_tie)} of them tie cells); "
+          f"full comparison: {len(over)} cells beyond the bar -- {n_plain_ok} within the bar of the plain oracle, {n_tie_over} tie cells of the "
+          f"plain oracle (the known deviation), {len(unexplained)} beyond the plain oracle's one-ulp sensitivity")
+    assert not not_tie, f"GPU beyond the bar of the plain oracle away from any tie: {not_tie[:5]}"
+    assert n_tie_over + (len(plain_over) - len(not_tie)) <= 8
     assert lit.sum() > 10000
     assert not unexplained, unexplained[:5]
 

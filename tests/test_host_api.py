@@ -255,3 +255,75 @@ def test_recognised_path_functions_follow_their_free_variables():
     assert _native_fun(power, (), None) is None
     cfg["n"] = 2  # a negative verdict is kept: the host route is always correct
     assert _native_fun(power, (), None) is None
+
+
+# ---- optimize.minimize* as callables (reference optimize.py:44-182; known answers: tests/test_optimize.py:27-74 + doctests) ------
+def _convex_fun(x):
+    x = x - 0.5
+    return np.dot(x, x) + 2.0
+
+
+@pytest.mark.parametrize("x0,expected_x,expected_loss", [(0.0, 0.5, 2.0), (0.5, 0.5, 2.0), ([1.0, 2.0, 3.0], [0.5, 0.5, 0.5], 2.0)])
+def test_minimize_known_answers_of_the_reference(x0, expected_x, expected_loss):
+    from differt2d_amd.optimize import minimize
+
+    x0 = np.atleast_1d(np.asarray(x0, np.float32))
+    got_x, got_loss = minimize(_convex_fun, x0, steps=1000)
+    assert got_x.shape == x0.shape and got_x.dtype == np.float32 and np.shape(got_loss) == ()
+    np.testing.assert_allclose(got_x, np.atleast_1d(expected_x), rtol=1e-3)
+    np.testing.assert_allclose(got_loss, expected_loss, rtol=1e-3)
+
+
+@pytest.mark.parametrize("expected_x,expected_loss", [(0.5, 2.0), ([0.5, 0.5, 0.5], 2.0)])
+def test_minimize_random_uniform_variants_known_answers_of_the_reference(expected_x, expected_loss, seed):
+    from differt2d_amd.optimize import minimize_many_random_uniform, minimize_random_uniform
+    from differt2d_amd.random import PRNGKey
+
+    expected_x = np.atleast_1d(np.asarray(expected_x, np.float32))
+    for f in (minimize_random_uniform, minimize_many_random_uniform):
+        got_x, got_loss = f(_convex_fun, n=len(expected_x), key=PRNGKey(seed), steps=1000)
+        assert got_x.shape == expected_x.shape
+        np.testing.assert_allclose(got_x, expected_x, rtol=1e-3)
+        np.testing.assert_allclose(got_loss, expected_loss, rtol=1e-3)
+
+
+def test_minimize_follows_the_oracles_adam_and_the_reference_conventions():
+    """The update rule is the one oracle/ref.py:616-638 restates from optax (and the solver kernels follow): the same iterates bit
+    for bit on an objective whose gradient is exact in fp32; the returned loss is the one evaluated BEFORE the last update
+    (optimize.py:86-97); args are passed through; a user-supplied value_and_grad is used; other optimisers are refused."""
+    from differt2d_amd import _lib as L
+    from differt2d_amd.optimize import adam, minimize
+    from oracle import ref as R
+
+    def f(x, offset=1.0):
+        x = x - offset
+        return np.dot(x, x)
+
+    x0 = np.array([0.25, -1.5, 3.0], np.float32)
+    for steps in (1, 2, 7, 60):
+        for hyper in (dict(), dict(learning_rate=0.03, b1=0.8, b2=0.99, eps=1e-6)):
+            got_x, got_loss = minimize(f, x0, args=(2.0,), steps=steps, optimizer=adam(**hyper) if hyper else None)
+            vg = lambda xs: (np.float32(np.dot(xs[0] - np.float32(2.0), xs[0] - np.float32(2.0))), [np.float32(2.0) * (xs[0] - np.float32(2.0))])  # noqa: E731
+            kw = {("lr" if k == "learning_rate" else k): v for k, v in hyper.items()}
+            want_x, want_loss = R.adam_minimize(vg, [x0.copy()], steps=steps, **kw)
+            assert np.array_equal(got_x, want_x[0]), (steps, hyper)
+            np.testing.assert_allclose(got_loss, want_loss, rtol=1e-6)  # (the sum inside np.dot has its own order)
+    # loss of the LAST EVALUATION, not of the returned x
+    x1, l1 = minimize(f, x0, steps=1)
+    np.testing.assert_allclose(l1, np.dot(x0 - 1, x0 - 1), rtol=1e-6)
+    assert not np.array_equal(x1, x0)
+
+    class WithGrad:
+        calls = 0
+
+        def __call__(self, x):
+            raise AssertionError("value_and_grad must be preferred")
+
+        def value_and_grad(self, x):
+            WithGrad.calls += 1
+            return np.dot(x - 0.5, x - 0.5), 2 * (x - 0.5)
+
+    xg, _ = minimize(WithGrad(), np.zeros(2, np.float32), steps=300)
+    assert WithGrad.calls == 300 and np.allclose(xg, 0.5, rtol=1e-2)
+    with pytest.raises(L.D2DUnsupported):
+        minimize(f, x0, optimizer=object())
