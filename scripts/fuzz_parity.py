@@ -61,6 +61,37 @@ def random_case(rng, big=False):
     return walls, tx, X, Y, kw, allowed
 
 
+def crowded_case(rng, budget=None):
+    """Coarse and crowded (VERDICT r5 item 1 d): 50 .. 200 walls under a grid of 16^2 .. 128^2 cells, orders <= 2.  A region of the
+    NaN scan (4 x 4 patches) is then a large part of the scene: nearly every candidate survives its box tests, the region's list
+    takes many rounds and its probe queue overflows -- the regime of the round-5 abort, which no fuzz class reached (<= 25 walls;
+    `big` scenes only in the forward fuzz).  Half the cases snap end points to a lattice (exact zeros in the backward scan: NaN
+    cells to find).  budget: upper bound of cells x candidates (the gradient oracle's time)."""
+    n = int(rng.integers(50, 201))
+    g = int(rng.choice([16, 24, 32, 48, 64, 96, 128]))
+    max_order = 2 if rng.random() < 0.75 else 1
+    if budget is not None:
+        C = 1 + n + (n * (n - 1) if max_order == 2 else 0)
+        while g > 8 and g * g * C > budget:
+            g //= 2
+    pts = rng.random((2 * n + 1, 2), dtype=F)
+    walls = pts[1:].reshape(n, 2, 2).copy()
+    if rng.random() < 0.5:
+        m = rng.random(walls.shape) < 0.4
+        walls = np.where(m, np.round(walls * 8) / 8, walls).astype(F)
+        walls[(walls[:, 0] == walls[:, 1]).all(-1)] += F(0.0625)
+    tx = pts[0].copy()
+    if rng.random() < 0.3:
+        tx = (np.round(tx * 8) / 8).astype(F)
+    gy = g if rng.random() < 0.6 else max(1, int(rng.integers(g // 2, g + 1)))
+    X, Y = np.meshgrid(np.linspace(0.0, 1.0, g).astype(F), np.linspace(0.0, 1.0, gy).astype(F))
+    mode = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")][int(rng.integers(0, 3))]
+    kw = dict(min_order=int(rng.integers(0, 2)), max_order=max_order, approx=mode[0], function=mode[1],
+              alpha=float(rng.choice([100.0, 50.0])), tol=1e-2, patch=0.0,
+              fun=str(rng.choice(["received_power", "one", "length", "length_squared"])), height=0.1)
+    return walls, tx, X, Y, kw, None
+
+
 def grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=False):
     """One value+grad case against the C gradient oracle (forward-mode duals, nothing shared with the kernels' adjoint).
     Returns (list of complaints, cells whose gradient was compared, NaN cells).  Values: bit for bit (sigmoid: rtol 1e-6);
@@ -146,17 +177,22 @@ def main_grad(argv):
     t0 = time.time()
     with Context(0) as ctx:
         for case in range(n_cases):
+            crowded = case % 8 == 7  # (coarse and crowded: the NaN scan's queue and list full; the oracle held to ~1 s per case)
             while True:
-                walls, tx, X, Y, kw, allowed = random_case(rng)
+                walls, tx, X, Y, kw, allowed = crowded_case(rng, budget=3e7) if crowded else random_case(rng)
                 if len(walls):
                     break
             if kw["max_order"] == 3 and X.size > 1600:  # (the oracle's order-3 duals: keep a case under a second)
                 X, Y = X[:40, :40], Y[:40, :40]
-            kw["fun"] = str(rng.choice(["received_power", "one", "length", "length_squared"]))
+            if not crowded:
+                kw["fun"] = str(rng.choice(["received_power", "one", "length", "length_squared"]))
             role = L.GRID_TX if case % 3 == 2 else L.GRID_RX
             ctx.set_scene(walls)
             ctx.set_candidate_mask(allowed)
             ctx.set_option("nan_scan", 2 if case % 5 == 4 else 1)
+            # (the region scan's buffers at their product sizes, or tiny: a full queue and a full list are then the rule)
+            ctx.set_option("nan_scan_wqcap", 64 if case % 16 == 15 else 0)
+            ctx.set_option("nan_scan_rb", 2 if case % 16 == 15 else 0)
             ctx.set_option("sched_min_tiles", 1 if case % 4 < 2 else 1 << 40)
             msgs, c, n = grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=case % 4 == 3)
             cells += c

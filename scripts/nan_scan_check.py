@@ -4,7 +4,7 @@ full size -- NaN positions of the per-cell gradient, of tx_bar and of walls_bar,
 every validity mode, with the scan's counters and the kernels' times; then N random lattice-snapped scenes (fuzz_parity's
 generator), where exact zeros are common.
 
-    python scripts/nan_scan_check.py [n_fuzz_cases] [seed] [--no-full]
+    python scripts/nan_scan_check.py [n_fuzz_cases] [seed] [--no-full] [--crowded]
 """
 import os
 import sys
@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from conftest import random_scene  # noqa: E402
-from fuzz_parity import random_case  # noqa: E402
+from fuzz_parity import crowded_case, random_case  # noqa: E402
 
 from differt2d_amd import _lib as L  # noqa: E402
 from differt2d_amd.engine import Context, make_params  # noqa: E402
@@ -96,7 +96,7 @@ def full_size():
     return total
 
 
-def fuzz(n_cases, seed):
+def fuzz(n_cases, seed, crowded_only=False):
     rng = np.random.default_rng(seed)
     bad = 0
     done = 0
@@ -104,10 +104,15 @@ def fuzz(n_cases, seed):
     t0 = time.time()
     with Context(0) as ctx:
         while done < n_cases:
-            walls, tx, X, Y, kw, allowed = random_case(rng)
+            # every fourth case (--crowded: every case) is coarse and crowded -- 50 .. 200 walls under 16^2 .. 128^2 cells: the region
+            # scan's list takes many rounds and its probe queue overflows; every eighth runs with tiny buffers on top
+            crowded = crowded_only or done % 4 == 3
+            walls, tx, X, Y, kw, allowed = crowded_case(rng) if crowded else random_case(rng)
             if len(walls) == 0:
                 continue
             role = L.GRID_TX if done % 3 == 2 else L.GRID_RX
+            ctx.set_option("nan_scan_wqcap", 64 if done % 8 == 7 else 0)
+            ctx.set_option("nan_scan_rb", 2 if done % 8 == 7 else 0)
             ctx.set_option("region_lists", 0 if done % 7 == 6 else 1)
             ctx.set_option("nan_scan", 2 if done % 5 == 4 else 1)  # (one wave per patch / two levels: the same flags)
             ctx.set_option("sched_min_tiles", 1 if done % 4 < 2 else 1 << 40)
@@ -133,7 +138,7 @@ def main():
     if "--no-full" not in sys.argv:
         bad += full_size()
     if n > 0:
-        bad += fuzz(n, seed)
+        bad += fuzz(n, seed, crowded_only="--crowded" in sys.argv)
     print("nan_scan_check:", "OK" if bad == 0 else f"{bad} FAILURES")
     return 1 if bad else 0
 

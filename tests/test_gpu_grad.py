@@ -384,10 +384,10 @@ def test_cfg3_rows_against_the_c_gradient_oracle(role, mode):
     v0, g0, kink = CO.power_map_grad(walls, tx, X[plain_rows], Y[plain_rows], min_order=0, max_order=2, prune=0,
                                      grid_role=role, with_kink=True, **kw)
     assert np.array_equal(v0, value[sub]) and np.array_equal(np.isnan(g0), np.isnan(grad[sub]))
-    smooth = ~kink.astype(bool)[..., None].repeat(2, -1)
-    assert (np.nan_to_num(np.abs(g0 - grad[sub])) <= bar[sub])[smooth].all(), "the oracle's shortcut changes a gradient away from a tie"
-    d_plain = np.nan_to_num(np.abs(g0 - g[sub]))
-    plain_over = np.argwhere(((d_plain > bar[sub]) & ~np.isnan(g0)).any(-1))
+    smooth = ~kink.astype(bool)[..., None].repeat(2, -1) & ~np.isnan(g0)  # (NaN cells: positions compared above, the bar is NaN there)
+    assert not (np.abs(g0 - grad[sub]) > bar[sub])[smooth].any(), "the oracle's shortcut changes a gradient away from a tie"
+    with np.errstate(invalid="ignore"):
+        plain_over = np.argwhere(((np.abs(g0 - g[sub]) > bar[sub]) & ~np.isnan(g0)).any(-1))
     # ... on those rows the GPU may differ from the plain oracle beyond the bar only in a cell where the oracle itself met a tie of
     # a minimum / maximum between arguments of different derivative (the known deviation, DESIGN.md K2 "Ties": a candidate that
     # culling never evaluates, hidden by an occluder saturated to exactly 1, while another occluder sits exactly on a kink of relu6)
@@ -427,7 +427,8 @@ def test_cfg3_rows_against_the_c_gradient_oracle(role, mode):
           f"full comparison: {len(over)} cells beyond the bar -- {n_plain_ok} within the bar of the plain oracle, {n_tie_over} tie cells of the "
           f"plain oracle (the known deviation), {len(unexplained)} beyond the plain oracle's one-ulp sensitivity")
     assert not not_tie, f"GPU beyond the bar of the plain oracle away from any tie: {not_tie[:5]}"
-    assert n_tie_over + (len(plain_over) - len(not_tie)) <= 8
+    # (the known deviation, measured: scripts/plain_vs_pruned_oracle.py, profiles/r06_parity_runs.txt -- a fraction of a cell per row)
+    assert n_tie_over <= 8 and len(plain_over) - len(not_tie) <= 4 * plain_rows.size
     assert lit.sum() > 10000
     assert not unexplained, unexplained[:5]
 
