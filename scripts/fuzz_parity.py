@@ -61,7 +61,7 @@ def random_case(rng, big=False):
     return walls, tx, X, Y, kw, allowed
 
 
-def crowded_case(rng, budget=None):
+def crowded_case(rng, budget=None, sigmoid=True):
     """Coarse and crowded (VERDICT r5 item 1 d): 50 .. 200 walls under a grid of 16^2 .. 128^2 cells, orders <= 2.  A region of the
     NaN scan (4 x 4 patches) is then a large part of the scene: nearly every candidate survives its box tests, the region's list
     takes many rounds and its probe queue overflows -- the regime of the round-5 abort, which no fuzz class reached (<= 25 walls;
@@ -85,14 +85,14 @@ def crowded_case(rng, budget=None):
         tx = (np.round(tx * 8) / 8).astype(F)
     gy = g if rng.random() < 0.6 else max(1, int(rng.integers(g // 2, g + 1)))
     X, Y = np.meshgrid(np.linspace(0.0, 1.0, g).astype(F), np.linspace(0.0, 1.0, gy).astype(F))
-    mode = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")][int(rng.integers(0, 3))]
+    mode = [(False, "hard_sigmoid"), (True, "hard_sigmoid"), (True, "sigmoid")][int(rng.integers(0, 3 if sigmoid else 2))]
     kw = dict(min_order=int(rng.integers(0, 2)), max_order=max_order, approx=mode[0], function=mode[1],
               alpha=float(rng.choice([100.0, 50.0])), tol=1e-2, patch=0.0,
               fun=str(rng.choice(["received_power", "one", "length", "length_squared"])), height=0.1)
     return walls, tx, X, Y, kw, None
 
 
-def grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=False):
+def grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=False, prune=0):
     """One value+grad case against the C gradient oracle (forward-mode duals, nothing shared with the kernels' adjoint).
     Returns (list of complaints, cells whose gradient was compared, NaN cells).  Values: bit for bit (sigmoid: rtol 1e-6);
     NaN positions: identical; finite gradients: within 1e-5 of the cell's gradient scale (+ 1e-5 relative; sigmoid 3e-4: at
@@ -101,7 +101,9 @@ def grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=False):
     result survives a one-ulp nudge of the fixed end point and of the cell (scenes snapped to a lattice put end points on
     walls' lines, where the interaction points are rounding noise for ANY two fp32 evaluation orders)."""
     role_s = "tx" if role == L.GRID_TX else "rx"
-    okw = dict(kw, grid_role=role_s, allowed=allowed)
+    # prune = 0 (default): the PLAIN oracle -- every fold of every candidate; prune = 1 (the crowded class only: 20 000 candidates of
+    # 150 segment tests per cell in duals are minutes per case): its exact shortcuts
+    okw = dict(kw, grid_role=role_s, allowed=allowed, prune=prune)
     value, grad, gabs, kink = CO.power_map_grad(walls, tx, X, Y, with_gabs=True, with_kink=True, **okw)
     up = lambda a: np.nextafter(np.asarray(a, F), F(np.inf))
     stable = np.ones(X.shape, bool)
@@ -179,7 +181,7 @@ def main_grad(argv):
         for case in range(n_cases):
             crowded = case % 8 == 7  # (coarse and crowded: the NaN scan's queue and list full; the oracle held to ~1 s per case)
             while True:
-                walls, tx, X, Y, kw, allowed = crowded_case(rng, budget=3e7) if crowded else random_case(rng)
+                walls, tx, X, Y, kw, allowed = crowded_case(rng, budget=2e7, sigmoid=False) if crowded  # (sigmoid: no exact shortcut to take, minutes per case) else random_case(rng)
                 if len(walls):
                     break
             if kw["max_order"] == 3 and X.size > 1600:  # (the oracle's order-3 duals: keep a case under a second)
@@ -194,7 +196,7 @@ def main_grad(argv):
             ctx.set_option("nan_scan_wqcap", 64 if case % 16 == 15 else 0)
             ctx.set_option("nan_scan_rb", 2 if case % 16 == 15 else 0)
             ctx.set_option("sched_min_tiles", 1 if case % 4 < 2 else 1 << 40)
-            msgs, c, n = grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=case % 4 == 3)
+            msgs, c, n = grad_case_check(ctx, walls, tx, X, Y, kw, allowed, role, strict=case % 4 == 3, prune=1 if crowded else 0)
             cells += c
             nans += n
             if msgs:

@@ -325,7 +325,7 @@ def test_cfg3_full_map_nan_positions_equal_the_exhaustive_kernels(role, mode):
 @pytest.mark.parametrize("mode", ["hard", "hsig", "sigmoid"])
 @pytest.mark.parametrize("role", ["rx", "tx"])
 def test_cfg3_rows_against_the_c_gradient_oracle(role, mode):
-    """An independent checker at FULL size: every second row of configs[2] and the 64 rows around the fixed end point (557 056 cells; TX grids every fourth row;
+    """An independent checker at FULL size: every fourth row of configs[2] and the 64 rows around the fixed end point (311 296 cells; TX grids every eighth row;
     sigmoid, whose oracle costs 6x as much per row: 32 / 16 rows around the fixed end point) against oracle/d2d_oracle_grad.c -- forward-mode dual
     numbers through the C oracle's op chain, no adjoint code, nothing shared with the kernels (validated against reverse-mode
     autodiff of oracle/ref.py in tests/test_oracle_grad_c.py) -- computed live on the host cores.  The GPU runs its DEFAULT
@@ -343,17 +343,16 @@ def test_cfg3_rows_against_the_c_gradient_oracle(role, mode):
     x = np.linspace(0.0, 1.0, 1024).astype(F)
     X, Y = np.meshgrid(x, x)
     i0 = min(max(int(tx[1] * 1023) - 32, 0), 1024 - 64)
-    # RX grids (the benchmark's role): every row.  TX grids: every fourth row + the 64 rows around the fixed end point (the
-    # oracle runs on the host's cores, and the whole -m gpu suite has 900 s on the driver's box; scripts/diag_rows.py runs the TX
-    # role over all 1024 rows: profiles/r05_parity_runs.txt).  sigmoid: 32 rows (RX) / 16 rows (TX) around the fixed end point.
+    # Which rows: the oracle runs on the host's cores and the whole -m gpu suite has 900 s on the driver's box.  RX grids (the
+    # benchmark's role): every fourth row + the 64 rows around the fixed end point; TX grids: every eighth + those 64 + the two rows
+    # round 5's full-map run named; sigmoid: 32 rows (RX) / 16 rows (TX) around the fixed end point.  ALL 1 024 rows, both roles,
+    # hard and hard_sigmoid: scripts/diag_rows.py <role> <mode> all (profiles/r06_parity_runs.txt).
     if mode == "sigmoid":
         rows = np.arange(i0 + 16, i0 + 48) if role == "rx" else np.arange(i0 + 24, i0 + 40)
     elif role == "rx":
-        # (every second row + the 64 rows around the fixed end point: 544 rows; scripts/diag_rows.py <role> <mode> all runs all 1 024,
-        # profiles/r06_parity_runs.txt -- the whole -m gpu suite has 900 s on the driver's box)
-        rows = np.unique(np.concatenate([np.arange(i0, i0 + 64), np.arange(0, 1024, 2)]))
+        rows = np.unique(np.concatenate([np.arange(i0, i0 + 64), np.arange(0, 1024, 4)]))
     else:
-        rows = np.unique(np.concatenate([np.arange(i0, i0 + 64), np.arange(0, 1024, 4), [197, 439]]))  # (197, 439: the tie cells of round 5's full-map run)
+        rows = np.unique(np.concatenate([np.arange(i0, i0 + 64), np.arange(0, 1024, 8), [197, 439]]))  # (197, 439: the tie cells of round 5's full-map run)
     at = int(np.searchsorted(rows, i0 + 31))  # two rows next to the fixed end point, by position in `rows`
     with Context(0) as c:
         c.set_scene(walls)
@@ -379,7 +378,7 @@ def test_cfg3_rows_against_the_c_gradient_oracle(role, mode):
     # point, the rows round 5's full-map diagnostic named (TX hard_sigmoid: 197, 439) and a dozen more -- where the GPU is
     # compared with it DIRECTLY, and (b) on every cell of the full comparison that is beyond the bar.
     plain_rows = np.unique(np.concatenate([rows[at:at + 2], rows[np.isin(rows, [197, 439])],
-                                           rows[np.linspace(0, rows.size - 1, 2 if mode == "sigmoid" else 8).astype(int)]]))
+                                           rows[np.linspace(0, rows.size - 1, 0 if mode == "sigmoid" else 6).astype(int)]]))
     sub = np.searchsorted(rows, plain_rows)
     v0, g0, kink = CO.power_map_grad(walls, tx, X[plain_rows], Y[plain_rows], min_order=0, max_order=2, prune=0,
                                      grid_role=role, with_kink=True, **kw)
