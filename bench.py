@@ -307,6 +307,9 @@ def reference_harness_leg(n_calls=30):
                    "accumulate_on_transmitters_grid_over_paths(X, Y, fun=received_power, reduce_all=True, approx=approx, key=key), "
                    "orders 0..1; wall ms per call through the Python mirror incl. PCIe both ways; cpu_ms = the C restatement of the same "
                    f"call, the faster of 1 thread and {usable_cores()} OpenMP threads (not JAX)", "calls": n_calls}
+    # (all the GPU timings first: an OpenMP team of the oracle keeps spinning on the host's cores for a while after its parallel
+    # region, and a call timed right behind it waited 95 ms for a core in the first version of this leg)
+    maps = {}
     for n in (5, 25, 50):
         X, Y = scene.grid(n)
         for approx in (False, True):
@@ -315,6 +318,11 @@ def reference_harness_leg(n_calls=30):
                 t0 = time.perf_counter()
                 Z = scene.accumulate_on_transmitters_grid_over_paths(X, Y, fun=received_power, reduce_all=True, approx=approx, key=key)
                 ts.append((time.perf_counter() - t0) * 1e3)
+            maps[n, approx] = Z
+            out[f"n={n},approx={approx}"] = {"first_ms": ts[0], "steady_ms": float(np.median(ts[2:])), "min_ms": float(np.min(ts[2:]))}
+    for n in (5, 25, 50):
+        X, Y = scene.grid(n)
+        for approx in (False, True):
             kw = dict(min_order=0, max_order=1, approx=approx, grid_role="tx")
             want = CO.power_map(walls, rx, X, Y, **kw)
             tc = {}
@@ -325,8 +333,9 @@ def reference_harness_leg(n_calls=30):
                     CO.power_map(walls, rx, X, Y, nthreads=nt, **kw)
                     tt.append((time.perf_counter() - t0) * 1e3)
                 tc[nt] = float(np.median(tt))
-            out[f"n={n},approx={approx}"] = {"first_ms": ts[0], "steady_ms": float(np.median(ts[2:])), "min_ms": float(np.min(ts[2:])),
-                                            "cpu_ms": min(tc.values()), "cpu_threads": 1 if tc[1] <= tc[0] else usable_cores(), "cells_differing_from_oracle": int((~((Z == want) | (np.isnan(Z) & np.isnan(want)))).sum())}
+            Z = maps[n, approx]
+            out[f"n={n},approx={approx}"].update({"cpu_ms": min(tc.values()), "cpu_threads": 1 if tc[1] <= tc[0] else usable_cores(),
+                                                  "cells_differing_from_oracle": int((~((Z == want) | (np.isnan(Z) & np.isnan(want)))).sum())})
     return out
 
 

@@ -181,7 +181,7 @@ def main_grad(argv):
         for case in range(n_cases):
             crowded = case % 8 == 7  # (coarse and crowded: the NaN scan's queue and list full; the oracle held to ~1 s per case)
             while True:
-                walls, tx, X, Y, kw, allowed = crowded_case(rng, budget=2e7, sigmoid=False) if crowded  # (sigmoid: no exact shortcut to take, minutes per case) else random_case(rng)
+                walls, tx, X, Y, kw, allowed = crowded_case(rng, budget=2e7, sigmoid=False) if crowded else random_case(rng)  # (crowded + sigmoid: no exact shortcut to take, minutes per case)
                 if len(walls):
                     break
             if kw["max_order"] == 3 and X.size > 1600:  # (the oracle's order-3 duals: keep a case under a second)

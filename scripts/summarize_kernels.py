@@ -20,6 +20,11 @@ WHAT = {"cfg3": "cfg2's sweep with value + per-cell gradient + scene VJP, hard (
         "txg": "TX grid of cfg2's size, hard (accumulate_on_transmitters_grid_over_paths)", "cfg4": "200 walls, 2048^2, orders 0..3, hard (configs[3])",
         "sigmoid": "cfg2 in sigmoid validity", "cfg5": "RIS scene, 300^2, MinPath x 1000 steps, value + gradient + scene VJP, reverse mode (configs[4])",
         "cfg5_fwd": "the same, values only", "cfg5_tan": "the same gradients by forward tangents (opt_grad_mode 1: round 2's kernel)"}
+# (second kernels of a case's run: the NaN scan beside the value+grad sweep -- VERDICT r5 item 4 asks for its counters)
+SECOND = {"cfg3_scan": ("cfg3", "nan_scan_region_kernel"), "cfg3_hsig_scan": ("cfg3_hsig", "nan_scan_region_kernel")}
+for k_, (dir_, key_) in SECOND.items():
+    MAIN[k_] = key_
+    WHAT[k_] = f"the NaN scan that runs beside the sweep of case {dir_} (d2d_nanscan.hpp)"
 PEAK = 157.3e12
 out_md = [f"# rocprofv3 summaries of the non-headline kernels, tag {tag}\n",
           "`scripts/profile_kernels.sh` -> `scripts/kernel_lab.py <case>` under `rocprofv3 --kernel-trace --stats` and, each on its own, the `--pmc` "
@@ -30,16 +35,18 @@ out_md = [f"# rocprofv3 summaries of the non-headline kernels, tag {tag}\n",
           "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 allpmc = {}
 for case, key in MAIN.items():
-    stats = sorted(glob.glob(os.path.join(src, f"{case}_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
+    rundir = SECOND[case][0] if case in SECOND else case
+    stats = sorted(glob.glob(os.path.join(src, f"{rundir}_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
     if not stats:
         continue
-    shutil.copy(stats[0], os.path.join(root, "profiles", f"{tag}_{case}_kernel_stats.csv"))
+    if case not in SECOND:
+        shutil.copy(stats[0], os.path.join(root, "profiles", f"{tag}_{case}_kernel_stats.csv"))
     rows = [r for r in csv.DictReader(open(stats[0])) if key in r["Name"]]
     if not rows:
         continue
     k = max(rows, key=lambda r: float(r["TotalDurationNs"]))
     pmc, meta = {}, {}
-    for f in glob.glob(os.path.join(src, f"{case}_pmc*", "*", "*_counter_collection.csv")):
+    for f in glob.glob(os.path.join(src, f"{rundir}_pmc*", "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         for r in csv.DictReader(open(f)):
             if key in r["Kernel_Name"]:

@@ -327,3 +327,17 @@ def test_minimize_follows_the_oracles_adam_and_the_reference_conventions():
     assert WithGrad.calls == 300 and np.allclose(xg, 0.5, rtol=1e-2)
     with pytest.raises(L.D2DUnsupported):
         minimize(f, x0, optimizer=object())
+
+
+def test_every_script_and_module_compiles():
+    """A syntax error in a script that the GPU suite imports (scripts/fuzz_parity.py feeds four GPU tests) must fail HERE, on the CPU,
+    not on the GPU box: every .py file of the repository's own directories is byte-compiled."""
+    import glob
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [f for d in ("scripts", "tests", "differt2d_amd", "oracle", "integration") for f in glob.glob(os.path.join(root, d, "**", "*.py"), recursive=True)]
+    files += [os.path.join(root, f) for f in ("bench.py", "__graft_entry__.py")]
+    assert len(files) > 80
+    for f in files:
+        with open(f, encoding="utf-8") as fh:
+            compile(fh.read(), f, "exec")  # (raises SyntaxError; writes nothing)
