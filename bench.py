@@ -326,7 +326,7 @@ def reference_harness_leg(n_calls=30):
             kw = dict(min_order=0, max_order=1, approx=approx, grid_role="tx")
             want = CO.power_map(walls, rx, X, Y, **kw)
             tc = {}
-            for nt in (1, 0):  # one thread, then all usable cores (a 5 x 5 grid is less work than waking an OpenMP team up)
+            for nt in (1, usable_cores()):  # one thread, then all usable cores (a 5 x 5 grid is less work than waking an OpenMP team up)
                 tt = []
                 for _ in range(5):
                     t0 = time.perf_counter()
@@ -334,7 +334,7 @@ def reference_harness_leg(n_calls=30):
                     tt.append((time.perf_counter() - t0) * 1e3)
                 tc[nt] = float(np.median(tt))
             Z = maps[n, approx]
-            out[f"n={n},approx={approx}"].update({"cpu_ms": min(tc.values()), "cpu_threads": 1 if tc[1] <= tc[0] else usable_cores(),
+            out[f"n={n},approx={approx}"].update({"cpu_ms": min(tc.values()), "cpu_threads": min(tc, key=tc.get),
                                                   "cells_differing_from_oracle": int((~((Z == want) | (np.isnan(Z) & np.isnan(want)))).sum())})
     return out
 

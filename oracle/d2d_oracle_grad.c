@@ -361,9 +361,10 @@ int orc_power_map_grad(const float* walls, int N, const uint8_t* allowed, const 
     long off = 0;
     for (int k = p->min_order; k <= p->max_order; ++k) off += enum_candidates(N, allowed, k, C + off);
 #ifdef _OPENMP
-    if (nthreads > 0) omp_set_num_threads(nthreads);
+    /* (a num_threads clause, not omp_set_num_threads: the count must not stick to later calls that ask for the default) */
+    const int nt_ = nthreads > 0 ? nthreads : omp_get_max_threads();
 #endif
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt_)
     for (long c = 0; c < ncell; ++c) {
         dual acc = dc(0.0f);
         double ga = 0.0, cell_amp = 0.0;

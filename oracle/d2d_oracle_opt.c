@@ -633,9 +633,10 @@ int SFX(orc_opt_power_map)(const double* xys, const uint8_t* kind, const double*
     OBJ* O = (OBJ*)malloc(sizeof(OBJ) * (N > 0 ? N : 1));
     for (int j = 0; j < N; ++j) SFX(make_obj)(&O[j], kind[j], xys + 4 * j, sincos + 2 * j, (REAL)p->patch);
 #ifdef _OPENMP
-    if (nthreads > 0) omp_set_num_threads(nthreads);
+    /* (a num_threads clause, not omp_set_num_threads: the count must not stick to later calls that ask for the default) */
+    const int nt_ = nthreads > 0 ? nthreads : omp_get_max_threads();
 #endif
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nt_)
     for (long c = 0; c < ncell; ++c) {
         REAL acc = (REAL)0;
         double gx = 0.0, gy = 0.0;
