@@ -225,6 +225,7 @@ struct d2d_ctx {
     // the scan BESIDE the sweep ("nan_scan_async", default on): on a stream of its own, its flags applied by nan_apply_kernel once
     // both are through (sweep 0.14 ms + scan 0.26 ms one behind the other at cfg3)
     bool nan_scan_async = true;
+    size_t lds_max = d2d_host::LDS_MAX;  // dynamic LDS a launch without a choice may take (gfx950: the CU's 160 KB less 4 KB of static LDS, d2d_host.hpp)
     long long nan_wqcap = 0, nan_rb = 0;  // "nan_scan_wqcap" / "nan_scan_rb": the region scan's queue entries / batches per round in use (0: all; tests)
     long long nan_scan_prio = 0;        // "nan_scan_prio": 0 the scan stream has the lowest priority, 1 the highest (A/B)
     hipStream_t scan_stream = nullptr;  // created at the first use
@@ -596,6 +597,19 @@ int d2d_create(int device, d2d_ctx** out) {
     if (const char* v = getenv("D2D_HEAVY_SPLIT")) c->heavy_split = atoll(v);
     if (const char* v = getenv("D2D_SPLIT_MAX_TILES")) c->split_max_tiles = atoll(v);  // tuning knob (0: never)
     hipError_t e1 = hipSetDevice(device);
+    if (e1 == hipSuccess) {
+        // The kernels are gfx950 code objects and size their LDS for a CU with 160 KB: say so HERE, in words, instead of failing a
+        // launch later with a generic HIP error.
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+                delete c;
+                return fail(D2D_ERR_UNSUPPORTED, "device %d is %s; libd2d is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (e1 == hipSuccess) e1 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->ev0);
     if (e1 == hipSuccess) e1 = hipEventCreate(&c->ev1);
@@ -1645,7 +1659,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     const dim3 grid_queue((unsigned)std::min<long long>(tiles, std::max<long long>(256, c->fb_hint)));
     if (txg_culled && !grad_mode) {
         const size_t lds_t = (size_t)(3 * c->N + 1) * sizeof(float4);
-        if (lds_t > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+        if (lds_t > c->lds_max) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
         a.grad = nullptr; a.cot = nullptr; a.partial = nullptr;
         HIP_TRY(d2d::launch_txg(mode, a.rl != nullptr, false, p->max_order, grid, lds_t, c->stream, a));
         if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none)
@@ -1705,7 +1719,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             const size_t lds_static = 512 + (size_t)d2d::NAN_WQCAP * sizeof(unsigned long long) + (size_t)d2d::NAN_W * (64 * sizeof(float2) + 16);
             const bool regions = c->nan_scan_mode != 2 && lds_r + lds_static <= d2d_host::LDS_LIMIT && c->N <= 4095;
             const size_t lds_n = regions ? lds_r : (size_t)(3 * c->N) * sizeof(float4) + (size_t)c->N * sizeof(int) + 16;
-            if (lds_n > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the NaN scan's LDS table", c->N);
+            if (lds_n > c->lds_max) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the NaN scan's LDS table", c->N);
             unsigned long long* ns = nullptr;
             if (c->nan_scan_stats) {
                 int rc2;
@@ -1723,9 +1737,9 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         // every size check of the sweeps below comes BEFORE the scan is forked onto its own stream: nothing may fail between the
         // fork and the join (a scan left running would read tables that a later d2d_set_scene rewrites)
         if (!txg && !p->strict_nan) {
-            if ((size_t)(4 * c->N + 1) * sizeof(float4) + 512 > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+            if ((size_t)(4 * c->N + 1) * sizeof(float4) + 512 > c->lds_max) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
         } else if (txg_culled) {
-            if ((size_t)(4 * c->N + 1) * sizeof(float4) > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+            if ((size_t)(4 * c->N + 1) * sizeof(float4) > c->lds_max) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
         }
         bool scan_beside = false;
         // ... and should a launch fail behind the fork all the same (a HIP error), the scan is waited for before the error is returned
@@ -1764,7 +1778,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         if (!txg && !p->strict_nan) {
             // culled value+grad sweep (default)
             const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4) + 512;  // tables, adjoint table, culling queue
-            if (lds2 > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+            if (lds2 > c->lds_max) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
             a.cullq_off = (int)((size_t)(4 * c->N + 1) * sizeof(float4));
             HIP_TRY(d2d::launch_fwd_grad(mode, a.rl != nullptr, p->max_order, grid_patches, lds2, c->stream, a));
             if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none): a few workgroups walk the queue
@@ -1777,7 +1791,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         } else if (txg_culled) {
             // TX grid, culled value+grad sweep
             const size_t lds2 = (size_t)(4 * c->N + 1) * sizeof(float4);
-            if (lds2 > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
+            if (lds2 > c->lds_max) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table", c->N);
             HIP_TRY(d2d::launch_txg(mode, a.rl != nullptr, true, p->max_order, grid_patches, lds2, c->stream, a));
             if (a.rl && !queue_impossible) {  // the patches the listed kernel left behind (usually none)
                 d2d::SweepArgs af = a;
@@ -1814,7 +1828,7 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
         return D2D_OK;
     }
     const size_t tab_lds = d2d_host::tab_lds_bytes(c->N);  // tables (+ adjoint table) + one culling queue
-    if (tab_lds > d2d_host::LDS_MAX) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~2400)", c->N);
+    if (tab_lds > c->lds_max) return fail(D2D_ERR_UNSUPPORTED, "%d objects exceed the kernel's LDS table (max ~2400)", c->N);
     // Launches that hold only a few patches per SIMD are bound by their dearest patch: share every patch between
     // D2D_SPLIT_W waves there (power_fwd_split_kernel).  Big grids are throughput-bound: one wave per patch.
     constexpr int D2D_SPLIT_W = d2d::SPLIT_W;
