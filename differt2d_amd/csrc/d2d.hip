@@ -225,7 +225,7 @@ struct d2d_ctx {
     // the scan BESIDE the sweep ("nan_scan_async", default on): on a stream of its own, its flags applied by nan_apply_kernel once
     // both are through (sweep 0.14 ms + scan 0.26 ms one behind the other at cfg3)
     bool nan_scan_async = true;
-    size_t lds_max = d2d_host::LDS_MAX;  // dynamic LDS a launch without a choice may take (gfx950: the CU's 160 KB less 4 KB of static LDS, d2d_host.hpp)
+    size_t lds_max = d2d_host::LDS_MAX;  // dynamic LDS a launch without a choice may take (gfx950: the CU's 160 KB less 4 KB of static LDS, d2d_host.hpp; d2d_create lowers it to what the device reports)
     long long nan_wqcap = 0, nan_rb = 0;  // "nan_scan_wqcap" / "nan_scan_rb": the region scan's queue entries / batches per round in use (0: all; tests)
     long long nan_scan_prio = 0;        // "nan_scan_prio": 0 the scan stream has the lowest priority, 1 the highest (A/B)
     hipStream_t scan_stream = nullptr;  // created at the first use
@@ -606,6 +606,10 @@ int d2d_create(int device, d2d_ctx** out) {
                 delete c;
                 return fail(D2D_ERR_UNSUPPORTED, "device %d is %s; libd2d is built for gfx950 (MI355X) only", device, prop.gcnArchName);
             }
+            // (gfx950 / ROCm 7.2 reports sharedMemPerBlock = 163 840 and grants it without an attribute: scripts/probes/lds_limit_probe.hip,
+            // profiles/r06_lds_probe.txt.  A runtime that reports less lowers the limit: D2D_ERR_UNSUPPORTED then names the object count)
+            if (prop.sharedMemPerBlock >= 64 * 1024 && prop.sharedMemPerBlock < d2d_host::LDS_MAX + 4096)
+                c->lds_max = prop.sharedMemPerBlock - 4096;  // (4 KB left for the kernels' static LDS)
         } else {
             (void)hipGetLastError();
         }
