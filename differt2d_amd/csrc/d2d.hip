@@ -1733,9 +1733,11 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
             }
             const dim3 grid_regions((unsigned)(((tiles_x + d2d::NAN_R - 1) / d2d::NAN_R) * ((tiles_y + d2d::NAN_RY - 1) / d2d::NAN_RY)));
             d2d::SweepArgs ac = as;
-            ac.nan_wqcap = (int)c->nan_wqcap;
-            ac.nan_rb = (int)c->nan_rb;
-            HIP_TRY(d2d::launch_nan_scan(p->approx != 0, txg, p->max_order, regions, regions ? grid_regions : grid_patches, lds_n, st, ac, ns));
+            ac.nan_wqcap = c->nan_wqcap > 0 ? (int)c->nan_wqcap : d2d::NAN_WQCAP;  // (the kernel takes them as they are: never 0)
+            ac.nan_rb = c->nan_rb > 0 ? (int)c->nan_rb : d2d::NAN_RB;
+            // (the region kernel's debug instance -- run-time buffer sizes, counters -- only when a test asked for either)
+            const bool dbg = c->nan_wqcap > 0 || c->nan_rb > 0 || c->nan_scan_stats;
+            HIP_TRY(d2d::launch_nan_scan(p->approx != 0, txg, p->max_order, regions, dbg, regions ? grid_regions : grid_patches, lds_n, st, ac, ns));
             return D2D_OK;
         };
         // every size check of the sweeps below comes BEFORE the scan is forked onto its own stream: nothing may fail between the

@@ -178,7 +178,7 @@ struct SweepArgs {
     unsigned long long* nan_cell_bits;  // [patches] bit l: the cell of lane l gets a NaN gradient
     unsigned* nan_row_bits;             // [patches][nan_row_words] word 0: the patch has a flag (the fixed end point's entries), then one bit per object
     int nan_row_words;
-    int nan_wqcap, nan_rb;  // region scan: queue entries / batches per round in use (0: the compile-time NAN_WQCAP / NAN_RB; "nan_scan_caps")
+    int nan_wqcap, nan_rb;  // region scan: queue entries / batches per round in use, in [1, NAN_WQCAP] / [1, NAN_RB] (the host fills them in)
 #ifdef D2D_AB_TIMELINE
     unsigned long long* tl_ring;  // diagnostic build: [256][2] first start / end (100 MHz real-time counter) of the last 256 forward launches
     int tl_seq;

@@ -34,7 +34,7 @@ hipError_t launch_region_refine(int K, bool grad, bool txg, dim3 grid, size_t ld
 
 // nan_scan_kernel<APPROX, TXG, MAXK> (d2d_nanscan.hpp): the reference's autodiff NaN positions, behind a culled value+grad sweep
 // regions: nan_scan_region_kernel (16 waves per region of 4 x 4 patches; grid = regions) instead of one wave per patch
-hipError_t launch_nan_scan(bool approx, bool txg, int max_order, bool regions, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a,
+hipError_t launch_nan_scan(bool approx, bool txg, int max_order, bool regions, bool dbg, dim3 grid, size_t lds, hipStream_t stream, const SweepArgs& a,
                            unsigned long long* stats);
 // nan_apply_kernel: the flags of a scan that ran beside the sweep (SweepArgs::nan_cell_bits / nan_row_bits) -> grad / partial
 hipError_t launch_nan_apply(hipStream_t stream, const SweepArgs& a, long tiles);

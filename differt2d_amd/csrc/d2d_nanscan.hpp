@@ -566,17 +566,21 @@ __device__ __forceinline__ void nan_decode_batch(long long id, int Nc, int n_chu
     for (int d = 1; d <= K - 2; ++d) pos[d] = dig[d] + (dig[d] >= pos[d - 1] ? 1 : 0);
 }
 
-template <int K, bool APPROX, bool TXG>
+template <int K, bool APPROX, bool TXG, bool DBG>
 __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float4* tab, unsigned long long* list, int* lcount, unsigned* wallbits,
                                                  unsigned long long* wq, int* wqn, const float2* cells, unsigned long long* cellmask, unsigned* wallbits_all, int nwords,
                                                  const unsigned* nearbits, const unsigned* region_near, const float (&rbx)[4], const float (&rby)[4], const float (&pbx)[4], const float (&pby)[4],
                                                  float cx, float cy, bool force, bool patch_exists, bool& cell_nan, bool& any_nan,
-                                                 unsigned long long& n_probe, int& round, unsigned long long& n_self, unsigned long long& n_bad) {
+                                                 unsigned long long& n_probe, int& round, unsigned* dbg_counts) {  // (dbg_counts: DBG builds only)
     static_assert(K >= 1, "order 0 has no scan");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // entries of the probe queue / batches per round in use: the compile-time sizes, or less ("nan_scan_caps": tests make overflow the rule)
-    const int wqcap = a.nan_wqcap > 0 && a.nan_wqcap < NAN_WQCAP ? a.nan_wqcap : NAN_WQCAP;
-    const int rb = a.nan_rb > 0 && a.nan_rb < NAN_RB ? a.nan_rb : NAN_RB;
+    // Entries of the probe queue / batches per round IN USE.  Product build (DBG = false): the compile-time sizes.  DBG = true -- chosen
+    // by the host when a test asked for smaller buffers ("nan_scan_wqcap" / "nan_scan_rb": a full queue and a full list as the rule)
+    // or for the counters ("nan_scan_stats") --: a.nan_wqcap in [1, NAN_WQCAP], a.nan_rb in [1, NAN_RB], and the counters through
+    // LDS.  Same code either way; as run-time values in the one kernel they cost the hard-mode scan 8 % (measured, round 6).
+    const int rb = DBG ? a.nan_rb : NAN_RB;
+    const int wqcap = DBG ? a.nan_wqcap : NAN_WQCAP;
+    if (!DBG) dbg_counts = nullptr;
     const bool plen = a.fun_id != D2D_FUN_ONE;
     const int Nc = a.Nc;
     if (Nc < 1 || (K >= 2 && Nc < 2)) return;  // (workgroup-uniform)
@@ -591,18 +595,23 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
     auto probe_item = [&](unsigned long long cu, int p, float pcx, float pcy) {
         int ce[D2D_MAX_ORDER] = {-1, -1, -1, -1};
         float ex[D2D_MAX_ORDER], ey[D2D_MAX_ORDER];
-        // (wave-uniform) an item names a patch of this region and K objects of the scene; anything else is refused and counted,
-        // never used as an address (the scene's tables are a few KB: an index of 4095 reads 128 KB past them)
-        bool item_ok = (unsigned)p < (unsigned)NAN_W;
+        // (wave-uniform) an item names a patch of this region and K objects of the scene.  Whatever it holds, it never becomes an
+        // address outside the tables: the patch index is taken modulo NAN_W, an object index is capped at N - 1 (one scalar min
+        // each; the scene's tables are a few KB and an index of 4095 would read 128 KB past them).  With the counters on
+        // ("nan_scan_stats": the tests) an item that NEEDED the cap is refused and counted instead -- an internal error, always 0.
+        if (dbg_counts != nullptr) {
+            bool item_ok = (unsigned)p < (unsigned)NAN_W;
 #pragma unroll
-        for (int d = 0; d < K; ++d) item_ok = item_ok && (int)((cu >> (12 * d)) & 0xfffull) < a.N;
-        if (!item_ok) {
-            n_bad += 1ull;
-            return;
+            for (int d = 0; d < K; ++d) item_ok = item_ok && (int)((cu >> (12 * d)) & 0xfffull) < a.N;
+            if (!item_ok) {
+                if (lane == 0) atomicAdd(&dbg_counts[1], 1u);
+                return;
+            }
         }
+        p &= NAN_W - 1;
 #pragma unroll
         for (int d = 0; d < K; ++d) {
-            ce[d] = (int)((cu >> (12 * d)) & 0xfffull);
+            ce[d] = min((int)((cu >> (12 * d)) & 0xfffull), a.N - 1);
             // RX grids: the transmitter's image chain (wave-uniform); TX grids: the lane's cell's (geometry.py:1086-1091)
             image_of(ldc4(a.refl, 2 * ce[d]), d == 0 ? (TXG ? pcx : a.txx) : ex[d > 0 ? d - 1 : 0], d == 0 ? (TXG ? pcy : a.txy) : ey[d > 0 ? d - 1 : 0],
                      ex[d], ey[d]);
@@ -623,11 +632,11 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
 #endif
         // ---- region level: batches [r0, r0 + rb) of the order, batch r0 + t * NAN_W + wv to wave wv: at most 64 rb <= NAN_LCAP
         // survivors per round, the list cannot overflow
-        const long long r1 = (r0 + rb < nb) ? r0 + rb : nb;
+        const int nbr = (nb - r0 < (long long)rb) ? (int)(nb - r0) : rb;  // batches of this round
 #pragma unroll 1
         for (int t = 0; t < (NAN_RB + NAN_W - 1) / NAN_W; ++t) {
+            if (t * NAN_W + wv >= nbr) break;
             const long long id = r0 + (long long)t * NAN_W + wv;
-            if (id >= r1) break;
             int pos[D2D_MAX_ORDER] = {0, 0, 0, 0};
             int chunk = 0;
             nan_decode_batch<K>(id, Nc, n_chunks, pos, chunk);
@@ -737,7 +746,7 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
                         if (alive) wq[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = code | ((unsigned long long)wv << 56);
                         mask = 0ull;
                     }
-                    n_self += (unsigned long long)__builtin_popcountll(mask);
+                    if (dbg_counts != nullptr && lane == 0 && mask != 0ull) atomicAdd(&dbg_counts[0], (unsigned)__builtin_popcountll(mask));
 #else
                     int base = 0;
                     if (lane == 0) base = atomicAdd(wqn, cnt);
@@ -746,7 +755,7 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
                     const bool queued = alive && slot < wqcap;
                     if (queued) wq[slot] = code | ((unsigned long long)wv << 56);
                     mask = __ballot(alive && !queued);
-                    n_self += (unsigned long long)__builtin_popcountll(mask);
+                    if (dbg_counts != nullptr && lane == 0 && mask != 0ull) atomicAdd(&dbg_counts[0], (unsigned)__builtin_popcountll(mask));
 #endif
                 }
                 // ... unless it is full: then the wave probes its own
@@ -779,7 +788,7 @@ __device__ __forceinline__ void nan_region_order(const SweepArgs& a, const float
 #ifndef D2D_NAN_MIN_WAVES
 #define D2D_NAN_MIN_WAVES 1  // A/B: waves per SIMD the region scan must leave room for (8: two of its workgroups per CU, <= 64 VGPRs)
 #endif
-template <bool APPROX, bool TXG, int MAXK>
+template <bool APPROX, bool TXG, int MAXK, bool DBG = false>
 __global__ void __launch_bounds__(64 * NAN_W, D2D_NAN_MIN_WAVES) nan_scan_region_kernel(SweepArgs a, unsigned long long* __restrict__ stats) {
     extern __shared__ float4 tab[];  // [2N] refl, [N] flt, the region's list [NAN_LCAP], then [2 NAN_W + 1][ceil(N / 32)] flag bits
     __shared__ float pbox[NAN_W][4];
@@ -789,6 +798,7 @@ __global__ void __launch_bounds__(64 * NAN_W, D2D_NAN_MIN_WAVES) nan_scan_region
     __shared__ int swqn;
     __shared__ float2 scells[NAN_W * 64];            // the region's cells, patch by patch
     __shared__ unsigned long long scellmask[NAN_W];  // flagged cells per patch
+    __shared__ unsigned sdbg[2];                     // counters of the stats build (nan_region_order)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 2 * a.N; i += 64 * NAN_W) tab[i] = ldc4(a.refl, i);
     for (int i = threadIdx.x; i < a.N; i += 64 * NAN_W) tab[2 * a.N + i] = ldc4(a.flt, i);
@@ -802,6 +812,7 @@ __global__ void __launch_bounds__(64 * NAN_W, D2D_NAN_MIN_WAVES) nan_scan_region
         lcount[0] = lcount[1] = 0;
         sbad = 0;
         swqn = 0;
+        sdbg[0] = sdbg[1] = 0u;
     }
     if (threadIdx.x < NAN_W) scellmask[threadIdx.x] = 0ull;
     __syncthreads();
@@ -868,7 +879,8 @@ __global__ void __launch_bounds__(64 * NAN_W, D2D_NAN_MIN_WAVES) nan_scan_region
     // a coordinate that is not comfortably finite anywhere in the region: no bound holds, every candidate is probed
     const bool force = sbad != 0;
     bool cell_nan = false, any_nan = false;
-    unsigned long long n_probe = 0ull, n_self = 0ull, n_bad = 0ull;
+    unsigned long long n_probe = 0ull;
+    unsigned* const dbg_counts = (DBG && stats != nullptr) ? sdbg : nullptr;  // [0] self probes, [1] refused items: through LDS, DBG builds only
     int round = 0;
     if (a.min_order <= 0 && a.max_order >= 0 && a.fun_id != D2D_FUN_ONE) {
         // order 0 has no scan, but its one segment has rule (3): px[0] = transmitter, px[1] = receiver
@@ -876,13 +888,13 @@ __global__ void __launch_bounds__(64 * NAN_W, D2D_NAN_MIN_WAVES) nan_scan_region
         any_nan = wave_any(cell_nan);
     }
     if (a.min_order <= 1 && a.max_order >= 1)
-        nan_region_order<1, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, n_self, n_bad);
+        nan_region_order<1, APPROX, TXG, DBG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, dbg_counts);
     if (a.min_order <= 2 && a.max_order >= 2)
-        nan_region_order<2, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, n_self, n_bad);
+        nan_region_order<2, APPROX, TXG, DBG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, dbg_counts);
     if (MAXK >= 3 && a.min_order <= 3 && a.max_order >= 3)
-        nan_region_order<3, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, n_self, n_bad);
+        nan_region_order<3, APPROX, TXG, DBG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, dbg_counts);
     if (MAXK >= 4 && a.min_order <= 4 && a.max_order >= 4)
-        nan_region_order<4, APPROX, TXG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, n_self, n_bad);
+        nan_region_order<4, APPROX, TXG, DBG>(a, tab, list, lcount, wallbits, swq, &swqn, scells, scellmask, wallbits_all, nwords, nearbits, region_near, rbx, rby, pbx, pby, cx, cy, force, patch_exists, cell_nan, any_nan, n_probe, round, dbg_counts);
     {
         // what the region's probes found in this wave's patch (nan_region_order ends on a barrier)
         const unsigned long long cm = scellmask[wv];
@@ -919,9 +931,11 @@ __global__ void __launch_bounds__(64 * NAN_W, D2D_NAN_MIN_WAVES) nan_scan_region
         atomicAdd(&stats[0], n_probe);
         atomicAdd(&stats[1], (unsigned long long)__builtin_popcountll(flagged));
         if (any_nan && patch_exists) atomicAdd(&stats[2], 1ull);
-        atomicAdd(&stats[3], n_self);  // probes a wave made itself because the region's queue was full
-        atomicAdd(&stats[4], n_bad);   // queue items refused because they named no patch / object (must stay 0)
-        if (wv == 0) atomicAdd(&stats[5], (unsigned long long)round);  // rounds (list fills) of this region
+        if (wv == 0) {  // (nan_region_order ends on a barrier: the workgroup's counters are complete)
+            atomicAdd(&stats[3], (unsigned long long)sdbg[0]);  // probes a wave made itself because the region's queue was full
+            atomicAdd(&stats[4], (unsigned long long)sdbg[1]);  // queue items refused because they named no patch / object (must stay 0)
+            atomicAdd(&stats[5], (unsigned long long)round);    // rounds (list fills) of this region
+        }
     }
 }
 

@@ -195,28 +195,44 @@ hipError_t launch_region_refine(int K, bool grad, bool txg, dim3 grid, size_t ld
 }
 #elif D2D_TU_FAMILY == 10
 // nan_scan_kernel<APPROX, TXG, MAXK>: depends on hard / approx only (compiled once, -DD2D_TU_MODE=0)
-hipError_t launch_nan_scan(bool approx, bool txg, int max_order, bool regions, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a,
+hipError_t launch_nan_scan(bool approx, bool txg, int max_order, bool regions, bool dbg, dim3 grid, size_t lds, hipStream_t s, const SweepArgs& a,
                            unsigned long long* stats) {
     const dim3 block(regions ? 64 * NAN_W : 64);
-#define D2D_NS(KERNEL, A, T)                                                                        \
-    do {                                                                                            \
-        if (max_order <= 2) hipLaunchKernelGGL((KERNEL<A, T, 2>), grid, block, lds, s, a, stats);    \
-        else if (max_order == 3) hipLaunchKernelGGL((KERNEL<A, T, 3>), grid, block, lds, s, a, stats); \
-        else hipLaunchKernelGGL((KERNEL<A, T, 4>), grid, block, lds, s, a, stats);                   \
+#define D2D_NS(KERNEL, ...)                                                                                   \
+    do {                                                                                                      \
+        if (max_order <= 2) hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 2>), grid, block, lds, s, a, stats);      \
+        else if (max_order == 3) hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 3>), grid, block, lds, s, a, stats); \
+        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 4>), grid, block, lds, s, a, stats);                     \
     } while (0)
-#define D2D_NS_AT(KERNEL)                    \
-    do {                                     \
-        if (approx) {                        \
-            if (txg) D2D_NS(KERNEL, true, true);   \
-            else D2D_NS(KERNEL, true, false);      \
-        } else {                             \
-            if (txg) D2D_NS(KERNEL, false, true);  \
-            else D2D_NS(KERNEL, false, false);     \
-        }                                    \
+    // (the region kernel's DBG instance: run-time buffer sizes and counters -- tests; the product launches DBG = false)
+#define D2D_NSR(A, T)                                                                                                      \
+    do {                                                                                                                   \
+        if (dbg) {                                                                                                         \
+            if (max_order <= 2) hipLaunchKernelGGL((nan_scan_region_kernel<A, T, 2, true>), grid, block, lds, s, a, stats); \
+            else if (max_order == 3) hipLaunchKernelGGL((nan_scan_region_kernel<A, T, 3, true>), grid, block, lds, s, a, stats); \
+            else hipLaunchKernelGGL((nan_scan_region_kernel<A, T, 4, true>), grid, block, lds, s, a, stats);               \
+        } else {                                                                                                           \
+            D2D_NS(nan_scan_region_kernel, A, T);                                                                          \
+        }                                                                                                                  \
     } while (0)
-    if (regions) D2D_NS_AT(nan_scan_region_kernel);
-    else D2D_NS_AT(nan_scan_kernel);
-#undef D2D_NS_AT
+    if (regions) {
+        if (approx) {
+            if (txg) D2D_NSR(true, true);
+            else D2D_NSR(true, false);
+        } else {
+            if (txg) D2D_NSR(false, true);
+            else D2D_NSR(false, false);
+        }
+    } else {
+        if (approx) {
+            if (txg) D2D_NS(nan_scan_kernel, true, true);
+            else D2D_NS(nan_scan_kernel, true, false);
+        } else {
+            if (txg) D2D_NS(nan_scan_kernel, false, true);
+            else D2D_NS(nan_scan_kernel, false, false);
+        }
+    }
+#undef D2D_NSR
 #undef D2D_NS
     return hipGetLastError();
 }

@@ -301,7 +301,8 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *                  "nan_scan_prio": priority of that stream, 0 (default) = lowest, 1 = highest (A/B: the highest is slower)
  *                  "nan_scan_wqcap" / "nan_scan_rb": entries of a region's probe queue / batches per round of its list that the
  *                  two-level scan USES (0 = default: all it has; tests set them small so that a full queue and a full list are the
- *                  rule instead of a rare event -- same flags whatever the values)
+ *                  rule instead of a rare event -- same flags whatever the values).  Any of these two, or "nan_scan_stats", selects the
+ *                  region kernel's debug instance (run-time sizes, counters through LDS); the product instance has neither
  *   "comm_prio": priority of the stream the RCCL collectives run on beside the next sweep: -1 lowest, 0 (default) normal, 1 highest;
  *                  set it BEFORE the first collective (D2D_ERR_STATE afterwards)
  *   "sig_narrow_filter": sigmoid validity, forward sweeps: 1 (default) = the divide-free filter of the occlusion tests drops what is

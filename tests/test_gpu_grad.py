@@ -178,11 +178,14 @@ def test_nan_scan_with_a_full_queue_and_a_full_list():
 
     rng = np.random.default_rng(2)
     with Context(0) as c:
-        c.set_option("nan_scan_stats", 1)
         overflowed = nan_cells = 0
-        for caps in ((64, 2), (1, 1), (0, 0)):  # tiny, degenerate (one queue slot, one batch per round), the product's sizes
+        # tiny buffers, degenerate ones (one queue slot, one batch per round), the product's sizes -- these three on the region
+        # kernel's DEBUG instance (run-time sizes, counters: nan_scan_stats = 1) -- and the PRODUCT instance (compile-time sizes, no
+        # counters: what every other launch of the library runs), whose queue overflows on the crowded scenes all the same
+        for caps in ((64, 2, 1), (1, 1, 1), (0, 0, 1), (0, 0, 0)):
             c.set_option("nan_scan_wqcap", caps[0])
             c.set_option("nan_scan_rb", caps[1])
+            c.set_option("nan_scan_stats", caps[2])
             # (a small grid first: the launch order of the suite that aborted)
             tx, walls = random_scene(10, seed=17)
             X, Y = unit_grid(19, 13)
@@ -194,16 +197,17 @@ def test_nan_scan_with_a_full_queue_and_a_full_list():
                 c.set_scene(walls)
                 for role in (L.GRID_RX, L.GRID_TX):
                     for approx in (False, True):
-                        if caps == (1, 1) and (nw > 50 or g > 32):
+                        if caps[:2] == (1, 1) and (nw > 50 or g > 32):
                             continue  # (one batch per round: thousands of barriers per region; the small case is enough)
                         kw = dict(min_order=0, max_order=2, approx=approx, grid_role=role)
                         b = c.value_and_grads(tx, X, Y, strict_nan=True, **kw)
                         for rep in range(3 if caps[0] else 1):
                             a = c.value_and_grads(tx, X, Y, strict_nan=False, **kw)
-                            st = c.debug_nan_scan()
-                            assert st["bad_items"] == 0, (caps, nw, g, role, approx, st)
-                            if caps[0]:
-                                overflowed += int(st["self_probes"] > 0)
+                            if caps[2]:
+                                st = c.debug_nan_scan()
+                                assert st["bad_items"] == 0, (caps, nw, g, role, approx, st)
+                                if caps[0]:
+                                    overflowed += int(st["self_probes"] > 0)
                             _same_flags_and_gradients(a, b, f"caps {caps}, {nw} walls, {g}^2, role {role}, approx {approx}, launch {rep}")
             # lattice scenes: exact zeros in the backward scan are common (NaN cells to find)
             for case in range(8):
@@ -217,7 +221,7 @@ def test_nan_scan_with_a_full_queue_and_a_full_list():
                 kw = dict(min_order=0, max_order=2, approx=bool(case % 2), grid_role=L.GRID_TX if case % 4 >= 2 else L.GRID_RX)
                 b = c.value_and_grads(tx, X, Y, strict_nan=True, **kw)
                 a = c.value_and_grads(tx, X, Y, strict_nan=False, **kw)
-                assert c.debug_nan_scan()["bad_items"] == 0
+                assert not caps[2] or c.debug_nan_scan()["bad_items"] == 0
                 _same_flags_and_gradients(a, b, f"caps {caps}, lattice case {case}")
                 nan_cells += int(np.isnan(b["grad_rx"]).any(-1).sum())
         print(f"launches with a full queue: {overflowed}; NaN cells compared on the lattice scenes: {nan_cells}")
