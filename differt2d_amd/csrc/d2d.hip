@@ -304,6 +304,8 @@ struct d2d_ctx {
     bool swept_pending = false;
     hipEvent_t ev_prep = nullptr;       // recorded on aux_stream behind a launch's preparation
     bool pipeline = true;
+    long long unpiped_max_tiles = 256; // "unpiped_max_tiles": launches of orders <= 1 over at most this many patches prepare on the sweep's own stream (latency of a small call)
+    bool last_small = false;           // ... what the previous launch was (a change of kind drains both streams first)
     bool prep_fused = true;             // shadow masks + zeroing in one kernel, the schedule's sort in one workgroup ("prep_fused" option; 0: round 2's chain)
     // RCCL (one communicator per ctx, collectives run on the ctx stream)
     ncclComm_t comm = nullptr;
@@ -1202,7 +1204,24 @@ static int sweep_launch(d2d_ctx* c, const d2d_params* p, const float* tx, unsign
     // (a lone call has no previous sweep to hide its preparation behind; preparing on the sweep stream whenever that stream is idle
     // was measured: launch -> synchronise 0.146 -> 0.137 ms at 300^2, but back-to-back launches whose host runs ahead of the GPU
     // only now and then lose 4-8 %: not kept)
-    const bool piped = c->pipeline && c->aux_stream != nullptr && d_stats == nullptr;
+    // Small launches without region lists ("unpiped_max_tiles", orders <= 1): a grid of a few patches is all launch latency; its one
+    // preparation kernel (the shadow masks) takes microseconds and gains nothing from running beside a previous sweep, while the fork
+    // to the side stream and the join back cost two cross-stream events per launch.  They prepare on the sweep's own stream: the
+    // reference's own benchmark workload (basic_scene, scene.grid(n <= 50), orders 0..1) 45 -> 37.5 us launch -> synchronise, back-to-back
+    // launches unchanged at 24 us (scripts/small_launch_ab.py).  With lists (orders >= 2) a lone call gains the same 8 us but
+    // back-to-back launches lose 30 - 40 us (71 -> 104 us at 128^2): those stay pipelined.  A context that changes kind drains its
+    // streams once, like the "pipeline" option does.
+    const long long tiles_early = (long long)((c->n + d2d::TILE_W - 1) / d2d::TILE_W) * ((c->m + d2d::TILE_H - 1) / d2d::TILE_H);
+    const bool small = c->pipeline && p->max_order <= 1 && tiles_early <= c->unpiped_max_tiles;
+    if (small != c->last_small) {
+        if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->aux_stream) HIP_TRY(hipStreamSynchronize(c->aux_stream));
+        if (c->sort_stream) HIP_TRY(hipStreamSynchronize(c->sort_stream));
+        c->swept_pending = false;
+        for (int i = 0; i < d2d_ctx::N_SPARE; ++i) c->spare_sets[i].swept_pending = false;
+        c->last_small = small;
+    }
+    const bool piped = c->pipeline && c->aux_stream != nullptr && d_stats == nullptr && !small;
     bool set_was_swept = false;  // the set this launch takes was read by a sweep that may still be running (ev_swept says when it is through)
     if (piped) {
         // rotate: the oldest set becomes the current one, the current one the newest spare
@@ -2083,6 +2102,10 @@ int d2d_set_option(d2d_ctx* c, const char* name, int64_t value) {
         c->swept_pending = false;
         for (int i = 0; i < d2d_ctx::N_SPARE; ++i) c->spare_sets[i].swept_pending = false;
         c->pipeline = value != 0;
+    }
+    else if (!strcmp(name, "unpiped_max_tiles")) {
+        if (value < 0) return fail(D2D_ERR_INVALID, "unpiped_max_tiles must be >= 0, got %lld", (long long)value);
+        c->unpiped_max_tiles = value;
     }
     else if (!strcmp(name, "fwd_waves")) {
         if (value != 0 && value != 1 && value != 4) return fail(D2D_ERR_INVALID, "fwd_waves must be 0, 1 or 4, got %lld", (long long)value);

@@ -330,6 +330,9 @@ int d2d_power_map_wave_cycles(d2d_ctx* ctx, const d2d_params* params, const floa
  *                   in three rotating sets and is built on side streams beside the previous launches' sweeps; the work
  *                   history a schedule is sorted by is then three launches old instead of one; zero = on the
  *                   launch's own stream, in front of its sweep (same results)
+ *   "unpiped_max_tiles": launches of orders <= 1 over at most this many 8 x 8 patches (default 256) prepare on the sweep's own
+ *                   stream whatever "pipeline" says: a small call is launch latency, and the side stream's fork and join cost it
+ *                   8 us of 45 (same results); 0 = never
  *   "side_stream": zero = the schedule's sort is never moved to a stream of its own; "fwd_waves": patches per workgroup
  *                   of the sweep with region lists (0 default: 4 when the per-wall LDS table is big, else 1)
  *   "region_budget_mb" also bounds the growth of the list pool: it starts at 256 MB and is quadrupled (up to the budget,
