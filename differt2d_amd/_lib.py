@@ -190,6 +190,16 @@ def device_count() -> int:
     return n.value
 
 
+def count_candidates(num_nodes: int, min_order: int = 0, max_order: int = 1, allowed=None) -> int:
+    """How many candidates :func:`enumerate_candidates` would return (no list is built)."""
+    lib = load()
+    a = None if allowed is None else np.ascontiguousarray(allowed, dtype=np.uint8)
+    ap = None if a is None else a.ctypes.data_as(C.c_void_p)
+    n = C.c_int64(0)
+    check(lib.d2d_count_candidates(int(num_nodes), ap, int(min_order), int(max_order), C.byref(n)))
+    return int(n.value)
+
+
 def enumerate_candidates(num_nodes: int, min_order: int = 0, max_order: int = 1, allowed=None):
     """Host-native candidate enumeration (no GPU needed): list of int32 arrays of shape (k,)."""
     lib = load()

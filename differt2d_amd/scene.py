@@ -544,7 +544,13 @@ class Scene(Plottable):
             return None
         name, extra = native
         solver = self._solver_of(path_cls)
-        cands = self.all_path_candidates(min_order, max_order, order=order, filter_objects=filter_objects)
+        if solver == "image":
+            # (ImagePath draws nothing per candidate: only WHETHER there are candidates matters here -- counted in the library
+            # instead of building N^K index arrays in Python per call)
+            lo, hi = (order, order) if order is not None else (min_order, max_order)
+            cands = [None] * min(1, L.count_candidates(len(self.objects), lo, hi, self._allowed_mask(filter_objects)))
+        else:
+            cands = self.all_path_candidates(min_order, max_order, order=order, filter_objects=filter_objects)
         rx_keys = list(self.receivers)
         rx = np.stack([r.xy for r in self.receivers.values()]).astype(F)
         pkw = dict(path_cls_kwargs or {})
