@@ -308,16 +308,19 @@ class RIS(Wall):
 def objects_to_tables(objects: Sequence[Object]):
     """(xys[N,2,2], kind[N], phi[N]) for ``d2d_set_scene``."""
     n = len(objects)
-    xys = np.zeros((n, 2, 2), F)
-    kind = np.zeros(n, np.uint8)
+    try:
+        rows = [o.as_rows() for o in objects]
+        kinds = [o.kind for o in objects]
+    except AttributeError:
+        bad = next(o for o in objects if not hasattr(o, "as_rows") or not hasattr(o, "kind"))
+        raise L.D2DUnsupported(-4, f"object {bad!r} is not a native Wall / RIS / Vertex") from None
+    xys = np.array(rows, F).reshape(n, 2, 2) if n else np.zeros((0, 2, 2), F)  # (one conversion for the whole scene: every sweep call passes here)
+    kind = np.array(kinds, np.uint8) if n else np.zeros(0, np.uint8)
     phi = np.full(n, math.pi / 4, F)
-    for i, o in enumerate(objects):
-        if not hasattr(o, "as_rows") or not hasattr(o, "kind"):
-            raise L.D2DUnsupported(-4, f"object {o!r} is not a native Wall / RIS / Vertex")
-        xys[i] = o.as_rows()
-        kind[i] = o.kind
-        if isinstance(o, RIS):
-            phi[i] = o.phi
+    if L.D2D_RIS in kinds:
+        for i, o in enumerate(objects):
+            if isinstance(o, RIS):
+                phi[i] = o.phi
     return xys, kind, phi
 
 
